@@ -1,0 +1,556 @@
+"""TEST INFRASTRUCTURE ONLY -- functional PyTorch-CPU fp32 restatement of the reference hot path.
+
+This is the parity oracle for the HIP engine.  It restates, in a functional style (a flat
+``{state_dict key: tensor}`` parameter dict instead of nn.Modules), the arithmetic of
+
+  * the sub-networks of ``models/vae_gan.py``   (Encoder :63-96, Decoder :99-132,
+    Discriminator :135-187, CognitiveEncoder :190-232, WaeDiscriminator :499-529),
+  * ``VaeGan.forward`` / ``VaeGan.loss``         (models/vae_gan.py:271-287, :302-320),
+  * ``VaeGanCognitive.forward``                  (models/vae_gan.py:352-395),
+  * the inline training-step bodies of ``train/train_vgan_stage1.py:330-432``,
+    ``train/train_vgan_stage2.py:331-407``, ``train/train_vgan_stage3.py:336-411``,
+    ``train/train_wae_stage1.py:259-311`` and ``train/wae_vgan_stage1.py:277-454``.
+
+Pinning: ``tests/test_oracle_golden.py`` checks every function here against the golden vectors in
+``tests/golden/*.npz`` that ``tests/golden/make_golden.py`` produced by importing and running the
+real reference (``/root/reference``) in the build container.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+State = Dict[str, Tensor]
+
+
+# ----------------------------------------------------------------------------------------------
+# architecture description  (configs/models_config.py:3-31)
+# ----------------------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class ArchCfg:
+    image_size: int = 64
+    fc_input: int = 8
+    fc_output: int = 1024
+    fc_input_gan: int = 8
+    fc_output_gan: int = 512
+    stride_gan: int = 1
+    latent_dim: int = 128
+    output_pad_dec: Tuple[bool, bool, bool] = (True, True, True)
+    encoder_channels: Tuple[int, ...] = (64, 128, 256)
+    decoder_channels: Tuple[int, ...] = (256, 128, 32, 3)
+    discrim_channels: Tuple[int, ...] = (32, 128, 256, 256, 512)
+    kernel_size: int = 5
+    stride: int = 2
+    padding: int = 2
+
+    @staticmethod
+    def px64() -> "ArchCfg":
+        """64x64 settings: the commented block configs/models_config.py:23-31 (+ :9)."""
+        return ArchCfg()
+
+    @staticmethod
+    def px100() -> "ArchCfg":
+        """as-shipped 'paper settings', configs/models_config.py:12-21."""
+        return ArchCfg(image_size=100, fc_input=13, fc_output=1024, fc_input_gan=7, fc_output_gan=256,
+                       stride_gan=2, latent_dim=512, output_pad_dec=(False, True, True),
+                       decoder_channels=(256, 128, 64, 3))
+
+    @staticmethod
+    def px128() -> "ArchCfg":
+        """128x128 variant used by BASELINE config 5: fc_input=16, stride_gan=2."""
+        return ArchCfg(image_size=128, fc_input=16, fc_input_gan=8, fc_output_gan=512, stride_gan=2)
+
+
+# ----------------------------------------------------------------------------------------------
+# state-dict specifications (key order == reference ``state_dict()`` order)
+# ----------------------------------------------------------------------------------------------
+def _bn_spec(pre: str, c: int):
+    return [(pre + "weight", (c,), "gamma"), (pre + "bias", (c,), "beta"),
+            (pre + "running_mean", (c,), "rm"), (pre + "running_var", (c,), "rv"),
+            (pre + "num_batches_tracked", (), "nbt")]
+
+
+def encoder_spec(cfg: ArchCfg, pre: str = "encoder.", channel_in: int = 3):
+    k = cfg.kernel_size
+    out, cin = [], channel_in
+    for i, c in enumerate(cfg.encoder_channels[:3]):
+        out.append((f"{pre}conv.{i}.conv.weight", (c, cin, k, k), "w"))
+        out += _bn_spec(f"{pre}conv.{i}.bn.", c)
+        cin = c
+    out.append((f"{pre}fc.0.weight", (cfg.fc_output, cfg.fc_input * cfg.fc_input * cin), "w"))
+    out += _bn_spec(f"{pre}fc.1.", cfg.fc_output)
+    for h in ("l_mu", "l_var"):
+        out.append((f"{pre}{h}.weight", (cfg.latent_dim, cfg.fc_output), "w"))
+        out.append((f"{pre}{h}.bias", (cfg.latent_dim,), "b"))
+    return out
+
+
+def decoder_spec(cfg: ArchCfg, pre: str = "decoder.", size: int = None):
+    k = cfg.kernel_size
+    size = cfg.encoder_channels[2] if size is None else size
+    feat = cfg.fc_input * cfg.fc_input * size
+    out = [(f"{pre}fc.0.weight", (feat, cfg.latent_dim), "w")]
+    out += _bn_spec(f"{pre}fc.1.", feat)
+    chans = [(size, size), (size, cfg.decoder_channels[1]), (cfg.decoder_channels[1], cfg.decoder_channels[2])]
+    for i, (ci, co) in enumerate(chans):
+        out.append((f"{pre}conv.{i}.conv.weight", (ci, co, k, k), "w"))  # ConvTranspose2d: (Cin, Cout, k, k)
+        out += _bn_spec(f"{pre}conv.{i}.bn.", co)
+    out.append((f"{pre}conv.3.0.weight", (cfg.decoder_channels[3], cfg.decoder_channels[2], 5, 5), "w"))
+    out.append((f"{pre}conv.3.0.bias", (cfg.decoder_channels[3],), "b"))
+    return out
+
+
+def discriminator_spec(cfg: ArchCfg, pre: str = "discriminator."):
+    k = cfg.kernel_size
+    d = cfg.discrim_channels
+    out = [(f"{pre}conv.0.0.weight", (d[0], 3, 5, 5), "w"), (f"{pre}conv.0.0.bias", (d[0],), "b")]
+    cin = d[0]
+    for i in (1, 2, 3):
+        out.append((f"{pre}conv.{i}.conv.weight", (d[i], cin, k, k), "w"))
+        out += _bn_spec(f"{pre}conv.{i}.bn.", d[i])
+        cin = d[i]
+    out.append((f"{pre}fc.0.weight", (cfg.fc_output_gan, cfg.fc_input_gan * cfg.fc_input_gan * cin), "w"))
+    out += _bn_spec(f"{pre}fc.1.", cfg.fc_output_gan)
+    out.append((f"{pre}fc.3.weight", (1, cfg.fc_output_gan), "w"))
+    out.append((f"{pre}fc.3.bias", (1,), "b"))
+    return out
+
+
+def cognitive_encoder_spec(cfg: ArchCfg, n_voxels: int, pre: str = "encoder."):
+    out = [(f"{pre}fc1.0.weight", (1024, n_voxels), "w")]
+    out += _bn_spec(f"{pre}fc1.1.", 1024)
+    for h in ("l_mu", "l_var"):
+        out.append((f"{pre}{h}.weight", (cfg.latent_dim, 1024), "w"))
+        out.append((f"{pre}{h}.bias", (cfg.latent_dim,), "b"))
+    return out
+
+
+def wae_discriminator_spec(cfg: ArchCfg, pre: str = "discriminator.", dim_h: int = 512):
+    dims = [cfg.latent_dim, dim_h, dim_h, dim_h, dim_h, 1]
+    out = []
+    for j, idx in enumerate((0, 2, 4, 6, 8)):
+        out.append((f"{pre}main.{idx}.weight", (dims[j + 1], dims[j]), "wn"))
+        out.append((f"{pre}main.{idx}.bias", (dims[j + 1],), "b"))
+    return out
+
+
+def vaegan_spec(cfg: ArchCfg, pre: str = ""):
+    return encoder_spec(cfg, pre + "encoder.") + decoder_spec(cfg, pre + "decoder.") + \
+        discriminator_spec(cfg, pre + "discriminator.")
+
+
+def fill_state(spec, seed: int, perturb: bool = False) -> State:
+    """Deterministic parameter recipe shared by the golden generator, the oracle and the engine tests.
+
+    Mirrors ``VaeGan.init_parameters`` (models/vae_gan.py:252-264): conv/deconv/linear weights
+    ~ U(+-1/sqrt(prod(shape[1:]))/sqrt(3)), biases 0, BN gamma 1 / beta 0 -- but drawn from a numpy
+    MT19937 stream (stable across torch versions).  ``perturb=True`` additionally jitters biases and
+    BN affine parameters so that those code paths cannot hide behind 0/1 values.
+    """
+    rs = np.random.RandomState(seed)
+    out: State = {}
+    for key, shape, kind in spec:
+        if kind == "w":
+            s = 1.0 / math.sqrt(float(np.prod(shape[1:]))) / math.sqrt(3.0)
+            v = rs.uniform(-s, s, shape).astype(np.float32)
+        elif kind == "wn":  # WaeDiscriminator init, models/vae_gan.py:522-525
+            v = rs.normal(0.0, 0.0099999, shape).astype(np.float32)
+        elif kind == "b":
+            v = rs.uniform(-0.05, 0.05, shape).astype(np.float32) if perturb else np.zeros(shape, np.float32)
+        elif kind == "gamma":
+            v = (1.0 + rs.uniform(-0.2, 0.2, shape)).astype(np.float32) if perturb else np.ones(shape, np.float32)
+        elif kind == "beta":
+            v = rs.uniform(-0.1, 0.1, shape).astype(np.float32) if perturb else np.zeros(shape, np.float32)
+        elif kind == "rm":
+            v = np.zeros(shape, np.float32)
+        elif kind == "rv":
+            v = np.ones(shape, np.float32)
+        elif kind == "nbt":
+            v = np.zeros(shape, np.int64)
+        else:
+            raise ValueError(kind)
+        out[key] = torch.from_numpy(np.ascontiguousarray(v))
+    return out
+
+
+def param_keys(spec) -> List[str]:
+    return [k for k, _, kind in spec if kind in ("w", "wn", "b", "gamma", "beta")]
+
+
+def synth_batch(batch: int, cfg: ArchCfg, n_voxels: int = 0, seed: int = 1234, steps: int = 1):
+    """Synthetic inputs: x~U[-1,1], fmri~N(0,1), noise~N(0,1), all numpy RandomState.
+
+    ``noise`` has shape (steps, 4, B, z): per step [0]=eps, [1]=z_p, [2]=eps_teacher / z_fake, [3]=spare."""
+    x = np.random.RandomState(seed).uniform(-1, 1, (batch, 3, cfg.image_size, cfg.image_size)).astype(np.float32)
+    out = {"x": torch.from_numpy(x)}
+    if n_voxels:
+        out["fmri"] = torch.from_numpy(
+            np.random.RandomState(seed + 1).standard_normal((batch, n_voxels)).astype(np.float32))
+    nz = np.random.RandomState(seed + 2).standard_normal((steps, 4, batch, cfg.latent_dim)).astype(np.float32)
+    out["noise"] = torch.from_numpy(nz)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# sub-network forwards
+# ----------------------------------------------------------------------------------------------
+def _bn(P: State, pre: str, x: Tensor, train: bool) -> Tensor:
+    """BatchNorm with momentum 0.9, eps 1e-5 (models/vae_gan.py:21,54,81,108,158)."""
+    y = F.batch_norm(x, P[pre + "running_mean"], P[pre + "running_var"], P[pre + "weight"], P[pre + "bias"],
+                     train, 0.9, 1e-5)
+    if train:
+        P[pre + "num_batches_tracked"] += 1
+    return y
+
+
+def encoder_fwd(P: State, pre: str, x: Tensor, cfg: ArchCfg, train: bool = True):
+    """Encoder.forward, models/vae_gan.py:87-93."""
+    h = x
+    for i in range(3):
+        h = F.conv2d(h, P[f"{pre}conv.{i}.conv.weight"], None, cfg.stride, cfg.padding)
+        h = F.relu(_bn(P, f"{pre}conv.{i}.bn.", h, train))
+    h = h.reshape(h.shape[0], -1)
+    h = F.relu(_bn(P, f"{pre}fc.1.", F.linear(h, P[f"{pre}fc.0.weight"]), train))
+    mu = F.linear(h, P[f"{pre}l_mu.weight"], P[f"{pre}l_mu.bias"])
+    logvar = F.linear(h, P[f"{pre}l_var.weight"], P[f"{pre}l_var.bias"])
+    return mu, logvar
+
+
+def decoder_fwd(P: State, pre: str, z: Tensor, cfg: ArchCfg, train: bool = True):
+    """Decoder.forward, models/vae_gan.py:125-129."""
+    h = F.relu(_bn(P, f"{pre}fc.1.", F.linear(z, P[f"{pre}fc.0.weight"]), train))
+    h = h.reshape(h.shape[0], -1, cfg.fc_input, cfg.fc_input)
+    for i in range(3):
+        h = F.conv_transpose2d(h, P[f"{pre}conv.{i}.conv.weight"], None, cfg.stride, cfg.padding,
+                               output_padding=1 if cfg.output_pad_dec[i] else 0)
+        h = F.relu(_bn(P, f"{pre}conv.{i}.bn.", h, train))
+    h = F.conv2d(h, P[f"{pre}conv.3.0.weight"], P[f"{pre}conv.3.0.bias"], 1, 2)
+    return torch.tanh(h)
+
+
+def discriminator_fwd(P: State, pre: str, x_orig: Tensor, x_pred: Tensor, x_samp: Tensor, mode: str,
+                      cfg: ArchCfg, train: bool = True, recon_level: int = 3):
+    """Discriminator.forward, models/vae_gan.py:163-183 (mode 'REC' or 'GAN')."""
+    h = torch.cat((x_orig, x_pred, x_samp), 0)
+    h = F.relu(F.conv2d(h, P[f"{pre}conv.0.0.weight"], P[f"{pre}conv.0.0.bias"], cfg.stride_gan, 2))
+    for i in (1, 2, 3):
+        raw = F.conv2d(h, P[f"{pre}conv.{i}.conv.weight"], None, cfg.stride, cfg.padding)
+        if mode == "REC" and i == recon_level:
+            # reference still runs bn+relu on this block before returning (vae_gan.py:25-30)
+            _bn(P, f"{pre}conv.{i}.bn.", raw, train)
+            return raw.reshape(raw.shape[0], -1)
+        h = F.relu(_bn(P, f"{pre}conv.{i}.bn.", raw, train))
+    h = h.reshape(h.shape[0], -1)
+    h = F.relu(_bn(P, f"{pre}fc.1.", F.linear(h, P[f"{pre}fc.0.weight"]), train))
+    h = F.linear(h, P[f"{pre}fc.3.weight"], P[f"{pre}fc.3.bias"])
+    return torch.sigmoid(h)
+
+
+def cognitive_encoder_fwd(P: State, pre: str, fmri: Tensor, train: bool = True):
+    """CognitiveEncoder.forward, models/vae_gan.py:224-229."""
+    h = F.relu(_bn(P, f"{pre}fc1.1.", F.linear(fmri, P[f"{pre}fc1.0.weight"]), train))
+    mu = F.linear(h, P[f"{pre}l_mu.weight"], P[f"{pre}l_mu.bias"])
+    logvar = F.linear(h, P[f"{pre}l_var.weight"], P[f"{pre}l_var.bias"])
+    return mu, logvar
+
+
+def wae_discriminator_fwd(P: State, pre: str, z: Tensor):
+    """WaeDiscriminator.forward, models/vae_gan.py:527-529."""
+    h = z
+    for idx in (0, 2, 4, 6):
+        h = F.relu(F.linear(h, P[f"{pre}main.{idx}.weight"], P[f"{pre}main.{idx}.bias"]))
+    return torch.sigmoid(F.linear(h, P[f"{pre}main.8.weight"], P[f"{pre}main.8.bias"]))
+
+
+def reparameterize(mu: Tensor, logvar: Tensor, eps: Tensor) -> Tensor:
+    """VaeGan.reparameterize (models/vae_gan.py:266-269) with the normal draw passed explicitly."""
+    return eps * torch.exp(0.5 * logvar) + mu
+
+
+# ----------------------------------------------------------------------------------------------
+# wrapper forwards + loss
+# ----------------------------------------------------------------------------------------------
+def vaegan_forward(P: State, x: Tensor, eps: Tensor, z_p: Tensor, cfg: ArchCfg, pre: str = ""):
+    """VaeGan.forward (train branch), models/vae_gan.py:276-287.  RNG order: eps, then z_p."""
+    mu, logvar = encoder_fwd(P, pre + "encoder.", x, cfg)
+    z = reparameterize(mu, logvar, eps)
+    x_tilde = decoder_fwd(P, pre + "decoder.", z, cfg)
+    x_p = decoder_fwd(P, pre + "decoder.", z_p, cfg)
+    disc_layer = discriminator_fwd(P, pre + "discriminator.", x, x_tilde, x_p, "REC", cfg)
+    disc_class = discriminator_fwd(P, pre + "discriminator.", x, x_tilde, x_p, "GAN", cfg)
+    return dict(x_tilde=x_tilde, x_p=x_p, disc_class=disc_class, disc_layer=disc_layer, mus=mu, log_variances=logvar)
+
+
+def vaegan_loss(x, x_tilde, dl_o, dl_p, dl_s, dc_o, dc_p, dc_s, mus, variances):
+    """VaeGan.loss == VaeGanCognitive.loss, models/vae_gan.py:302-320 / :411-432."""
+    nle = 0.5 * (x.reshape(len(x), -1) - x_tilde.reshape(len(x_tilde), -1)) ** 2
+    kl = -0.5 * torch.sum(-variances.exp() - mus.pow(2) + variances + 1, 1)
+    mse = torch.sum(0.5 * (dl_o - dl_p) ** 2, 1)
+    bce_o = -torch.log(dc_o + 1e-3)
+    bce_p = -torch.log(1 - dc_p + 1e-3)
+    bce_s = -torch.log(1 - dc_s + 1e-3)
+    return nle, kl, mse, bce_o, bce_p, bce_s
+
+
+def cognitive_forward(P: State, fmri: Tensor, image: Tensor, noise: Tensor, cfg: ArchCfg, stage: int,
+                      teacher: bool = True):
+    """VaeGanCognitive.forward (train, mode='vae'), models/vae_gan.py:359-395.
+
+    noise[0] = eps of the cognitive encoder, noise[1] = z_p, noise[2] = eps of the teacher encoder
+    (only drawn at stage 2).  RNG order in the reference: eps_cog, eps_teacher, z_p.
+    Keys: cognitive encoder under ``encoder.``, decoder ``decoder.``, discriminator ``discriminator.``,
+    teacher encoder under ``teacher_net.encoder.``.
+    """
+    mu, logvar = cognitive_encoder_fwd(P, "encoder.", fmri)
+    z = reparameterize(mu, logvar, noise[0])
+    x_tilde = decoder_fwd(P, "decoder.", z, cfg)
+    gt_x = image
+    if teacher and stage == 2:
+        mu_t, lv_t = encoder_fwd(P, "teacher_net.encoder.", image, cfg)
+        gt_x = decoder_fwd(P, "decoder.", reparameterize(mu_t, lv_t, noise[2]), cfg)
+    x_p = decoder_fwd(P, "decoder.", noise[1], cfg)
+    disc_layer = discriminator_fwd(P, "discriminator.", gt_x, x_tilde, x_p, "REC", cfg)
+    disc_class = discriminator_fwd(P, "discriminator.", gt_x, x_tilde, x_p, "GAN", cfg)
+    return dict(gt_x=gt_x, x_tilde=x_tilde, x_p=x_p, disc_class=disc_class, disc_layer=disc_layer,
+                mus=mu, log_variances=logvar)
+
+
+# ----------------------------------------------------------------------------------------------
+# optimizers (functional restatement of torch.optim.RMSprop / Adam as the scripts configure them)
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class OptState:
+    kind: str = "rmsprop"          # 'rmsprop' (train_vgan_stage1.py:275) or 'adam' (train_wae_stage1.py:221)
+    lr: float = 1e-4
+    alpha: float = 0.9
+    eps: float = 1e-8
+    betas: Tuple[float, float] = (0.5, 0.999)
+    step: int = 0
+    bufs: Dict[str, Tensor] = field(default_factory=dict)
+
+
+@torch.no_grad()
+def opt_step(P: State, keys: List[str], grads: List[Tensor], opt: OptState, clamp: float = None):
+    opt.step += 1
+    for k, g in zip(keys, grads):
+        if g is None:
+            continue
+        if clamp is not None:
+            g = g.clamp(-clamp, clamp)
+        p = P[k]
+        if opt.kind == "rmsprop":
+            sq = opt.bufs.setdefault(k, torch.zeros_like(p))
+            sq.mul_(opt.alpha).addcmul_(g, g, value=1 - opt.alpha)
+            p.addcdiv_(g, sq.sqrt().add_(opt.eps), value=-opt.lr)
+        else:  # adam, amsgrad off, weight_decay 0
+            b1, b2 = opt.betas
+            m = opt.bufs.setdefault(k + "/m", torch.zeros_like(p))
+            v = opt.bufs.setdefault(k + "/v", torch.zeros_like(p))
+            m.mul_(b1).add_(g, alpha=1 - b1)
+            v.mul_(b2).addcmul_(g, g, value=1 - b2)
+            bc1 = 1 - b1 ** opt.step
+            bc2 = 1 - b2 ** opt.step
+            denom = (v.sqrt() / math.sqrt(bc2)).add_(opt.eps)
+            p.addcdiv_(m, denom, value=-opt.lr / bc1)
+
+
+def _leafify(P: State, keys: List[str]):
+    for k in keys:
+        P[k] = P[k].detach().requires_grad_(True)
+
+
+def _grads(loss: Tensor, P: State, keys: List[str], retain: bool, literal_all: List[str] = None):
+    """Gradient of ``loss`` w.r.t. P[keys] at the current (pre-update) weights.
+
+    ``literal_all``: also differentiate w.r.t. every other trainable key and throw those away --
+    this reproduces the cost of the reference's full ``loss.backward()`` traversal
+    (train_vgan_stage1.py:412,422,430) for the CPU-baseline timing; values are identical.
+    """
+    if literal_all is not None:
+        allk = list(keys) + [k for k in literal_all if k not in keys]
+        g = torch.autograd.grad(loss, [P[k] for k in allk], retain_graph=retain, allow_unused=True)
+        return list(g[:len(keys)])
+    return list(torch.autograd.grad(loss, [P[k] for k in keys], retain_graph=retain, allow_unused=True))
+
+
+@dataclass
+class GanHyper:
+    """configs/gan_config.py:19-31 defaults consumed by the step bodies."""
+    lr: float = 1e-4
+    lambda_mse: float = 1e-6
+    margin: float = 0.35
+    equilibrium: float = 0.68
+
+
+def equilibrium_gate(bce_o_mean: float, bce_p_mean: float, hp: GanHyper):
+    """train_vgan_stage1.py:396-404."""
+    train_dis, train_dec = True, True
+    if bce_o_mean < hp.equilibrium - hp.margin or bce_p_mean < hp.equilibrium - hp.margin:
+        train_dis = False
+    if bce_o_mean > hp.equilibrium + hp.margin or bce_p_mean > hp.equilibrium + hp.margin:
+        train_dec = False
+    if (not train_dec) and (not train_dis):
+        train_dis, train_dec = True, True
+    return train_dis, train_dec
+
+
+def _compose_losses(fw, x_real, B, hp: GanHyper):
+    dl, dc = fw["disc_layer"], fw["disc_class"]
+    nle, kl, mse, bo, bp, bs = vaegan_loss(x_real, fw["x_tilde"], dl[:B], dl[B:-B], dl[-B:], dc[:B], dc[B:-B],
+                                           dc[-B:], fw["mus"], fw["log_variances"])
+    loss_enc = torch.sum(kl) + torch.sum(mse)                                   # stage1.py:369
+    loss_dis = torch.sum(bo) + torch.sum(bp) + torch.sum(bs)                   # :370-371
+    loss_dec = torch.sum(hp.lambda_mse * mse) - (1.0 - hp.lambda_mse) * loss_dis  # :372
+    logs = dict(loss_encoder=loss_enc.item(), loss_discriminator=loss_dis.item(), loss_decoder=loss_dec.item(),
+                nle=torch.sum(nle).item(), kl=torch.sum(kl).item(), mse=torch.sum(mse).item(),
+                bce_orig=torch.sum(bo).item(), bce_pred=torch.sum(bp).item(), bce_samp=torch.sum(bs).item())
+    return loss_enc, loss_dis, loss_dec, logs
+
+
+def stage1_step(P: State, opts: Dict[str, OptState], x: Tensor, eps: Tensor, z_p: Tensor, cfg: ArchCfg,
+                hp: GanHyper = GanHyper(), literal: bool = False, keep_grads: bool = False):
+    """One Stage-I VAE/GAN step, mode 'vae-gan' (train/train_vgan_stage1.py:330-432).
+
+    One forward, three gradient sets at the pre-update weights, gate, three RMSprop steps.
+    """
+    spec = vaegan_spec(cfg)
+    enc_k = param_keys(encoder_spec(cfg))
+    dec_k = param_keys(decoder_spec(cfg))
+    dis_k = param_keys(discriminator_spec(cfg))
+    _leafify(P, enc_k + dec_k + dis_k)
+    B = x.shape[0]
+    fw = vaegan_forward(P, x, eps, z_p, cfg)
+    loss_enc, loss_dis, loss_dec, logs = _compose_losses(fw, x, B, hp)
+    train_dis, train_dec = equilibrium_gate(logs["bce_orig"] / B, logs["bce_pred"] / B, hp)
+    allk = enc_k + dec_k + dis_k if literal else None
+    g_enc = _grads(loss_enc, P, enc_k, True, allk)
+    g_dec = _grads(loss_dec, P, dec_k, True, allk)
+    g_dis = _grads(loss_dis, P, dis_k, False, allk)
+    opt_step(P, enc_k, g_enc, opts["encoder"])
+    if train_dec:
+        opt_step(P, dec_k, g_dec, opts["decoder"])
+    if train_dis:
+        opt_step(P, dis_k, g_dis, opts["discriminator"])
+    for k in enc_k + dec_k + dis_k:
+        P[k] = P[k].detach()
+    logs.update(train_dis=train_dis, train_dec=train_dec)
+    out = dict(logs=logs, fw={k: v.detach() for k, v in fw.items()})
+    if keep_grads:
+        out["grads"] = {**dict(zip(enc_k, g_enc)), **dict(zip(dec_k, g_dec)), **dict(zip(dis_k, g_dis))}
+    return out
+
+
+def stage2_step(P: State, opts: Dict[str, OptState], fmri: Tensor, image: Tensor, noise: Tensor, cfg: ArchCfg,
+                n_voxels: int, hp: GanHyper = GanHyper(), keep_grads: bool = False):
+    """Stage-II step (train/train_vgan_stage2.py:321-407): decoder frozen, teacher distillation,
+    encoder + discriminator trained, no gate, gradients clamped to +-1."""
+    enc_k = param_keys(cognitive_encoder_spec(cfg, n_voxels))
+    dis_k = param_keys(discriminator_spec(cfg))
+    _leafify(P, enc_k + dis_k)
+    B = fmri.shape[0]
+    fw = cognitive_forward(P, fmri, image, noise, cfg, stage=2, teacher=True)
+    loss_enc, loss_dis, loss_dec, logs = _compose_losses(fw, fw["gt_x"], B, hp)
+    g_enc = _grads(loss_enc, P, enc_k, True)
+    g_dis = _grads(loss_dis, P, dis_k, False)
+    opt_step(P, enc_k, g_enc, opts["encoder"], clamp=1.0)
+    opt_step(P, dis_k, g_dis, opts["discriminator"], clamp=1.0)
+    for k in enc_k + dis_k:
+        P[k] = P[k].detach()
+    logs.update(train_dis=True, train_dec=False)
+    out = dict(logs=logs, fw={k: v.detach() for k, v in fw.items()})
+    if keep_grads:
+        out["grads"] = {**dict(zip(enc_k, g_enc)), **dict(zip(dis_k, g_dis))}
+    return out
+
+
+def stage3_step(P: State, opts: Dict[str, OptState], fmri: Tensor, image: Tensor, noise: Tensor, cfg: ArchCfg,
+                n_voxels: int, hp: GanHyper = GanHyper(), keep_grads: bool = False):
+    """Stage-III step (train/train_vgan_stage3.py:324-411): cognitive encoder frozen, decoder +
+    discriminator trained, equilibrium gate on, gradients clamped to +-1."""
+    dec_k = param_keys(decoder_spec(cfg))
+    dis_k = param_keys(discriminator_spec(cfg))
+    _leafify(P, dec_k + dis_k)
+    B = fmri.shape[0]
+    fw = cognitive_forward(P, fmri, image, noise, cfg, stage=3, teacher=False)
+    loss_enc, loss_dis, loss_dec, logs = _compose_losses(fw, image, B, hp)
+    train_dis, train_dec = equilibrium_gate(logs["bce_orig"] / B, logs["bce_pred"] / B, hp)
+    g_dec = _grads(loss_dec, P, dec_k, True)
+    g_dis = _grads(loss_dis, P, dis_k, False)
+    if train_dec:
+        opt_step(P, dec_k, g_dec, opts["decoder"], clamp=1.0)
+    if train_dis:
+        opt_step(P, dis_k, g_dis, opts["discriminator"], clamp=1.0)
+    for k in dec_k + dis_k:
+        P[k] = P[k].detach()
+    logs.update(train_dis=train_dis, train_dec=train_dec)
+    out = dict(logs=logs, fw={k: v.detach() for k, v in fw.items()})
+    if keep_grads:
+        out["grads"] = {**dict(zip(dec_k, g_dec)), **dict(zip(dis_k, g_dis))}
+    return out
+
+
+def wae_stage1_step(P: State, opts: Dict[str, OptState], x: Tensor, z_fake_noise: Tensor, cfg: ArchCfg,
+                    keep_grads: bool = False):
+    """WAE Stage-I step (train/train_wae_stage1.py:259-311).
+
+    Phase D: latent discriminator on encoder means vs 0.5*N(0,1) (:275-288); phase G: encoder+decoder on
+    pixel reconstruction + GAN penalty with the *updated* discriminator (:296-311).
+    """
+    enc_k = param_keys(encoder_spec(cfg))
+    dec_k = param_keys(decoder_spec(cfg))
+    dis_k = param_keys(wae_discriminator_spec(cfg))
+    _leafify(P, dis_k)
+    with torch.no_grad():
+        z_real, _ = encoder_fwd(P, "encoder.", x, cfg)          # frozen encoder, still train-mode BN
+    z_fake = z_fake_noise * 0.5                                 # :276
+    d_real = wae_discriminator_fwd(P, "discriminator.", z_real)
+    d_fake = wae_discriminator_fwd(P, "discriminator.", z_fake)
+    l_fake = -10 * torch.sum(torch.log(d_fake + 1e-3))          # :281
+    l_real = -10 * torch.sum(torch.log(1 - d_real + 1e-3))      # :282
+    # two separate backward passes accumulate into .grad in the reference (:283-284)
+    g_dis = [a + b for a, b in zip(_grads(l_fake, P, dis_k, True), _grads(l_real, P, dis_k, False))]
+    opt_step(P, dis_k, g_dis, opts["discriminator"])
+    for k in dis_k:
+        P[k] = P[k].detach()
+    _leafify(P, enc_k + dec_k)
+    z_real, _ = encoder_fwd(P, "encoder.", x, cfg)              # :296, second encoder pass
+    x_recon = decoder_fwd(P, "decoder.", z_real, cfg)
+    d_real2 = wae_discriminator_fwd(P, "discriminator.", z_real)
+    l_rec = torch.sum(torch.sum(0.5 * (x_recon - x) ** 2, 1))   # :301
+    l_pen = -10 * torch.sum(torch.log(d_real2 + 1e-3))          # :303
+    g_rec = _grads(l_rec, P, enc_k + dec_k, True)               # :306
+    g_pen = _grads(l_pen, P, enc_k + dec_k, False)              # :307 (decoder gets no penalty gradient)
+    g = [a if b is None else a + b for a, b in zip(g_rec, g_pen)]
+    opt_step(P, enc_k, g[:len(enc_k)], opts["encoder"])
+    opt_step(P, dec_k, g[len(enc_k):], opts["decoder"])
+    for k in enc_k + dec_k:
+        P[k] = P[k].detach()
+    logs = dict(loss_reconstruction=l_rec.item(), loss_penalty=l_pen.item(),
+                loss_discriminator_fake=l_fake.item(), loss_discriminator_real=l_real.item())
+    out = dict(logs=logs, fw=dict(x_recon=x_recon.detach(), z_real=z_real.detach()))
+    if keep_grads:
+        out["grads"] = {**dict(zip(dis_k, g_dis)), **dict(zip(enc_k + dec_k, g))}
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# summaries used by golden fixtures
+# ----------------------------------------------------------------------------------------------
+def tensor_summary(t: Tensor, n: int = 8) -> np.ndarray:
+    """[L2 norm, sum, first n, last n] as float64 -- a compact fingerprint for golden fixtures."""
+    f = t.detach().double().reshape(-1)
+    head = f[:n]
+    tail = f[-n:]
+    pad = n - head.numel()
+    if pad > 0:
+        head = torch.cat([head, torch.zeros(pad, dtype=torch.float64)])
+        tail = torch.cat([tail, torch.zeros(pad, dtype=torch.float64)])
+    return torch.cat([f.norm().reshape(1), f.sum().reshape(1), head, tail]).numpy()

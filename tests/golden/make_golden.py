@@ -1,0 +1,396 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/*.npz by RUNNING THE REAL REFERENCE.
+
+Run in the build container only (needs /root/reference; that tree never travels):
+
+    python tests/golden/make_golden.py            # writes tests/golden/<case>.npz
+
+What it does
+  * imports ``models.vae_gan`` / ``configs.models_config`` from /root/reference (torchvision is stubbed:
+    only ``ResNetEncoder`` uses it), switches the config module to the wanted resolution *before* import,
+  * loads the deterministic parameter recipe (oracle.fill_state) into the reference nn.Modules,
+  * checks once per case that calling the sub-modules in the documented order with explicit noise equals
+    the reference's own ``model(x)`` under a fixed torch seed (RNG draw order),
+  * runs the inline step bodies of the training scripts (restated here because the scripts cannot be
+    imported: tensorboard/torchvision/nibabel are missing and their optimizer ordering needs torch<=1.4):
+    literal ``loss.backward()`` x3 at the pre-update weights, then ``torch.optim`` steps,
+  * stores compact fingerprints: logged losses, gate flags, per-tensor [norm,sum,first8,last8] of every
+    gradient, every post-step state_dict entry and every forward output.
+
+Fixtures are data only (numbers); no reference source is stored.
+"""
+import importlib
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+warnings.filterwarnings("ignore")
+
+from oracle import vaegan_oracle as O  # noqa: E402  (recipe + fingerprints only)
+
+REF = "/root/reference"
+
+
+def load_reference(cfg: O.ArchCfg):
+    """(Re-)import the reference model module under architecture ``cfg``."""
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    tv = types.ModuleType("torchvision")
+    tvm = types.ModuleType("torchvision.models")
+    tv.models = tvm
+    sys.modules["torchvision"] = tv
+    sys.modules["torchvision.models"] = tvm
+    for m in ("models.vae_gan", "models", "configs.models_config", "configs"):
+        sys.modules.pop(m, None)
+    mc = importlib.import_module("configs.models_config")
+    mc.image_size = cfg.image_size
+    mc.fc_input = cfg.fc_input
+    mc.fc_output = cfg.fc_output
+    mc.fc_input_gan = cfg.fc_input_gan
+    mc.fc_output_gan = cfg.fc_output_gan
+    mc.stride_gan = cfg.stride_gan
+    mc.latent_dim = cfg.latent_dim
+    mc.output_pad_dec = list(cfg.output_pad_dec)
+    mc.decoder_channels = list(cfg.decoder_channels)
+    mc.encoder_channels = list(cfg.encoder_channels)
+    mc.discrim_channels = list(cfg.discrim_channels)
+    return importlib.import_module("models.vae_gan")
+
+
+def summarize_state(sd):
+    keys = list(sd.keys())
+    return keys, np.stack([O.tensor_summary(sd[k].float() if sd[k].dtype != torch.float32 else sd[k]) for k in keys])
+
+
+def grads_of(params_named):
+    return {k: (p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p)) for k, p in params_named}
+
+
+def pack(out, prefix, dct):
+    for k, v in dct.items():
+        out[f"{prefix}/{k}"] = np.asarray(v)
+
+
+def literal_three_backward(model, loss_enc, loss_dec, loss_dis, nets):
+    """train_vgan_stage1.py:408-432 with optimizer steps deferred."""
+    g = {}
+    model.zero_grad()
+    if "encoder" in nets:
+        loss_enc.backward(retain_graph=True)
+        g.update(grads_of([("encoder." + k, p) for k, p in model.encoder.named_parameters()]))
+        model.zero_grad()
+    if "decoder" in nets:
+        loss_dec.backward(retain_graph=True)
+        g.update(grads_of([("decoder." + k, p) for k, p in model.decoder.named_parameters()]))
+        model.discriminator.zero_grad()
+    if "discriminator" in nets:
+        loss_dis.backward()
+        g.update(grads_of([("discriminator." + k, p) for k, p in model.discriminator.named_parameters()]))
+    return g
+
+
+def apply_grads(module, prefix, g, opt, clamp=None):
+    for k, p in module.named_parameters():
+        p.grad = g[prefix + k].clone()
+        if clamp is not None:
+            p.grad.data.clamp_(-clamp, clamp)
+    opt.step()
+
+
+def gate(bo, bp, hp):
+    train_dis, train_dec = True, True
+    if bo < hp.equilibrium - hp.margin or bp < hp.equilibrium - hp.margin:
+        train_dis = False
+    if bo > hp.equilibrium + hp.margin or bp > hp.equilibrium + hp.margin:
+        train_dec = False
+    if train_dec is False and train_dis is False:
+        train_dis = True
+        train_dec = True
+    return train_dis, train_dec
+
+
+def rms(params, lr):
+    return torch.optim.RMSprop(params=params, lr=lr, alpha=0.9, eps=1e-8, weight_decay=0, momentum=0, centered=False)
+
+
+def record_step(out, tag, logs, fw, grads):
+    pack(out, f"{tag}/logs", {k: np.float64(v) for k, v in logs.items()})
+    pack(out, f"{tag}/fw", {k: O.tensor_summary(v) for k, v in fw.items()})
+    out[f"{tag}/grad_keys"] = np.array(list(grads.keys()))
+    out[f"{tag}/grad_sum"] = np.stack([O.tensor_summary(v) for v in grads.values()])
+
+
+# ------------------------------------------------------------------------------------------------
+def case_stage1(name, cfg, B, seed, perturb, steps=2):
+    vg = load_reference(cfg)
+    hp = O.GanHyper()
+    model = vg.VaeGan(device="cpu", z_size=cfg.latent_dim)
+    sd0 = O.fill_state(O.vaegan_spec(cfg), seed, perturb)
+    assert list(model.state_dict().keys()) == list(sd0.keys())
+    model.load_state_dict(sd0)
+    model.train()
+    data = O.synth_batch(B, cfg, seed=1234, steps=steps)
+    x = data["x"]
+
+    # RNG-order check against the reference's own forward
+    chk = vg.VaeGan(device="cpu", z_size=cfg.latent_dim)
+    chk.load_state_dict(sd0)
+    chk.train()
+    torch.manual_seed(7)
+    ref_out = chk(x)
+    torch.manual_seed(7)
+    eps_t = torch.empty(B, cfg.latent_dim).normal_()
+    zp_t = torch.randn(B, cfg.latent_dim)
+    chk2 = vg.VaeGan(device="cpu", z_size=cfg.latent_dim)
+    chk2.load_state_dict(sd0)
+    chk2.train()
+    mus, lv = chk2.encoder(x)
+    xt = chk2.decoder(eps_t * torch.exp(0.5 * lv) + mus)
+    xp = chk2.decoder(zp_t)
+    dl = chk2.discriminator(x, xt, xp, "REC")
+    dc = chk2.discriminator(x, xt, xp, "GAN")
+    for a, b in zip(ref_out, (xt, dc, dl, mus, lv)):
+        assert torch.equal(a, b), "sub-module order does not reproduce model(x)"
+
+    opt_e = rms(model.encoder.parameters(), hp.lr)
+    opt_d = rms(model.decoder.parameters(), hp.lr)
+    opt_s = rms(model.discriminator.parameters(), hp.lr)
+    out = {"meta/case": np.array("stage1"), "meta/B": B, "meta/seed": seed, "meta/perturb": perturb,
+           "meta/steps": steps, "meta/image_size": cfg.image_size}
+    for s in range(steps):
+        eps, z_p = data["noise"][s, 0], data["noise"][s, 1]
+        mus, lv = model.encoder(x)
+        z = eps * torch.exp(0.5 * lv) + mus
+        x_tilde = model.decoder(z)
+        x_p = model.decoder(z_p)
+        disc_layer = model.discriminator(x, x_tilde, x_p, "REC")
+        disc_class = model.discriminator(x, x_tilde, x_p, "GAN")
+        nle, kld, mse, bo, bp, bs = vg.VaeGan.loss(x, x_tilde, disc_layer[:B], disc_layer[B:-B], disc_layer[-B:],
+                                                   disc_class[:B], disc_class[B:-B], disc_class[-B:], mus, lv)
+        loss_enc = torch.sum(kld) + torch.sum(mse)
+        loss_dis = torch.sum(bo) + torch.sum(bp) + torch.sum(bs)
+        loss_dec = torch.sum(hp.lambda_mse * mse) - (1.0 - hp.lambda_mse) * loss_dis
+        train_dis, train_dec = gate(torch.mean(bo).item(), torch.mean(bp).item(), hp)
+        g = literal_three_backward(model, loss_enc, loss_dec, loss_dis, ("encoder", "decoder", "discriminator"))
+        apply_grads(model.encoder, "encoder.", g, opt_e)
+        if train_dec:
+            apply_grads(model.decoder, "decoder.", g, opt_d)
+        if train_dis:
+            apply_grads(model.discriminator, "discriminator.", g, opt_s)
+        model.zero_grad()
+        logs = dict(loss_encoder=loss_enc.item(), loss_discriminator=loss_dis.item(), loss_decoder=loss_dec.item(),
+                    nle=torch.sum(nle).item(), kl=torch.sum(kld).item(), mse=torch.sum(mse).item(),
+                    bce_orig=torch.sum(bo).item(), bce_pred=torch.sum(bp).item(), bce_samp=torch.sum(bs).item(),
+                    train_dis=float(train_dis), train_dec=float(train_dec))
+        fw = dict(x_tilde=x_tilde, x_p=x_p, disc_class=disc_class, disc_layer=disc_layer, mus=mus, log_variances=lv)
+        record_step(out, f"step{s}", logs, fw, g)
+        keys, summ = summarize_state(model.state_dict())
+        out[f"step{s}/state_keys"] = np.array(keys)
+        out[f"step{s}/state_sum"] = summ
+        print(name, "step", s, {k: round(v, 5) for k, v in logs.items()})
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+
+
+def build_cognitive(vg, cfg, V, seed, perturb, stage):
+    """Model wiring of train_vgan_stage2.py:211-232 / train_vgan_stage3.py:222-245 on recipe weights."""
+    teacher = vg.VaeGan(device="cpu", z_size=cfg.latent_dim)
+    teacher.load_state_dict(O.fill_state(O.vaegan_spec(cfg), seed, perturb))
+    cog = vg.CognitiveEncoder(input_size=V, z_size=cfg.latent_dim)
+    cog.load_state_dict({k[len("encoder."):]: v for k, v in
+                         O.fill_state(O.cognitive_encoder_spec(cfg, V), seed + 100, perturb).items()})
+    if stage == 2:
+        for p in teacher.decoder.parameters():
+            p.requires_grad = False
+        model = vg.VaeGanCognitive(device="cpu", encoder=cog, decoder=teacher.decoder,
+                                   discriminator=teacher.discriminator, teacher_net=teacher, stage=2,
+                                   z_size=cfg.latent_dim)
+    else:
+        # stage 3 builds fresh Decoder/Discriminator and loads stage-II weights; equivalent: reuse tensors
+        for p in cog.parameters():
+            p.requires_grad = False
+        model = vg.VaeGanCognitive(device="cpu", encoder=cog, decoder=teacher.decoder,
+                                   discriminator=teacher.discriminator, teacher_net=None, stage=3,
+                                   z_size=cfg.latent_dim)
+    model.train()
+    return model
+
+
+def case_cognitive(name, cfg, B, V, seed, perturb, stage, steps=2):
+    vg = load_reference(cfg)
+    hp = O.GanHyper()
+    model = build_cognitive(vg, cfg, V, seed, perturb, stage)
+    data = O.synth_batch(B, cfg, n_voxels=V, seed=1234, steps=steps)
+    x, fmri = data["x"], data["fmri"]
+
+    # RNG-order check against the reference's own forward (eps_cog, [eps_teacher], z_p)
+    chk = build_cognitive(vg, cfg, V, seed, perturb, stage)
+    torch.manual_seed(11)
+    ref_out = chk({"fmri": fmri, "image": x})
+    torch.manual_seed(11)
+    e1 = torch.empty(B, cfg.latent_dim).normal_()
+    e2 = torch.empty(B, cfg.latent_dim).normal_() if stage == 2 else None
+    zp = torch.randn(B, cfg.latent_dim)
+    chk2 = build_cognitive(vg, cfg, V, seed, perturb, stage)
+    mus, lv = chk2.encoder(fmri)
+    xt = chk2.decoder(e1 * torch.exp(0.5 * lv) + mus)
+    gt = x
+    if stage == 2:
+        mt, lt = chk2.teacher_net.encoder(x)
+        gt = chk2.decoder(e2 * torch.exp(0.5 * lt) + mt)
+    xp = chk2.decoder(zp)
+    dl = chk2.discriminator(gt, xt, xp, "REC")
+    dc = chk2.discriminator(gt, xt, xp, "GAN")
+    for a, b in zip(ref_out, (gt, xt, dc, dl, mus, lv)):
+        assert torch.equal(a, b), "sub-module order does not reproduce model(sample)"
+
+    opt_e = rms(model.encoder.parameters(), hp.lr)
+    opt_d = rms(model.decoder.parameters(), hp.lr)
+    opt_s = rms(model.discriminator.parameters(), hp.lr)
+    out = {"meta/case": np.array(f"stage{stage}"), "meta/B": B, "meta/V": V, "meta/seed": seed,
+           "meta/perturb": perturb, "meta/steps": steps, "meta/image_size": cfg.image_size}
+    for s in range(steps):
+        nz = data["noise"][s]
+        if stage == 2:
+            for p in model.decoder.parameters():
+                p.requires_grad = False
+        else:
+            for p in model.encoder.parameters():
+                p.requires_grad = False
+            for p in model.decoder.parameters():
+                p.requires_grad = True
+            for p in model.discriminator.parameters():
+                p.requires_grad = True
+        mus, lv = model.encoder(fmri)
+        x_tilde = model.decoder(nz[0] * torch.exp(0.5 * lv) + mus)
+        gt_x = x
+        if stage == 2:
+            for p in model.teacher_net.encoder.parameters():
+                p.requires_grad = False
+            mt, lt = model.teacher_net.encoder(x)
+            gt_x = model.decoder(nz[2] * torch.exp(0.5 * lt) + mt)
+        x_p = model.decoder(nz[1])
+        disc_layer = model.discriminator(gt_x, x_tilde, x_p, "REC")
+        disc_class = model.discriminator(gt_x, x_tilde, x_p, "GAN")
+        nle, kld, mse, bo, bp, bs = vg.VaeGanCognitive.loss(gt_x, x_tilde, disc_layer[:B], disc_layer[B:-B],
+                                                            disc_layer[-B:], disc_class[:B], disc_class[B:-B],
+                                                            disc_class[-B:], mus, lv)
+        loss_enc = torch.sum(kld) + torch.sum(mse)
+        loss_dis = torch.sum(bo) + torch.sum(bp) + torch.sum(bs)
+        loss_dec = torch.sum(hp.lambda_mse * mse) - (1.0 - hp.lambda_mse) * loss_dis
+        if stage == 2:
+            train_dis, train_dec = True, False
+            g = literal_three_backward(model, loss_enc, loss_dec, loss_dis, ("encoder", "discriminator"))
+            apply_grads(model.encoder, "encoder.", g, opt_e, clamp=1.0)
+            apply_grads(model.discriminator, "discriminator.", g, opt_s, clamp=1.0)
+        else:
+            train_dis, train_dec = gate(torch.mean(bo).item(), torch.mean(bp).item(), hp)
+            g = literal_three_backward(model, loss_enc, loss_dec, loss_dis, ("decoder", "discriminator"))
+            if train_dec:
+                apply_grads(model.decoder, "decoder.", g, opt_d, clamp=1.0)
+            if train_dis:
+                apply_grads(model.discriminator, "discriminator.", g, opt_s, clamp=1.0)
+        model.zero_grad()
+        logs = dict(loss_encoder=loss_enc.item(), loss_discriminator=loss_dis.item(), loss_decoder=loss_dec.item(),
+                    nle=torch.sum(nle).item(), kl=torch.sum(kld).item(), mse=torch.sum(mse).item(),
+                    bce_orig=torch.sum(bo).item(), bce_pred=torch.sum(bp).item(), bce_samp=torch.sum(bs).item(),
+                    train_dis=float(train_dis), train_dec=float(train_dec))
+        fw = dict(gt_x=gt_x, x_tilde=x_tilde, x_p=x_p, disc_class=disc_class, disc_layer=disc_layer, mus=mus,
+                  log_variances=lv)
+        record_step(out, f"step{s}", logs, fw, g)
+        keys, summ = summarize_state(model.state_dict())
+        out[f"step{s}/state_keys"] = np.array(keys)
+        out[f"step{s}/state_sum"] = summ
+        print(name, "step", s, {k: round(v, 5) for k, v in logs.items()})
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+
+
+def case_wae1(name, cfg, B, seed, steps=2):
+    """train/train_wae_stage1.py:259-311 on the reference WaeGan container."""
+    vg = load_reference(cfg)
+    model = vg.WaeGan(device="cpu", z_size=cfg.latent_dim)
+    spec = O.encoder_spec(cfg) + O.decoder_spec(cfg) + O.wae_discriminator_spec(cfg)
+    sd0 = O.fill_state(spec, seed, False)
+    assert list(model.state_dict().keys()) == list(sd0.keys())
+    model.load_state_dict(sd0)
+    lr = 1e-4
+    opt_e = torch.optim.Adam(model.encoder.parameters(), lr=lr, betas=(0.5, 0.999))
+    opt_d = torch.optim.Adam(model.decoder.parameters(), lr=lr, betas=(0.5, 0.999))
+    opt_s = torch.optim.Adam(model.discriminator.parameters(), lr=0.5 * lr, betas=(0.5, 0.999))
+    data = O.synth_batch(B, cfg, seed=1234, steps=steps)
+    x = data["x"]
+
+    def freeze(m, flag):
+        for p in m.parameters():
+            p.requires_grad = not flag
+
+    out = {"meta/case": np.array("wae1"), "meta/B": B, "meta/seed": seed, "meta/steps": steps,
+           "meta/image_size": cfg.image_size}
+    for s in range(steps):
+        model.train()
+        model.encoder.zero_grad()
+        model.decoder.zero_grad()
+        model.discriminator.zero_grad()
+        freeze(model.decoder, True)
+        freeze(model.encoder, True)
+        freeze(model.discriminator, False)
+        z_real, var = model.encoder(x)
+        z_fake = data["noise"][s, 2] * 0.5
+        d_real = model.discriminator(z_real)
+        d_fake = model.discriminator(z_fake)
+        l_fake = -10 * torch.sum(torch.log(d_fake + 1e-3))
+        l_real = -10 * torch.sum(torch.log(1 - d_real + 1e-3))
+        l_fake.backward(retain_graph=True)
+        l_real.backward(retain_graph=True)
+        g = grads_of([("discriminator." + k, p) for k, p in model.discriminator.named_parameters()])
+        opt_s.step()
+        freeze(model.encoder, False)
+        freeze(model.decoder, False)
+        freeze(model.discriminator, True)
+        z_real, var = model.encoder(x)
+        x_recon = model.decoder(z_real)
+        d_real = model.discriminator(z_real)
+        l_rec = torch.sum(torch.sum(0.5 * (x_recon - x) ** 2, 1))
+        l_pen = -10 * torch.sum(torch.log(d_real + 1e-3))
+        l_rec.backward(retain_graph=True)
+        l_pen.backward()
+        g.update(grads_of([("encoder." + k, p) for k, p in model.encoder.named_parameters()]))
+        g.update(grads_of([("decoder." + k, p) for k, p in model.decoder.named_parameters()]))
+        opt_e.step()
+        opt_d.step()
+        logs = dict(loss_reconstruction=l_rec.item(), loss_penalty=l_pen.item(),
+                    loss_discriminator_fake=l_fake.item(), loss_discriminator_real=l_real.item())
+        record_step(out, f"step{s}", logs, dict(x_recon=x_recon, z_real=z_real), g)
+        keys, summ = summarize_state(model.state_dict())
+        out[f"step{s}/state_keys"] = np.array(keys)
+        out[f"step{s}/state_sum"] = summ
+        print(name, "step", s, {k: round(v, 5) for k, v in logs.items()})
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or ["all"]
+
+    def want(n):
+        return "all" in which or n in which
+
+    if want("stage1_b4"):
+        case_stage1("stage1_b4", O.ArchCfg.px64(), B=4, seed=0, perturb=True)
+    if want("stage1_b32"):
+        case_stage1("stage1_b32", O.ArchCfg.px64(), B=32, seed=0, perturb=False, steps=1)
+    if want("stage1_px100_b2"):
+        case_stage1("stage1_px100_b2", O.ArchCfg.px100(), B=2, seed=3, perturb=True, steps=1)
+    if want("stage2_b4"):
+        case_cognitive("stage2_b4", O.ArchCfg.px64(), B=4, V=4096, seed=1, perturb=True, stage=2)
+    if want("stage3_b4"):
+        case_cognitive("stage3_b4", O.ArchCfg.px64(), B=4, V=4096, seed=2, perturb=True, stage=3)
+    if want("wae1_b4"):
+        case_wae1("wae1_b4", O.ArchCfg.px64(), B=4, seed=5)

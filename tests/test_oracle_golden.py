@@ -1,0 +1,134 @@
+"""Pin the CPU oracle (oracle/vaegan_oracle.py) to golden vectors produced by the real reference.
+
+The fixtures in tests/golden/*.npz were written by tests/golden/make_golden.py, which imports and runs
+/root/reference in the build container.  These tests need neither the reference nor a GPU.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vaegan_oracle as O
+
+LOG_RTOL = 2e-5      # logged scalar losses: same fp32 torch kernels on both sides
+SUM_RTOL = 2e-4      # tensor fingerprints (norm / sum / head / tail)
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"), allow_pickle=False)
+
+
+def _check_logs(g, tag, logs):
+    for k, v in logs.items():
+        ref = float(g[f"{tag}/logs/{k}"])
+        assert float(v) == pytest.approx(ref, rel=LOG_RTOL, abs=1e-6), (tag, k, v, ref)
+
+
+def _check_summ(ref, got, what, rtol=SUM_RTOL):
+    scale = max(abs(ref[0]), 1e-12)  # tensor L2 norm
+    np.testing.assert_allclose(got[0], ref[0], rtol=rtol, err_msg=f"{what} norm")
+    # sum / elements: absolute tolerance relative to the tensor's norm
+    np.testing.assert_allclose(got[1:], ref[1:], rtol=rtol, atol=rtol * scale, err_msg=what)
+
+
+def _check_step(g, tag, out, P):
+    _check_logs(g, tag, out["logs"])
+    for k, v in out["fw"].items():
+        _check_summ(g[f"{tag}/fw/{k}"], O.tensor_summary(v), f"{tag} fw {k}")
+    gkeys = [str(k) for k in g[f"{tag}/grad_keys"]]
+    gs = g[f"{tag}/grad_sum"]
+    for i, k in enumerate(gkeys):
+        if k in out["grads"] and out["grads"][k] is not None:
+            _check_summ(gs[i], O.tensor_summary(out["grads"][k]), f"{tag} grad {k}", rtol=1e-3)
+    skeys = [str(k) for k in g[f"{tag}/state_keys"]]
+    ss = g[f"{tag}/state_sum"]
+    for i, k in enumerate(skeys):
+        assert k in P, k
+        _check_summ(ss[i], O.tensor_summary(P[k].float()), f"{tag} state {k}")
+
+
+def _rms_opts(*names):
+    return {n: O.OptState(kind="rmsprop", lr=1e-4) for n in names}
+
+
+@pytest.mark.parametrize("name,cfg", [("stage1_b4", O.ArchCfg.px64()), ("stage1_px100_b2", O.ArchCfg.px100())])
+def test_stage1_matches_reference(golden_dir, name, cfg):
+    g = _load(golden_dir, name)
+    B, seed, perturb, steps = int(g["meta/B"]), int(g["meta/seed"]), bool(g["meta/perturb"]), int(g["meta/steps"])
+    P = O.fill_state(O.vaegan_spec(cfg), seed, perturb)
+    data = O.synth_batch(B, cfg, seed=1234, steps=steps)
+    opts = _rms_opts("encoder", "decoder", "discriminator")
+    for s in range(steps):
+        out = O.stage1_step(P, opts, data["x"], data["noise"][s, 0], data["noise"][s, 1], cfg, keep_grads=True)
+        assert out["logs"].pop("train_dis") == bool(g[f"step{s}/logs/train_dis"])
+        assert out["logs"].pop("train_dec") == bool(g[f"step{s}/logs/train_dec"])
+        _check_step(g, f"step{s}", out, P)
+
+
+def test_stage1_literal_equals_pruned():
+    """The 'literal' three-full-backward variant (CPU-baseline timing) gives the same numbers."""
+    cfg = O.ArchCfg.px64()
+    data = O.synth_batch(2, cfg, seed=1234)
+    res = []
+    for literal in (False, True):
+        P = O.fill_state(O.vaegan_spec(cfg), 0, True)
+        out = O.stage1_step(P, _rms_opts("encoder", "decoder", "discriminator"), data["x"], data["noise"][0, 0],
+                            data["noise"][0, 1], cfg, literal=literal)
+        res.append((out["logs"], P))
+    assert res[0][0] == res[1][0]
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
+
+
+@pytest.mark.parametrize("stage", [2, 3])
+def test_cognitive_stages_match_reference(golden_dir, stage):
+    cfg = O.ArchCfg.px64()
+    g = _load(golden_dir, f"stage{stage}_b4")
+    B, V, seed, perturb, steps = (int(g["meta/B"]), int(g["meta/V"]), int(g["meta/seed"]), bool(g["meta/perturb"]),
+                                  int(g["meta/steps"]))
+    teacher = O.fill_state(O.vaegan_spec(cfg), seed, perturb)
+    cog = O.fill_state(O.cognitive_encoder_spec(cfg, V), seed + 100, perturb)
+    P = dict(cog)
+    P.update({k: v for k, v in teacher.items() if k.startswith(("decoder.", "discriminator."))})
+    if stage == 2:
+        # teacher_net.* entries alias the shared decoder/discriminator tensors (train_vgan_stage2.py:217,230)
+        for k, v in teacher.items():
+            P["teacher_net." + k] = P[k] if k.startswith(("decoder.", "discriminator.")) else v
+    data = O.synth_batch(B, cfg, n_voxels=V, seed=1234, steps=steps)
+    opts = _rms_opts("encoder", "decoder", "discriminator")
+    step = O.stage2_step if stage == 2 else O.stage3_step
+    for s in range(steps):
+        out = step(P, opts, data["fmri"], data["x"], data["noise"][s], cfg, V, keep_grads=True)
+        assert out["logs"].pop("train_dis") == bool(g[f"step{s}/logs/train_dis"])
+        assert out["logs"].pop("train_dec") == bool(g[f"step{s}/logs/train_dec"])
+        if stage == 2:  # keep aliases in sync after the functional update replaced tensors
+            for k in teacher:
+                if k.startswith(("decoder.", "discriminator.")):
+                    P["teacher_net." + k] = P[k]
+        _check_step(g, f"step{s}", out, P)
+
+
+def test_wae_stage1_matches_reference(golden_dir):
+    cfg = O.ArchCfg.px64()
+    g = _load(golden_dir, "wae1_b4")
+    B, seed, steps = int(g["meta/B"]), int(g["meta/seed"]), int(g["meta/steps"])
+    P = O.fill_state(O.encoder_spec(cfg) + O.decoder_spec(cfg) + O.wae_discriminator_spec(cfg), seed, False)
+    data = O.synth_batch(B, cfg, seed=1234, steps=steps)
+    opts = {"encoder": O.OptState(kind="adam", lr=1e-4), "decoder": O.OptState(kind="adam", lr=1e-4),
+            "discriminator": O.OptState(kind="adam", lr=0.5e-4)}
+    for s in range(steps):
+        out = O.wae_stage1_step(P, opts, data["x"], data["noise"][s, 2], cfg, keep_grads=True)
+        _check_step(g, f"step{s}", out, P)
+
+
+def test_stage1_b32_first_step_losses(golden_dir):
+    """BASELINE config 1 (batch 32, CPU reference): first-step losses of the oracle equal the reference's."""
+    cfg = O.ArchCfg.px64()
+    g = _load(golden_dir, "stage1_b32")
+    P = O.fill_state(O.vaegan_spec(cfg), int(g["meta/seed"]), bool(g["meta/perturb"]))
+    data = O.synth_batch(32, cfg, seed=1234, steps=1)
+    with torch.no_grad():
+        fw = O.vaegan_forward(P, data["x"], data["noise"][0, 0], data["noise"][0, 1], cfg)
+        _, _, _, logs = O._compose_losses(fw, data["x"], 32, O.GanHyper())
+    _check_logs(g, "step0", logs)

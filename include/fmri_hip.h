@@ -1,0 +1,122 @@
+/*
+ * fmri_hip.h -- C ABI of libfmri_hip.so, the MI355X (gfx950) kernel library behind the drop-in
+ * `models.vae_gan` engine.
+ *
+ * The reference (MariaPdg/thesis-fmri-reconstruction) is pure Python on PyTorch: it has no FFI of its
+ * own.  The boundary this library sits behind is the ATen operator set that `models/vae_gan.py` calls
+ * (SURVEY.md 8a row a15); each entry point below names the reference call site(s) it replaces.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every buffer (incl. workspaces) is owned by the caller
+ *     (the PyTorch caching allocator in our host code); the library allocates nothing and keeps no
+ *     mutable global state => re-entrant, callable from autograd worker threads.
+ *   - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*); no host sync.
+ *   - return 0 on success, a negative fmri_err otherwise; never throws, never exits.
+ *   - activations: fp16 NHWC rows [N][H][W][C] with C a multiple of 8 (images are channel-padded 3->8);
+ *     weights: fp16 "packed" matrices [rows_pad][kpad] produced by fmri_pack_weight;
+ *     reductions / statistics / losses / master weights: fp32.
+ */
+#ifndef FMRI_HIP_H
+#define FMRI_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum fmri_err { FMRI_OK = 0, FMRI_E_BADARG = -1, FMRI_E_UNSUPPORTED = -2, FMRI_E_LAUNCH = -3, FMRI_E_WORKSPACE = -4 };
+enum fmri_act { FMRI_ACT_NONE = 0, FMRI_ACT_RELU = 1, FMRI_ACT_TANH = 2, FMRI_ACT_SIGMOID = 3 };
+/* contraction modes of fmri_igemm */
+enum fmri_mode {
+    FMRI_CONV = 0,        /* correlation: in pixel = out*stride + k - pad          (nn.Conv2d fwd, deconv dgrad) */
+    FMRI_TCONV2 = 1,      /* stride-2 transposed conv as 4 parity classes          (nn.ConvTranspose2d fwd, conv-s2 dgrad) */
+    FMRI_CONV_FLIP = 2    /* stride-1 correlation with flipped taps: in = out + pad - k   (conv-s1 dgrad) */
+};
+
+int fmri_version(void);
+const char* fmri_last_error_string(int code);
+
+/* exact division helper exported for the host-side tests of the kernels' index arithmetic */
+uint32_t fmri_test_fastdiv(uint32_t n, uint32_t d);
+
+/* Geometry of parity class (cy,cx) of a k x k, stride-2, pad-p transposed convolution: first tap
+ * (py,px), tap grid TH x TW, padded K and element offset of the class's packed weight block. */
+int fmri_tconv_class(int k, int pad, int cy, int cx, int ci, int rows_pad, int* py, int* px, int* th, int* tw,
+                     int* kpad, int64_t* w_off);
+/* padded K (multiple of 64) of a T-tap, ci-channel reduction */
+int fmri_kpad(int taps, int ci);
+
+/* ---- weights ------------------------------------------------------------------------------------
+ * dst[(ta*A + a)][(tb*Bp + b)] = (fp16) src[a*sa + ta*sta + b*sb + t(tb)*stb],  t(tb) = (py+step*ty)*KW + (px+step*tx),
+ * zero padded to [rows_pad][kpad].  Replaces the implicit weight layout handling of ATen conv/linear
+ * (models/vae_gan.py:18,46,79,107,119,146,156) incl. the (C,H,W) flatten order at :89,:127,:181. */
+int fmri_pack_weight(const float* src, void* dst, int64_t sa, int64_t sta, int64_t sb, int64_t stb, int A, int TA,
+                     int B, int KW, int py, int px, int step, int TH, int TW, int rows_pad, int kpad, void* stream);
+/* inverse map for fp32 weight gradients: dst[...] (+)= scale * src[(ta*A+a)*ld + tb*Bp + b] */
+int fmri_unpack_grad(const float* src, float* dst, int64_t sa, int64_t sta, int64_t sb, int64_t stb, int A, int TA,
+                     int B, int KW, int py, int px, int step, int TH, int TW, int ld, float scale, int accumulate,
+                     void* stream);
+
+/* ---- contractions (MFMA) ------------------------------------------------------------------------
+ * out = act(bias + contraction(in, w)); see csrc/igemm.hip.  Replaces F.conv2d / F.conv_transpose2d /
+ * F.linear forward and data-gradient (models/vae_gan.py:26,32,57,90-92,126,128,175,182).
+ * out_f32 != 0: raw fp32 result written to `splits` slabs (slab_stride elements apart), no bias/act. */
+int fmri_igemm(const void* in, const void* w, void* out, const float* bias, const void* zero16, int N, int Hi, int Wi,
+               int Ci, int Ho, int Wo, int CoStore, int Co, int k, int stride, int pad, int mode, int act,
+               int out_f32, int splits, int64_t slab_stride, int bn_tile, void* stream);
+/* dW[a][tap*Bc+b] (+)= sum_m P[m][a] * Q[gather(m,tap)][b]; see csrc/wgrad.hip.  Replaces the weight
+ * gradients autograd computes for the same modules (train/train_vgan_stage1.py:412,422,430). */
+int fmri_wgrad(const void* P, const void* Q, float* out, const void* zero16, int N, int Yc, int Xc, int A, int Hq,
+               int Wq, int Bc, int k, int stride, int pad, int apad, int ba_tile, int ldo, int splits, int atomic,
+               void* stream);
+
+/* ---- layout casts ------------------------------------------------------------------------------- */
+int fmri_nchw_to_nhwc(const float* src, void* dst, int N, int C, int HW, int Cp, void* stream);
+int fmri_nhwc_to_nchw(const void* src, float* dst, int N, int C, int HW, int Cp, float scale, void* stream);
+int fmri_rows_f32_to_f16(const float* src, void* dst, int M, int C, int Cp, float scale, void* stream);
+int fmri_rows_f16_to_f32(const void* src, float* dst, int M, int C, int Cp, float scale, void* stream);
+int fmri_reduce_slabs(const float* slabs, int nslabs, int64_t slab_stride, int M, int C, int ld, const float* bias,
+                      int act, float* out32, int ld32, void* out16, int ld16, void* stream);
+int fmri_permute_chw(const float* src, float* dst, int C, int HW, int to_engine, float scale, int accumulate,
+                     void* stream);
+
+/* ---- batch norm (train mode, momentum 0.9; models/vae_gan.py:21,54,81,108,158) -------------------- */
+int fmri_bn_stats(const void* x, int M, int C, float* sums2C, void* stream);
+int fmri_bn_finalize(const float* sums2C, int C, float count, const float* gamma, const float* beta, float eps,
+                     float momentum, int updates, float* running_mean, float* running_var, float* mean, float* rstd,
+                     float* scale, float* shift, void* stream);
+int fmri_bn_apply(const void* x, void* y, int M, int C, const float* scale, const float* shift, int relu,
+                  void* stream);
+int fmri_bn_bwd_reduce(const void* x, const void* dy, int M, int C, const float* mean, const float* rstd,
+                       const float* gamma, const float* beta, int relu, float* sums2C, void* stream);
+int fmri_bn_bwd_apply(const void* x, const void* dy, void* dx, int M, int C, float count, const float* mean,
+                      const float* rstd, const float* gamma, const float* beta, int relu, const float* sums2C,
+                      void* stream);
+int fmri_act_bwd(const void* y, const void* dy, void* dpre, int M, int C, int act, float* colsum, void* stream);
+
+/* ---- latent / losses (models/vae_gan.py:266-269, :302-320; train_vgan_stage1.py:368-404) ----------- */
+int fmri_latent_fwd(const float* head, const float* eps, int B, int Z, int zp, void* z16, float* kl_rows,
+                    float* kl_total, int sample, void* stream);
+int fmri_latent_bwd(const float* head, const float* eps, const float* dz, int ldz, float dz_unscale, float kl_w,
+                    int B, int Z, float out_scale, void* dhead16, float* dhead32, int sample, void* stream);
+int fmri_feat_mse(const void* feat, int B, int F, float* mse_rows, float* mse_total, void* dfeat, float gscale,
+                  void* stream);
+int fmri_pixel_sq(const void* x, const void* xt, int64_t npix, int C, int Cp, float* total, void* dxt, float gscale,
+                  void* stream);
+int fmri_gan_head(const float* logit, int ldl, int B, float* prob, float* scal3, void* dlogit, int ldg, float gscale,
+                  void* stream);
+int fmri_wae_logloss(const float* logit, int ldl, int n, int one_minus, float w, float* total, float* prob,
+                     void* dlogit, int ldg, float gscale, void* stream);
+int fmri_compose_gate(float* scal, int* flags, float batch, float lambda_mse, float equilibrium, float margin,
+                      int gate_on, int force_dis, int force_dec, void* stream);
+int fmri_axpby_f16(const void* x, const void* y, void* out, int64_t n, float a, float b, void* stream);
+
+/* ---- optimizers over flat fp32 buffers (train_vgan_stage1.py:275-283; train_wae_stage1.py:221-224) --- */
+int fmri_rmsprop(float* p, const float* g, float* sq, int64_t n, float lr, float alpha, float eps, float gscale,
+                 float clamp, const int* flag, void* stream);
+int fmri_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
+              float bc1, float bc2_sqrt, float gscale, float clamp, const int* flag, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FMRI_HIP_H */

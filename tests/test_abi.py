@@ -1,0 +1,76 @@
+"""CPU-side checks of the C-ABI shared library: it loads, exports every symbol include/fmri_hip.h
+declares, and its host-side index arithmetic is exact.  No kernels are launched here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from fmri_hip import build, lib as L
+    build.build(verbose=False)
+    return L.load()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "fmri_hip.h")).read()
+    declared = set(re.findall(r"\b(fmri_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"fmri_err", "fmri_act", "fmri_mode"}
+    assert len(declared) >= 30
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/fmri_hip.h but not exported"
+    from fmri_hip import lib as L
+    assert set(L.EXPORTS) == declared
+
+
+def test_version_and_error_strings(lib):
+    assert lib.fmri_version() >= 100
+    assert lib.fmri_last_error_string(0) == b"ok"
+    assert b"bad argument" in lib.fmri_last_error_string(-1)
+
+
+def test_fastdiv_is_exact(lib):
+    rs = np.random.RandomState(0)
+    divisors = [1, 2, 3, 5, 7, 8, 13, 25, 50, 64, 100, 169, 625, 4096, 10000, 65537, 2 ** 31 - 1]
+    for d in divisors:
+        ns = np.concatenate([np.arange(0, 2000), rs.randint(0, 2 ** 32, 2000, dtype=np.uint64),
+                             np.array([2 ** 32 - 1, 2 ** 31, 2 ** 31 - 1, d, d - 1, 2 * d, 2 * d - 1])])
+        for n in ns:
+            n = int(n) & 0xFFFFFFFF
+            assert lib.fmri_test_fastdiv(n, d) == n // d, (n, d)
+
+
+def test_tconv_class_geometry(lib):
+    """k=5, pad=2 stride-2 transposed conv: classes have 3x3, 3x2, 2x3, 2x2 taps (25 in total)."""
+    from fmri_hip import lib as L
+    taps = 0
+    off = 0
+    for cy in range(2):
+        for cx in range(2):
+            g = L.tconv_class(5, 2, cy, cx, 128, 256)
+            assert (g["py"], g["px"]) == (cy, cx)
+            assert g["th"] == (3 if cy == 0 else 2) and g["tw"] == (3 if cx == 0 else 2)
+            assert g["kpad"] == g["th"] * g["tw"] * 128 and g["kpad"] % 64 == 0
+            assert g["w_off"] == off
+            off += 256 * g["kpad"]
+            taps += g["th"] * g["tw"]
+    assert taps == 25
+    assert L.kpad(25, 8) == 256 and L.kpad(1, 4096) == 4096
+
+
+def test_argument_validation_without_gpu(lib):
+    """Bad shapes are rejected on the host before anything is enqueued."""
+    from fmri_hip import lib as L
+    z = ctypes.c_void_p(16)
+    # Ci not a multiple of 8
+    assert lib.fmri_igemm(z, z, z, None, z, 1, 4, 4, 3, 4, 4, 8, 8, 5, 1, 2, 0, 0, 0, 1, 0, 32, None) == -1
+    # unsupported tile
+    assert lib.fmri_igemm(z, z, z, None, z, 1, 4, 4, 8, 4, 4, 8, 8, 5, 1, 2, 0, 0, 0, 1, 0, 48, None) == -2
+    # split-K needs fp32 slabs
+    assert lib.fmri_igemm(z, z, z, None, z, 1, 4, 4, 8, 4, 4, 8, 8, 5, 1, 2, 0, 0, 0, 2, 0, 32, None) == -1
+    assert L.load().fmri_bn_stats(None, 4, 8, None, None) == -1

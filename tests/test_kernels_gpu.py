@@ -1,0 +1,378 @@
+"""GPU parity of the individual HIP operators (through the C ABI) against plain PyTorch fp32 on the CPU.
+
+Inputs are pre-rounded to fp16 so that the only differences left are fp32 accumulation order and the
+fp16 rounding of stored results: tolerance = 2e-3 of the output's RMS (+ 2e-3 relative).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _h(t):
+    return t.half().float()
+
+
+def _close(got, ref, what, tol=2e-3):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), what
+    rms = ref.pow(2).mean().sqrt().item() + 1e-12
+    err = (got - ref).abs()
+    lim = tol * rms + tol * ref.abs()
+    bad = (err > lim)
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} off; max err {err.max():.3e} rms {rms:.3e}"
+
+
+def _nhwc16(x):   # NCHW fp32 cpu -> NHWC fp16 cuda, channels padded to 8
+    from fmri_hip.ops import images_to_nhwc
+    return images_to_nhwc(x.to(DEV))
+
+
+def _from_nhwc(x16, C):
+    from fmri_hip.ops import nhwc_to_images
+    return nhwc_to_images(x16, C).cpu()
+
+
+class _G:
+    """Minimal FlatGroup stand-in for single-layer tests."""
+
+    def __init__(self, tensors):
+        self.views = {k: v.to(DEV).contiguous() for k, v in tensors.items()}
+        self.grads = {k: torch.zeros_like(v) for k, v in self.views.items()}
+        self.version = 0
+        self.device = torch.device(DEV)
+
+
+def test_image_layout_roundtrip():
+    x = _h(torch.randn(3, 3, 10, 7))
+    x16 = _nhwc16(x)
+    assert x16.shape == (3, 10, 7, 8)
+    assert torch.equal(_from_nhwc(x16, 3), x)
+    assert (x16[..., 3:] == 0).all()
+
+
+CONV_CASES = [
+    # cin, cout, stride, H, W, N
+    (3, 32, 1, 12, 12, 3),       # discriminator conv0 (stride_gan=1), K=75
+    (3, 64, 2, 16, 16, 2),       # encoder conv0
+    (32, 128, 2, 16, 16, 3),     # two taps per K-step
+    (64, 128, 2, 12, 12, 2),
+    (128, 256, 2, 8, 8, 5),
+    (32, 3, 1, 16, 16, 2),       # decoder last conv, N=3 outputs
+    (64, 128, 2, 25, 25, 2),     # odd size (100-px config: 25 -> 13)
+    (128, 256, 2, 13, 13, 3),    # 13 -> 7
+    (3, 32, 2, 20, 20, 2),       # stride_gan = 2
+]
+
+
+@pytest.mark.parametrize("cin,cout,stride,H,W,N", CONV_CASES)
+def test_conv_forward_dgrad_wgrad(cin, cout, stride, H, W, N):
+    from fmri_hip.ops import ConvLayer, ACT_NONE
+    torch.manual_seed(cin * 1000 + cout + H)
+    w = _h(torch.randn(cout, cin, 5, 5) * 0.1)
+    b = torch.randn(cout) * 0.1
+    x = _h(torch.randn(N, cin, H, W))
+    g = _G({"w": w, "b": b})
+    layer = ConvLayer(g, "w", "b", "conv", cin, cout, 5, stride, 2)
+    x16 = _nhwc16(x)
+    y16 = layer.forward(x16, ACT_NONE)
+    ref = F.conv2d(x, w, b, stride, 2)
+    _close(_from_nhwc(y16, cout), ref, "conv fwd")
+    if cout % 8:
+        assert (y16[..., cout:] == 0).all()
+    # cotangent
+    dy = _h(torch.randn_like(ref))
+    dy16 = _nhwc16(dy)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    F.conv2d(xr, wr, None, stride, 2).backward(dy)
+    dx16 = layer.dgrad(dy16, H, W)
+    _close(_from_nhwc(dx16, cin), xr.grad, "conv dgrad")
+    layer.wgrad(x16, dy16, 4.0)          # scale 4 -> grad accumulates dW/4
+    _close(g.grads["w"].cpu() * 4.0, wr.grad, "conv wgrad", tol=3e-3)
+
+
+DECONV_CASES = [
+    # cin, cout, H, out_pad, N
+    (256, 256, 8, 1, 3),
+    (256, 128, 16, 1, 2),
+    (128, 32, 16, 1, 2),
+    (256, 256, 13, 0, 2),        # 100-px config first block: 13 -> 25
+    (128, 64, 25, 1, 2),         # 25 -> 50
+]
+
+
+@pytest.mark.parametrize("cin,cout,H,op,N", DECONV_CASES)
+def test_deconv_forward_dgrad_wgrad(cin, cout, H, op, N):
+    from fmri_hip.ops import ConvLayer, ACT_NONE
+    torch.manual_seed(cin + cout + H)
+    w = _h(torch.randn(cin, cout, 5, 5) * 0.05)
+    x = _h(torch.randn(N, cin, H, H))
+    g = _G({"w": w})
+    layer = ConvLayer(g, "w", None, "deconv", cin, cout, 5, 2, 2, op)
+    x16 = _nhwc16(x)
+    y16 = layer.forward(x16, ACT_NONE)
+    ref = F.conv_transpose2d(x, w, None, 2, 2, output_padding=op)
+    assert y16.shape[1] == ref.shape[2]
+    _close(_from_nhwc(y16, cout), ref, "deconv fwd")
+    dy = _h(torch.randn_like(ref))
+    dy16 = _nhwc16(dy)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    F.conv_transpose2d(xr, wr, None, 2, 2, output_padding=op).backward(dy)
+    dx16 = layer.dgrad(dy16, H, H)
+    _close(_from_nhwc(dx16, cin), xr.grad, "deconv dgrad")
+    layer.wgrad(x16, dy16, 1.0)
+    _close(g.grads["w"].cpu(), wr.grad, "deconv wgrad", tol=3e-3)
+
+
+def test_conv_bias_relu_tanh_epilogues():
+    from fmri_hip.ops import ConvLayer, ACT_RELU, ACT_TANH
+    torch.manual_seed(5)
+    w = _h(torch.randn(32, 3, 5, 5) * 0.2)
+    b = torch.randn(32) * 0.2
+    x = _h(torch.randn(2, 3, 9, 11))
+    g = _G({"w": w, "b": b})
+    layer = ConvLayer(g, "w", "b", "conv", 3, 32, 5, 1, 2)
+    x16 = _nhwc16(x)
+    _close(_from_nhwc(layer.forward(x16, ACT_RELU), 32), F.relu(F.conv2d(x, w, b, 1, 2)), "bias+relu")
+    _close(_from_nhwc(layer.forward(x16, ACT_TANH), 32), torch.tanh(F.conv2d(x, w, b, 1, 2)), "bias+tanh")
+
+
+DENSE_CASES = [
+    # M, K, N, in_perm, out_perm
+    (6, 1024, 256, None, None),          # fused heads
+    (12, 512, 1, None, None),            # discriminator fc.3
+    (5, 4096, 1024, None, None),         # cognitive encoder fc1 (split-K)
+    (5, 3620, 1024, None, None),         # BOLD5000-shaped voxel count (not a multiple of 8)
+    (4, 16384, 1024, (256, 64), None),   # encoder fc.0 with (C,H,W)->(H,W,C) flatten
+    (9, 16384, 512, (256, 64), None),    # discriminator fc.0
+    (4, 128, 16384, None, (256, 64)),    # decoder fc.0
+    (3, 128, 512, None, None),           # WAE latent discriminator layer
+]
+
+
+@pytest.mark.parametrize("M,K,N,in_perm,out_perm", DENSE_CASES)
+def test_dense_forward_dgrad_wgrad(M, K, N, in_perm, out_perm):
+    from fmri_hip.ops import DenseLayer, ACT_NONE, pad8, rows_to_f16
+    torch.manual_seed(M + K + N)
+    w = _h(torch.randn(N, K) / np.sqrt(K))
+    # the only output-permuted layer of the model (decoder.fc.0) has no bias
+    b = torch.zeros(N) if out_perm else torch.randn(N) * 0.1
+    x = _h(torch.randn(M, K))
+    g = _G({"w": w, "b": b})
+    layer = DenseLayer(g, "w", "b", K, N, in_perm=in_perm, out_perm=out_perm)
+
+    def to_engine_in(t):          # reference (C,HW) feature order -> engine (HW,C)
+        if in_perm:
+            C, HW = in_perm
+            return t.reshape(-1, C, HW).transpose(1, 2).reshape(-1, K)
+        return t
+
+    def from_engine_out(t):
+        if out_perm:
+            C, HW = out_perm
+            return t.reshape(-1, HW, C).transpose(1, 2).reshape(-1, N)
+        return t
+
+    def to_engine_out(t):
+        if out_perm:
+            C, HW = out_perm
+            return t.reshape(-1, C, HW).transpose(1, 2).reshape(-1, N)
+        return t
+
+    def from_engine_in(t):
+        if in_perm:
+            C, HW = in_perm
+            return t.reshape(-1, HW, C).transpose(1, 2).reshape(-1, K)
+        return t
+
+    x16 = rows_to_f16(to_engine_in(x).contiguous().to(DEV))
+    ref = F.linear(x, w, b)
+    o16, o32 = layer.forward(x16, ACT_NONE, want16=True, want32=True)
+    _close(from_engine_out(o32.cpu()), ref, "dense fwd fp32", tol=1e-3)
+    _close(from_engine_out(o16[:, :N].float().cpu()), ref, "dense fwd fp16")
+    dy = _h(torch.randn(M, N))
+    dy16 = rows_to_f16(to_engine_out(dy).contiguous().to(DEV))
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    F.linear(xr, wr, None).backward(dy)
+    dx16, _ = layer.dgrad(dy16)
+    _close(from_engine_in(dx16[:, :K].float().cpu()), xr.grad, "dense dgrad")
+    _, dx32 = layer.dgrad(dy16, want32=True)
+    _close(from_engine_in(dx32.cpu()), xr.grad, "dense dgrad fp32", tol=1e-3)
+    layer.wgrad(x16, dy16, 2.0)
+    _close(g.grads["w"].cpu() * 2.0, wr.grad, "dense wgrad", tol=3e-3)
+    layer.bias_grad(dy16, 2.0)
+    _close(g.grads["b"].cpu() * 2.0, dy.sum(0), "dense bias grad")
+
+
+@pytest.mark.parametrize("M,C", [(3 * 64 * 64, 32), (600, 128), (2 * 13 * 13, 256), (7, 1024), (5, 16384), (12, 512)])
+def test_batchnorm_forward_backward(M, C):
+    from fmri_hip.ops import BatchNorm
+    torch.manual_seed(M + C)
+    x = _h(torch.randn(M, C) * 1.5 + 0.3)
+    gamma = 1 + 0.2 * torch.randn(C)
+    beta = 0.1 * torch.randn(C)
+
+    class G2(_G):
+        pass
+    g = G2({"bn.weight": gamma, "bn.bias": beta})
+    g.bufs = {"bn.running_mean": torch.zeros(C, device=DEV), "bn.running_var": torch.ones(C, device=DEV),
+              "bn.num_batches_tracked": torch.zeros((), dtype=torch.int64, device=DEV)}
+    bn = BatchNorm(g, "bn.", C)
+    x16 = x.half().to(DEV)
+    y16, sv = bn.forward(x16, relu=True, updates=2)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    xr = x.clone().requires_grad_(True)
+    gr = gamma.clone().requires_grad_(True)
+    br = beta.clone().requires_grad_(True)
+    yr = F.relu(F.batch_norm(xr, rm, rv, gr, br, True, 0.9, 1e-5))
+    F.batch_norm(x, rm, rv, gamma, beta, True, 0.9, 1e-5)      # second running-stat update
+    _close(y16.float().cpu(), yr, "bn fwd")
+    _close(g.bufs["bn.running_mean"].cpu(), rm, "running mean", tol=1e-3)
+    _close(g.bufs["bn.running_var"].cpu(), rv, "running var", tol=1e-3)
+    assert int(g.bufs["bn.num_batches_tracked"]) == 2
+    dy = _h(torch.randn(M, C))
+    yr.backward(dy)
+    dx16, _ = bn.backward(x16, dy.half().to(DEV), sv, relu=True, param_scale=8.0)
+    _close(dx16.float().cpu(), xr.grad, "bn dx", tol=3e-3)
+    _close(g.grads["bn.weight"].cpu() * 8.0, gr.grad, "bn dgamma", tol=3e-3)
+    _close(g.grads["bn.bias"].cpu() * 8.0, br.grad, "bn dbeta", tol=3e-3)
+
+
+def test_batchnorm_permuted_features():
+    """decoder.fc.1: reference vectors in (C,HW) order, engine rows in (HW,C) order."""
+    from fmri_hip.ops import BatchNorm
+    C0, HW, M = 16, 9, 6
+    C = C0 * HW
+    torch.manual_seed(0)
+    x = _h(torch.randn(M, C))                       # reference order
+    gamma = 1 + 0.2 * torch.randn(C)
+    beta = 0.1 * torch.randn(C)
+    g = _G({"bn.weight": gamma, "bn.bias": beta})
+    g.bufs = {"bn.running_mean": torch.zeros(C, device=DEV), "bn.running_var": torch.ones(C, device=DEV),
+              "bn.num_batches_tracked": torch.zeros((), dtype=torch.int64, device=DEV)}
+    bn = BatchNorm(g, "bn.", C, perm=(C0, HW))
+    xe = x.reshape(M, C0, HW).transpose(1, 2).reshape(M, C).contiguous()
+    y16, sv = bn.forward(xe.half().to(DEV), relu=True, updates=1)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    xr = x.clone().requires_grad_(True)
+    gr = gamma.clone().requires_grad_(True)
+    yr = F.relu(F.batch_norm(xr, rm, rv, gr, beta, True, 0.9, 1e-5))
+    got = y16.float().cpu().reshape(M, HW, C0).transpose(1, 2).reshape(M, C)
+    _close(got, yr, "perm bn fwd")
+    _close(g.bufs["bn.running_var"].cpu(), rv, "perm running var", tol=1e-3)
+    dy = _h(torch.randn(M, C))
+    yr.backward(dy)
+    dye = dy.reshape(M, C0, HW).transpose(1, 2).reshape(M, C).contiguous()
+    bn.backward(xe.half().to(DEV), dye.half().to(DEV), sv, True, param_scale=1.0)
+    _close(g.grads["bn.weight"].cpu(), gr.grad, "perm dgamma", tol=3e-3)
+
+
+def test_loss_kernels():
+    from fmri_hip import lib
+    P = lib.ptr
+    torch.manual_seed(1)
+    B, Z = 5, 128
+    head = torch.randn(B, 2 * Z) * 0.5
+    eps = torch.randn(B, Z)
+    mu, lv = head[:, :Z], head[:, Z:]
+    z_ref = eps * torch.exp(0.5 * lv) + mu
+    kl_ref = (-0.5 * torch.sum(-lv.exp() - mu.pow(2) + lv + 1, 1))
+    hd, ed = head.to(DEV), eps.to(DEV)
+    z16 = torch.empty(B, Z, dtype=torch.float16, device=DEV)
+    klr = torch.zeros(B, device=DEV)
+    klt = torch.zeros(1, device=DEV)
+    lib.call("fmri_latent_fwd", P(hd), P(ed), B, Z, Z, P(z16), P(klr), P(klt), 1)
+    _close(z16.float().cpu(), z_ref, "z")
+    _close(klr.cpu(), kl_ref, "kl rows", tol=1e-4)
+    assert abs(klt.item() - kl_ref.sum().item()) < 1e-3 * abs(kl_ref.sum().item())
+    # backward
+    dz = torch.randn(B, Z)
+    hr = head.clone().requires_grad_(True)
+    zr = eps * torch.exp(0.5 * hr[:, Z:]) + hr[:, :Z]
+    loss = (zr * dz).sum() + (-0.5 * torch.sum(-hr[:, Z:].exp() - hr[:, :Z].pow(2) + hr[:, Z:] + 1, 1)).sum()
+    loss.backward()
+    dh16 = torch.empty(B, 2 * Z, dtype=torch.float16, device=DEV)
+    dh32 = torch.empty(B, 2 * Z, device=DEV)
+    lib.call("fmri_latent_bwd", P(hd), P(ed), P(dz.to(DEV)), Z, 1.0, 1.0, B, Z, 16.0, P(dh16), P(dh32), 1)
+    _close(dh32.cpu(), hr.grad, "dhead32", tol=1e-4)
+    _close(dh16.float().cpu() / 16.0, hr.grad, "dhead16")
+    # GAN head
+    logit = torch.randn(3 * B) * 2
+    p_ref = torch.sigmoid(logit)
+    lr_ = logit.clone().requires_grad_(True)
+    pr = torch.sigmoid(lr_)
+    bo = -torch.log(pr[:B] + 1e-3)
+    bp = -torch.log(1 - pr[B:2 * B] + 1e-3)
+    bs = -torch.log(1 - pr[2 * B:] + 1e-3)
+    (bo.sum() + bp.sum() + bs.sum()).backward()
+    scal = torch.zeros(16, device=DEV)
+    prob = torch.empty(3 * B, device=DEV)
+    dl16 = torch.empty(3 * B, 8, dtype=torch.float16, device=DEV)
+    lib.call("fmri_gan_head", P(logit.to(DEV)), 1, B, P(prob), P(scal), P(dl16), 8, 32.0)
+    _close(prob.cpu(), p_ref, "prob", tol=1e-5)
+    _close(scal[:3].cpu(), torch.stack([bo.sum(), bp.sum(), bs.sum()]).detach(), "bce sums", tol=1e-5)
+    _close(dl16[:, 0].float().cpu() / 32.0, lr_.grad, "dlogit")
+    assert (dl16[:, 1:] == 0).all()
+    # feature mse
+    Fd = 16384
+    feat = _h(torch.randn(3 * B, Fd))
+    fr = feat.clone().requires_grad_(True)
+    mse = torch.sum(0.5 * (fr[:B] - fr[B:2 * B]) ** 2, 1)
+    mse.sum().backward()
+    f16 = feat.half().to(DEV)
+    rows = torch.zeros(B, device=DEV)
+    tot = torch.zeros(1, device=DEV)
+    df = torch.empty_like(f16)
+    lib.call("fmri_feat_mse", P(f16), B, Fd, P(rows), P(tot), P(df), 4.0)
+    _close(rows.cpu(), mse.detach(), "mse rows", tol=1e-4)
+    _close(df.float().cpu() / 4.0, fr.grad, "dfeat")
+    # gate
+    scal = torch.tensor([0.4 * B, 0.2 * B, 0.5 * B, 7.0, 11.0, 3.0] + [0.0] * 10, device=DEV)
+    flags = torch.zeros(2, dtype=torch.int32, device=DEV)
+    lib.call("fmri_compose_gate", P(scal), P(flags), float(B), 1e-6, 0.68, 0.35, 1, -1, -1)
+    s = scal.cpu()
+    assert flags.tolist() == [0, 1]                     # bce_pred mean 0.2 < 0.33 -> discriminator paused
+    assert abs(s[6] - 18.0) < 1e-5 and abs(s[7] - 1.1 * B) < 1e-5
+    assert abs(s[8] - (1e-6 * 11.0 - (1 - 1e-6) * 1.1 * B)) < 1e-5
+
+
+def test_optimizers_match_torch():
+    from fmri_hip import lib
+    P = lib.ptr
+    torch.manual_seed(3)
+    n = 10007
+    p0 = torch.randn(n)
+    grads = [torch.randn(n) * (10.0 ** np.random.RandomState(i).uniform(-6, 0)) for i in range(3)]
+    # RMSprop
+    pt = p0.clone().requires_grad_(True)
+    opt = torch.optim.RMSprop([pt], lr=1e-4, alpha=0.9, eps=1e-8)
+    pd, sq = p0.to(DEV).clone(), torch.zeros(n, device=DEV)
+    flag = torch.ones(1, dtype=torch.int32, device=DEV)
+    for g in grads:
+        pt.grad = g.clone()
+        opt.step()
+        lib.call("fmri_rmsprop", P(pd), P(g.to(DEV)), P(sq), n, 1e-4, 0.9, 1e-8, 1.0, 0.0, P(flag))
+    assert torch.allclose(pd.cpu(), pt.detach(), rtol=1e-6, atol=1e-7)
+    flag.zero_()
+    before = pd.clone()
+    lib.call("fmri_rmsprop", P(pd), P(grads[0].to(DEV)), P(sq), n, 1e-4, 0.9, 1e-8, 1.0, 0.0, P(flag))
+    assert torch.equal(pd, before)                       # gated off
+    # Adam(0.5, 0.999)
+    pt = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pt], lr=1e-4, betas=(0.5, 0.999))
+    pd, m, v = p0.to(DEV).clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for t, g in enumerate(grads, 1):
+        pt.grad = g.clone()
+        opt.step()
+        lib.call("fmri_adam", P(pd), P(g.to(DEV)), P(m), P(v), n, 1e-4, 0.5, 0.999, 1e-8, 1 - 0.5 ** t,
+                 float(np.sqrt(1 - 0.999 ** t)), 1.0, 0.0, None)
+    assert torch.allclose(pd.cpu(), pt.detach(), rtol=2e-6, atol=1e-7)

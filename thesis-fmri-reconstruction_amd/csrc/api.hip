@@ -1,0 +1,292 @@
+// extern "C" surface of libfmri_hip.so (declared in include/fmri_hip.h).
+// Host-side geometry derivation + argument validation; all device work is enqueued on the caller's stream.
+#include "../../include/fmri_hip.h"
+#include "kernels.h"
+
+using namespace fmri;
+
+namespace {
+inline hipStream_t S(void* s) { return (hipStream_t)s; }
+inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
+
+struct TClass { int py, px, th, tw, dy0, dx0, kpad; int64_t w_off; };
+
+// parity classes of a k x k stride-2 pad-p transposed convolution (see csrc/igemm.hip header)
+void tconv_classes(int k, int pad, int ci, int rows_pad, TClass out[4]) {
+    int64_t off = 0;
+    for (int cy = 0; cy < 2; ++cy)
+        for (int cx = 0; cx < 2; ++cx) {
+            TClass& c = out[cy * 2 + cx];
+            c.py = (cy + pad) & 1;
+            c.px = (cx + pad) & 1;
+            c.th = (k - c.py + 1) / 2;
+            c.tw = (k - c.px + 1) / 2;
+            c.dy0 = (cy + pad - c.py) / 2;
+            c.dx0 = (cx + pad - c.px) / 2;
+            c.kpad = pad_to(c.th * c.tw * ci, 64);
+            c.w_off = off;
+            off += (int64_t)rows_pad * c.kpad;
+        }
+}
+}  // namespace
+
+extern "C" {
+
+int fmri_version(void) { return 100; }
+
+const char* fmri_last_error_string(int code) {
+    switch (code) {
+        case FMRI_OK: return "ok";
+        case FMRI_E_BADARG: return "bad argument (shape/alignment constraint violated)";
+        case FMRI_E_UNSUPPORTED: return "unsupported configuration";
+        case FMRI_E_LAUNCH: return "HIP kernel launch failed";
+        case FMRI_E_WORKSPACE: return "workspace too small";
+        default: return "unknown error";
+    }
+}
+
+uint32_t fmri_test_fastdiv(uint32_t n, uint32_t d) { return fd_div(n, make_fastdiv(d)); }
+
+int fmri_kpad(int taps, int ci) { return pad_to(taps * ci, 64); }
+
+int fmri_tconv_class(int k, int pad, int cy, int cx, int ci, int rows_pad, int* py, int* px, int* th, int* tw,
+                     int* kpad, int64_t* w_off) {
+    if (cy < 0 || cy > 1 || cx < 0 || cx > 1 || k < 1 || ci < 1) return FMRI_E_BADARG;
+    TClass c[4];
+    tconv_classes(k, pad, ci, rows_pad, c);
+    const TClass& t = c[cy * 2 + cx];
+    *py = t.py; *px = t.px; *th = t.th; *tw = t.tw; *kpad = t.kpad; *w_off = t.w_off;
+    return FMRI_OK;
+}
+
+int fmri_pack_weight(const float* src, void* dst, int64_t sa, int64_t sta, int64_t sb, int64_t stb, int A, int TA,
+                     int B, int KW, int py, int px, int step, int TH, int TW, int rows_pad, int kpad, void* stream) {
+    if (!src || !dst || A < 1 || TA < 1 || B < 1 || TH < 1 || TW < 1) return FMRI_E_BADARG;
+    PackArgs p;
+    p.src = src; p.dst = (half_t*)dst; p.sa = sa; p.sta = sta; p.sb = sb; p.stb = stb;
+    p.A = A; p.TA = TA; p.B = B; p.Bp = pad_to(B, 8);
+    p.KW = KW; p.py = py; p.px = px; p.step = step; p.TH = TH; p.TW = TW;
+    p.rows_pad = rows_pad; p.kpad = kpad;
+    if (rows_pad < TA * A || kpad < TH * TW * p.Bp) return FMRI_E_BADARG;
+    return pack_weight_launch(p, S(stream));
+}
+
+int fmri_unpack_grad(const float* src, float* dst, int64_t sa, int64_t sta, int64_t sb, int64_t stb, int A, int TA,
+                     int B, int KW, int py, int px, int step, int TH, int TW, int ld, float scale, int accumulate,
+                     void* stream) {
+    if (!src || !dst || A < 1 || TA < 1 || B < 1) return FMRI_E_BADARG;
+    UnpackArgs p;
+    p.src = src; p.dst = dst; p.sa = sa; p.sta = sta; p.sb = sb; p.stb = stb;
+    p.A = A; p.TA = TA; p.B = B; p.Bp = pad_to(B, 8);
+    p.KW = KW; p.py = py; p.px = px; p.step = step; p.TH = TH; p.TW = TW;
+    p.ld = ld; p.scale = scale; p.accumulate = accumulate;
+    if (ld < TH * TW * p.Bp) return FMRI_E_BADARG;
+    return unpack_grad_launch(p, S(stream));
+}
+
+int fmri_igemm(const void* in, const void* w, void* out, const float* bias, const void* zero16, int N, int Hi, int Wi,
+               int Ci, int Ho, int Wo, int CoStore, int Co, int k, int stride, int pad, int mode, int act,
+               int out_f32, int splits, int64_t slab_stride, int bn_tile, void* stream) {
+    if (!in || !w || !out || !zero16) return FMRI_E_BADARG;
+    if (N < 1 || Ci < 8 || (Ci & 7) || CoStore < 4 || (CoStore & 3) || Co < 1 || Co > CoStore) return FMRI_E_BADARG;
+    if (bn_tile != 32 && bn_tile != 64 && bn_tile != 128) return FMRI_E_UNSUPPORTED;
+    if (splits < 1) return FMRI_E_BADARG;
+    if (splits > 1 && !out_f32) return FMRI_E_BADARG;
+    const int copad = pad_to(Co, bn_tile);
+    if (copad < CoStore) return FMRI_E_BADARG;   // every stored channel must be covered by a tile
+    IgemmArgs a;
+    a.in = (const half_t*)in; a.w = (const half_t*)w; a.out = out; a.bias = bias; a.zero = (const half_t*)zero16;
+    a.N = N; a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.Ho = Ho; a.Wo = Wo; a.CoStore = CoStore; a.Co = Co;
+    a.act = act; a.splits = splits; a.slab_stride = slab_stride;
+    a.fdCi = make_fastdiv((uint32_t)Ci);
+    int maxM = 0;
+    auto set_class = [&](IgemmClass& c, int Yc, int Xc, int oy0, int ox0, int TH, int TW, int dy0, int dx0, int dstep,
+                         int kpad, int64_t w_off) -> bool {
+        c.Yc = Yc; c.Xc = Xc; c.oy0 = oy0; c.ox0 = ox0; c.T = TH * TW; c.TW = TW;
+        c.dy0 = dy0; c.dx0 = dx0; c.dstep = dstep;
+        const int64_t M = (int64_t)N * Yc * Xc;
+        if (M > 0x7fffff00LL) return false;
+        c.M = (int)(M > 0 ? M : 0);
+        c.Kpad = kpad; c.ksteps = kpad / 64; c.w_off = w_off;
+        c.fdX = make_fastdiv((uint32_t)(Xc > 0 ? Xc : 1));
+        c.fdYX = make_fastdiv((uint32_t)(Yc * Xc > 0 ? Yc * Xc : 1));
+        c.fdTW = make_fastdiv((uint32_t)TW);
+        if (c.M > maxM) maxM = c.M;
+        return true;
+    };
+    if (mode == FMRI_CONV || mode == FMRI_CONV_FLIP) {
+        if (mode == FMRI_CONV_FLIP && stride != 1) return FMRI_E_UNSUPPORTED;
+        a.s = stride; a.os = 1; a.ncls = 1;
+        const int d0 = mode == FMRI_CONV ? -pad : pad;
+        const int ds = mode == FMRI_CONV ? 1 : -1;
+        if (!set_class(a.cls[0], Ho, Wo, 0, 0, k, k, d0, d0, ds, pad_to(k * k * Ci, 64), 0)) return FMRI_E_BADARG;
+        for (int i = 1; i < 4; ++i) a.cls[i] = a.cls[0];
+    } else if (mode == FMRI_TCONV2) {
+        if (stride != 2) return FMRI_E_UNSUPPORTED;
+        a.s = 1; a.os = 2; a.ncls = 4;
+        TClass tc[4];
+        tconv_classes(k, pad, Ci, copad, tc);
+        for (int cy = 0; cy < 2; ++cy)
+            for (int cx = 0; cx < 2; ++cx) {
+                const TClass& t = tc[cy * 2 + cx];
+                const int Yc = (Ho - cy + 1) / 2, Xc = (Wo - cx + 1) / 2;
+                if (!set_class(a.cls[cy * 2 + cx], Yc, Xc, cy, cx, t.th, t.tw, t.dy0, t.dx0, -1, t.kpad, t.w_off))
+                    return FMRI_E_BADARG;
+            }
+    } else {
+        return FMRI_E_UNSUPPORTED;
+    }
+    // no empty split: every split must own >= 1 K-step in every class
+    for (int i = 0; i < a.ncls; ++i) {
+        const int per = (a.cls[i].ksteps + splits - 1) / splits;
+        if (per * (splits - 1) >= a.cls[i].ksteps && splits > 1) return FMRI_E_BADARG;
+    }
+    if (maxM == 0) return FMRI_OK;
+    return igemm_launch(a, maxM, bn_tile, copad, out_f32 != 0, S(stream));
+}
+
+int fmri_wgrad(const void* P, const void* Q, float* out, const void* zero16, int N, int Yc, int Xc, int A, int Hq,
+               int Wq, int Bc, int k, int stride, int pad, int apad, int ba_tile, int ldo, int splits, int atomic,
+               void* stream) {
+    if (!P || !Q || !out || !zero16) return FMRI_E_BADARG;
+    if (N < 1 || A < 8 || (A & 7) || Bc < 8 || (Bc & 7) || splits < 1) return FMRI_E_BADARG;
+    if (ba_tile != 32 && ba_tile != 64 && ba_tile != 128) return FMRI_E_UNSUPPORTED;
+    if (apad % ba_tile || apad < A) return FMRI_E_BADARG;
+    const int T = k * k;
+    if (ldo % 128 || ldo < T * Bc) return FMRI_E_BADARG;
+    if (splits > 1 && !atomic) return FMRI_E_BADARG;
+    const int64_t M = (int64_t)N * Yc * Xc;
+    if (M < 1 || M > 0x7fffff00LL) return FMRI_E_BADARG;
+    WgradArgs a;
+    a.P = (const half_t*)P; a.Q = (const half_t*)Q; a.out = out; a.zero = (const half_t*)zero16;
+    a.N = N; a.Yc = Yc; a.Xc = Xc; a.A = A; a.Hq = Hq; a.Wq = Wq; a.Bc = Bc;
+    a.s = stride; a.T = T; a.TW = k; a.dy0 = -pad; a.dx0 = -pad; a.dstep = 1;
+    a.M = (int)M; a.ldo = ldo;
+    const int steps = (int)((M + 63) / 64);
+    if (splits > steps) splits = steps;
+    a.steps_per_split = (steps + splits - 1) / splits;
+    a.splits = (steps + a.steps_per_split - 1) / a.steps_per_split;
+    a.atomic = atomic;
+    a.ncol_chunks = T * Bc / 8;
+    a.fdX = make_fastdiv((uint32_t)Xc);
+    a.fdYX = make_fastdiv((uint32_t)(Yc * Xc));
+    a.fdTW = make_fastdiv((uint32_t)k);
+    a.fdBc8 = make_fastdiv((uint32_t)(Bc / 8));
+    return wgrad_launch(a, apad, ba_tile, S(stream));
+}
+
+int fmri_nchw_to_nhwc(const float* src, void* dst, int N, int C, int HW, int Cp, void* stream) {
+    if (!src || !dst || (Cp & 7) || C > Cp) return FMRI_E_BADARG;
+    return nchw_to_nhwc_launch(src, (half_t*)dst, N, C, HW, Cp, S(stream));
+}
+int fmri_nhwc_to_nchw(const void* src, float* dst, int N, int C, int HW, int Cp, float scale, void* stream) {
+    if (!src || !dst || C > Cp) return FMRI_E_BADARG;
+    return nhwc_to_nchw_launch((const half_t*)src, dst, N, C, HW, Cp, scale, S(stream));
+}
+int fmri_rows_f32_to_f16(const float* src, void* dst, int M, int C, int Cp, float scale, void* stream) {
+    if (!src || !dst || C > Cp) return FMRI_E_BADARG;
+    return rows_f32_to_f16_launch(src, (half_t*)dst, M, C, Cp, scale, S(stream));
+}
+int fmri_rows_f16_to_f32(const void* src, float* dst, int M, int C, int Cp, float scale, void* stream) {
+    if (!src || !dst || C > Cp) return FMRI_E_BADARG;
+    return rows_f16_to_f32_launch((const half_t*)src, dst, M, C, Cp, scale, S(stream));
+}
+int fmri_reduce_slabs(const float* slabs, int nslabs, int64_t slab_stride, int M, int C, int ld, const float* bias,
+                      int act, float* out32, int ld32, void* out16, int ld16, void* stream) {
+    if (!slabs || nslabs < 1 || C > ld) return FMRI_E_BADARG;
+    return reduce_slabs_launch(slabs, nslabs, slab_stride, M, C, ld, bias, act, out32, ld32, (half_t*)out16, ld16,
+                               S(stream));
+}
+int fmri_permute_chw(const float* src, float* dst, int C, int HW, int to_engine, float scale, int accumulate,
+                     void* stream) {
+    if (!src || !dst) return FMRI_E_BADARG;
+    return permute_chw_launch(src, dst, C, HW, to_engine, scale, accumulate, S(stream));
+}
+
+int fmri_bn_stats(const void* x, int M, int C, float* sums2C, void* stream) {
+    if (!x || !sums2C || (C & 7) || M < 1) return FMRI_E_BADARG;
+    return bn_stats_launch((const half_t*)x, M, C, sums2C, S(stream));
+}
+int fmri_bn_finalize(const float* sums2C, int C, float count, const float* gamma, const float* beta, float eps,
+                     float momentum, int updates, float* running_mean, float* running_var, float* mean, float* rstd,
+                     float* scale, float* shift, void* stream) {
+    if (!sums2C || !gamma || !beta || !mean || !rstd || !scale || !shift) return FMRI_E_BADARG;
+    return bn_finalize_launch(sums2C, C, count, gamma, beta, eps, momentum, updates, running_mean, running_var, mean,
+                              rstd, scale, shift, S(stream));
+}
+int fmri_bn_apply(const void* x, void* y, int M, int C, const float* scale, const float* shift, int relu,
+                  void* stream) {
+    if (!x || !y || (C & 7)) return FMRI_E_BADARG;
+    return bn_apply_launch((const half_t*)x, (half_t*)y, M, C, scale, shift, relu, S(stream));
+}
+int fmri_bn_bwd_reduce(const void* x, const void* dy, int M, int C, const float* mean, const float* rstd,
+                       const float* gamma, const float* beta, int relu, float* sums2C, void* stream) {
+    if (!x || !dy || (C & 7)) return FMRI_E_BADARG;
+    return bn_bwd_reduce_launch((const half_t*)x, (const half_t*)dy, M, C, mean, rstd, gamma, beta, relu, sums2C,
+                                S(stream));
+}
+int fmri_bn_bwd_apply(const void* x, const void* dy, void* dx, int M, int C, float count, const float* mean,
+                      const float* rstd, const float* gamma, const float* beta, int relu, const float* sums2C,
+                      void* stream) {
+    if (!x || !dy || !dx || (C & 7)) return FMRI_E_BADARG;
+    return bn_bwd_apply_launch((const half_t*)x, (const half_t*)dy, (half_t*)dx, M, C, count, mean, rstd, gamma, beta,
+                               relu, sums2C, S(stream));
+}
+int fmri_act_bwd(const void* y, const void* dy, void* dpre, int M, int C, int act, float* colsum, void* stream) {
+    if (!y || !dy || !dpre || (C & 7)) return FMRI_E_BADARG;
+    return act_bwd_launch((const half_t*)y, (const half_t*)dy, (half_t*)dpre, M, C, act, colsum, S(stream));
+}
+
+int fmri_latent_fwd(const float* head, const float* eps, int B, int Z, int zp, void* z16, float* kl_rows,
+                    float* kl_total, int sample, void* stream) {
+    if (!head || !z16 || (sample && !eps) || zp < Z) return FMRI_E_BADARG;
+    return latent_fwd_launch(head, eps, B, Z, zp, (half_t*)z16, kl_rows, kl_total, sample, S(stream));
+}
+int fmri_latent_bwd(const float* head, const float* eps, const float* dz, int ldz, float dz_unscale, float kl_w,
+                    int B, int Z, float out_scale, void* dhead16, float* dhead32, int sample, void* stream) {
+    if (!head || (sample && !eps)) return FMRI_E_BADARG;
+    return latent_bwd_launch(head, eps, dz, ldz, dz_unscale, kl_w, B, Z, out_scale, (half_t*)dhead16, dhead32, sample,
+                             S(stream));
+}
+int fmri_feat_mse(const void* feat, int B, int F, float* mse_rows, float* mse_total, void* dfeat, float gscale,
+                  void* stream) {
+    if (!feat || (F & 7)) return FMRI_E_BADARG;
+    return feat_mse_launch((const half_t*)feat, B, F, mse_rows, mse_total, (half_t*)dfeat, gscale, S(stream));
+}
+int fmri_pixel_sq(const void* x, const void* xt, int64_t npix, int C, int Cp, float* total, void* dxt, float gscale,
+                  void* stream) {
+    if (!x || !xt) return FMRI_E_BADARG;
+    return pixel_sq_launch((const half_t*)x, (const half_t*)xt, npix, C, Cp, total, (half_t*)dxt, gscale, S(stream));
+}
+int fmri_gan_head(const float* logit, int ldl, int B, float* prob, float* scal3, void* dlogit, int ldg, float gscale,
+                  void* stream) {
+    if (!logit || !scal3) return FMRI_E_BADARG;
+    return gan_head_launch(logit, ldl, B, prob, scal3, (half_t*)dlogit, ldg, gscale, S(stream));
+}
+int fmri_wae_logloss(const float* logit, int ldl, int n, int one_minus, float w, float* total, float* prob,
+                     void* dlogit, int ldg, float gscale, void* stream) {
+    if (!logit) return FMRI_E_BADARG;
+    return wae_logloss_launch(logit, ldl, n, one_minus, w, total, prob, (half_t*)dlogit, ldg, gscale, S(stream));
+}
+int fmri_compose_gate(float* scal, int* flags, float batch, float lambda_mse, float equilibrium, float margin,
+                      int gate_on, int force_dis, int force_dec, void* stream) {
+    if (!scal || !flags) return FMRI_E_BADARG;
+    return compose_gate_launch(scal, flags, batch, lambda_mse, equilibrium, margin, gate_on, force_dis, force_dec,
+                               S(stream));
+}
+int fmri_axpby_f16(const void* x, const void* y, void* out, int64_t n, float a, float b, void* stream) {
+    if (!x || !out || (n & 7)) return FMRI_E_BADARG;
+    return axpby_f16_launch((const half_t*)x, (const half_t*)y, (half_t*)out, n, a, b, S(stream));
+}
+int fmri_rmsprop(float* p, const float* g, float* sq, int64_t n, float lr, float alpha, float eps, float gscale,
+                 float clamp, const int* flag, void* stream) {
+    if (!p || !g || !sq) return FMRI_E_BADARG;
+    return rmsprop_launch(p, g, sq, n, lr, alpha, eps, gscale, clamp, flag, S(stream));
+}
+int fmri_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
+              float bc1, float bc2_sqrt, float gscale, float clamp, const int* flag, void* stream) {
+    if (!p || !g || !m || !v) return FMRI_E_BADARG;
+    return adam_launch(p, g, m, v, n, lr, b1, b2, eps, bc1, bc2_sqrt, gscale, clamp, flag, S(stream));
+}
+
+}  // extern "C"

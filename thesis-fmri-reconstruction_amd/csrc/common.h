@@ -1,0 +1,120 @@
+// Shared device/host definitions for the gfx950 (CDNA4) kernels of the fMRI VAE/GAN engine.
+// Everything here is written for MI355X only: 64-wide wavefronts, MFMA 16x16x32 f16,
+// LDS-DMA (global_load_lds) staging, 160 KB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fmri {
+
+typedef _Float16 half_t;
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef short s4v __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2, ACT_SIGMOID = 3 };
+
+// error codes of the C ABI (include/fmri_hip.h)
+enum Err { OK = 0, E_BADARG = -1, E_UNSUPPORTED = -2, E_LAUNCH = -3, E_WORKSPACE = -4 };
+
+// ---------------------------------------------------------------------------------------------
+// exact unsigned division by a runtime constant (Granlund-Montgomery round-up method):
+//   q = (t + ((n - t) >> 1)) >> sh,  t = umulhi(n, magic)      for d >= 2
+// valid for all 32-bit n.  d == 1 is encoded as magic = 0, sh = 0 with the identity path.
+// ---------------------------------------------------------------------------------------------
+struct FastDiv {
+    uint32_t magic;
+    uint32_t sh;   // shift - 1 ; 0xffffffff marks d == 1
+    uint32_t d;
+    uint32_t pad;
+};
+
+inline FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f;
+    f.d = d;
+    f.pad = 0;
+    if (d <= 1) { f.magic = 0; f.sh = 0xffffffffu; f.d = 1; return f; }
+    uint32_t s = 0;
+    while ((1ull << s) < (uint64_t)d) ++s;            // s = ceil(log2 d), 1..32
+    uint64_t m = (((1ull << s) - d) << 32) / d + 1;   // < 2^32
+    f.magic = (uint32_t)m;
+    f.sh = s - 1;
+    return f;
+}
+
+__host__ __device__ inline uint32_t fd_div(uint32_t n, const FastDiv& f) {
+    if (f.sh == 0xffffffffu) return n;
+#ifdef __HIP_DEVICE_COMPILE__
+    uint32_t t = __umulhi(n, f.magic);
+#else
+    uint32_t t = (uint32_t)(((uint64_t)n * f.magic) >> 32);
+#endif
+    return (t + ((n - t) >> 1)) >> f.sh;
+}
+
+// ---------------------------------------------------------------------------------------------
+// implicit-GEMM geometry (see igemm.hip).  One "class" = one dense sub-problem:
+//   out[n, y*os+oy0, x*os+ox0, co] = sum_{tap<T, ci} in[n, y*s+dy(tap), x*s+dx(tap), ci] * w[co][tap*Ci+ci]
+// with tap = ty*TW + tx, dy = dy0 + ty*dstep, dx = dx0 + tx*dstep.  A plain convolution has one
+// class; a stride-2 transposed convolution has four (output parity classes).
+// ---------------------------------------------------------------------------------------------
+struct IgemmClass {
+    int32_t Yc, Xc;        // rows / cols of the output sub-grid per image
+    int32_t oy0, ox0;      // output offset of the class
+    int32_t T, TW;         // number of taps, taps per tap-row
+    int32_t dy0, dx0, dstep;
+    int32_t M;             // N * Yc * Xc
+    int32_t Kpad;          // padded reduction length (multiple of 64)
+    int32_t ksteps;        // Kpad / 64
+    int64_t w_off;         // element offset of this class's packed weight matrix
+    FastDiv fdX, fdYX, fdTW;
+};
+
+struct IgemmArgs {
+    const half_t* in;
+    const half_t* w;
+    void* out;
+    const float* bias;       // may be null
+    const half_t* zero;      // >= 16 bytes of zeros (gather target for padding)
+    int32_t N, Hi, Wi, Ci;
+    int32_t Ho, Wo, CoStore, Co;
+    int32_t s, os;
+    int32_t act;
+    int32_t ncls, splits;
+    int64_t slab_stride;     // elements between split-K slabs (fp32 output only)
+    FastDiv fdCi;
+    IgemmClass cls[4];
+};
+
+// weight-gradient implicit GEMM (wgrad.hip):
+//   dW[a][tap*Bc + b] (+)= sum_m P[m][a] * Q[n, y*s+dy(tap), x*s+dx(tap), b],  m = (n, y, x)
+struct WgradArgs {
+    const half_t* P;       // [M][A]      (A multiple of 8)
+    const half_t* Q;       // [N][Hq][Wq][Bc]
+    float* out;            // [Apad][ldo] fp32, ldo = padded T*Bc
+    const half_t* zero;
+    int32_t N, Yc, Xc, A;
+    int32_t Hq, Wq, Bc;
+    int32_t s, T, TW, dy0, dx0, dstep;
+    int32_t M, ldo;
+    int32_t splits, steps_per_split, atomic;
+    int32_t ncol_chunks;   // T*Bc/8
+    FastDiv fdX, fdYX, fdTW, fdBc8;
+};
+
+// 16-byte global -> LDS DMA.  LDS destination = wave-uniform base + lane*16.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    if (act == ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == ACT_TANH) return tanhf(v);
+    if (act == ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
+    return v;
+}
+
+}  // namespace fmri

@@ -1,0 +1,201 @@
+// Tap-list implicit GEMM on MFMA for gfx950 -- the one contraction kernel behind every
+// conv / transposed-conv / dense forward and data-gradient of the VAE/GAN step.
+//
+//   out[n, y*os+oy0, x*os+ox0, co] = act( bias[co] +
+//        sum_{tap<T} sum_{ci<Ci} in[n, y*s+dy(tap), x*s+dx(tap), ci] * w[co][tap*Ci + ci] )
+//
+// Replaces (reference, models/vae_gan.py): nn.Conv2d k5 s2 p2 (:18-20), nn.ConvTranspose2d k5 s2 p2
+// (:46-53, as 4 output-parity classes -> no multiplications by inserted zeros), nn.Linear (:79,:107,
+// :156, T = 1) and their autograd data-gradients (conv dgrad == transposed conv, deconv dgrad == conv).
+//
+// Design (MI355X):
+//   * GEMM view M = N*Yc*Xc output pixels, N = Co, K = T*Ci.  Block tile 128 x BN x 64, 4 waves.
+//   * Both operand tiles are staged global -> LDS with 16-byte LDS-DMA (global_load_lds_dwordx4):
+//     the im2col gather is done by the DMA's per-lane source address, padding taps read a zero page.
+//   * LDS rows are 128 B (64 halfs); 16-B chunks are XOR-swizzled with (row>>1)&7 on the *source*
+//     side (the DMA writes linearly) and on the ds_read_b128 side -> conflict-free fragment reads.
+//   * 2-stage ring, one barrier per K-step, next tile's DMA in flight under the current tile's MFMAs.
+//   * v_mfma_f32_16x16x32_f16, weights as the A operand so every lane owns 4 consecutive output
+//     channels of one pixel -> 8-byte NHWC stores.
+//   * fp32 accumulate; epilogue fuses bias + ReLU/tanh, or writes fp32 split-K slabs.
+#include "kernels.h"
+
+namespace fmri {
+
+template <int BN, int WM, int WN, bool OUT_F32>
+__global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
+    constexpr int BM = 128;
+    constexpr int A_BYTES = BM * 128;
+    constexpr int B_BYTES = BN * 128;
+    constexpr int STAGE = A_BYTES + B_BYTES;
+    constexpr int TM = BM / WM / 16;
+    constexpr int TN = BN / WN / 16;
+    constexpr int BROWS = BN / 32;
+    static_assert(WM * WN == 4, "4 waves");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int icls = blockIdx.z % a.ncls;
+    const int split = blockIdx.z / a.ncls;
+    const IgemmClass& c = a.cls[icls];
+    const int m0 = blockIdx.x * BM;
+    if (m0 >= c.M) return;
+    const int co0 = blockIdx.y * BN;
+
+    const int trow = tid >> 3;
+    const int cphys = tid & 7;
+    const int clog = cphys ^ ((trow >> 1) & 7);
+
+    // geometry of the 4 gather rows owned by this thread (fixed for the whole K loop)
+    int iy0[4], ix0[4], pixbase[4];
+    const int YX = c.Yc * c.Xc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + trow + 32 * i;
+        const bool v = m < c.M;
+        const uint32_t mm = v ? (uint32_t)m : 0u;
+        const uint32_t n = fd_div(mm, c.fdYX);
+        const uint32_t rem = mm - n * (uint32_t)YX;
+        const uint32_t y = fd_div(rem, c.fdX);
+        const uint32_t x = rem - y * (uint32_t)c.Xc;
+        iy0[i] = v ? (int)y * a.s : -(1 << 20);
+        ix0[i] = (int)x * a.s;
+        pixbase[i] = (int)n * a.Hi * a.Wi;
+    }
+
+    const half_t* wrow = a.w + c.w_off + (int64_t)(co0 + trow) * c.Kpad + clog * 8;
+
+    auto stage_load = [&](int buf, int kstep) {
+        const int k = kstep * 64 + clog * 8;
+        const int tap = (int)fd_div((uint32_t)k, a.fdCi);
+        const int ci = k - tap * a.Ci;
+        const int ty = (int)fd_div((uint32_t)tap, c.fdTW);
+        const int tx = tap - ty * c.TW;
+        const int dy = c.dy0 + ty * c.dstep;
+        const int dx = c.dx0 + tx * c.dstep;
+        const bool tv = tap < c.T;
+        char* dstA = smem + buf * STAGE + wave * (8 * 128);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int iy = iy0[i] + dy;
+            const int ix = ix0[i] + dx;
+            const bool ok = tv && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
+            const half_t* src = ok ? a.in + ((int64_t)(pixbase[i] + iy * a.Wi + ix) * a.Ci + ci) : a.zero;
+            glds16(src, dstA + i * (32 * 128));
+        }
+        char* dstB = smem + buf * STAGE + A_BYTES + wave * (8 * 128);
+        const half_t* wsrc = wrow + (int64_t)kstep * 64;
+#pragma unroll
+        for (int i = 0; i < BROWS; ++i) glds16(wsrc + (int64_t)i * 32 * c.Kpad, dstB + i * (32 * 128));
+    };
+
+    f4 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+
+    const int wm = wave / WN, wn = wave % WN;
+    const int frow = lane & 15, fq = lane >> 4;
+
+    auto compute = [&](int buf) {
+        const char* As = smem + buf * STAGE;
+        const char* Bs = As + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            h8 af[TM], bf[TN];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const int row = wm * (BM / WM) + tm * 16 + frow;
+                const int ph = (ks * 4 + fq) ^ ((row >> 1) & 7);
+                af[tm] = *(const h8*)(As + row * 128 + ph * 16);
+            }
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int row = wn * (BN / WN) + tn * 16 + frow;
+                const int ph = (ks * 4 + fq) ^ ((row >> 1) & 7);
+                bf[tn] = *(const h8*)(Bs + row * 128 + ph * 16);
+            }
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[tn], af[tm], acc[tn][tm], 0, 0, 0);
+        }
+    };
+
+    const int per = (c.ksteps + a.splits - 1) / a.splits;
+    const int kb = split * per;
+    const int ke = (kb + per < c.ksteps) ? kb + per : c.ksteps;
+    if (kb < ke) stage_load(0, kb);
+    for (int it = kb; it < ke; ++it) {
+        const int cur = (it - kb) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (it + 1 < ke) stage_load(cur ^ 1, it + 1);
+        compute(cur);
+    }
+
+    // ---- epilogue: D[i = co][j = pixel]; lane owns pixel (lane&15), channels (lane>>4)*4 .. +3
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const int m = m0 + wm * (BM / WM) + tm * 16 + frow;
+        if (m >= c.M) continue;
+        const uint32_t n = fd_div((uint32_t)m, c.fdYX);
+        const uint32_t rem = (uint32_t)m - n * (uint32_t)YX;
+        const uint32_t y = fd_div(rem, c.fdX);
+        const uint32_t x = rem - y * (uint32_t)c.Xc;
+        const int64_t opix = ((int64_t)n * a.Ho + (y * a.os + c.oy0)) * a.Wo + (x * a.os + c.ox0);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int co = co0 + wn * (BN / WN) + tn * 16 + fq * 4;
+            if (co >= a.CoStore) continue;
+            f4 v = acc[tn][tm];
+            if constexpr (OUT_F32) {
+                float* o = (float*)a.out + (int64_t)split * a.slab_stride + opix * a.CoStore + co;
+                *(f4*)o = v;
+            } else {
+                h4 hv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float f = v[r];
+                    if (co + r < a.Co) {
+                        if (a.bias) f += a.bias[co + r];
+                        f = act_apply(f, a.act);
+                    } else {
+                        f = 0.f;
+                    }
+                    hv[r] = (half_t)f;
+                }
+                *(h4*)((half_t*)a.out + opix * a.CoStore + co) = hv;
+            }
+        }
+    }
+}
+
+template <int BN, int WM, int WN>
+static int launch_bn(const IgemmArgs& a, int maxM, int copad, bool out_f32, hipStream_t st) {
+    dim3 grid((maxM + 127) / 128, copad / BN, a.ncls * a.splits);
+    const int lds = 2 * (128 * 128 + BN * 128);
+    // fp32-slab output is used for split-K / fp32 consumers
+    if (out_f32) {
+        hipLaunchKernelGGL((igemm_kernel<BN, WM, WN, true>), grid, dim3(256), lds, st, a);
+    } else {
+        hipLaunchKernelGGL((igemm_kernel<BN, WM, WN, false>), grid, dim3(256), lds, st, a);
+    }
+    return hipGetLastError() == hipSuccess ? OK : E_LAUNCH;
+}
+
+// host entry used by api.hip.  bn_tile in {32, 64, 128}.
+int igemm_launch(const IgemmArgs& a, int maxM, int bn_tile, int copad, bool out_f32, hipStream_t st) {
+    switch (bn_tile) {
+        case 128: return launch_bn<128, 2, 2>(a, maxM, copad, out_f32, st);
+        case 64: return launch_bn<64, 2, 2>(a, maxM, copad, out_f32, st);
+        case 32: return launch_bn<32, 4, 1>(a, maxM, copad, out_f32, st);
+        default: return E_UNSUPPORTED;
+    }
+}
+
+}  // namespace fmri

@@ -1,0 +1,75 @@
+// Internal launcher declarations shared between the kernel translation units and api.hip.
+#pragma once
+#include "common.h"
+
+namespace fmri {
+
+struct PackArgs {
+    const float* src;
+    half_t* dst;
+    int64_t sa, sta, sb, stb;
+    int32_t A, TA, B, Bp;          // Bp = B padded to a multiple of 8
+    int32_t KW, py, px, step, TH, TW;
+    int32_t rows_pad, kpad;        // destination matrix [rows_pad][kpad]
+};
+
+struct UnpackArgs {
+    const float* src;      // packed [rows][ld]
+    float* dst;            // reference layout
+    int64_t sa, sta, sb, stb;
+    int32_t A, TA, B, Bp;
+    int32_t KW, py, px, step, TH, TW;
+    int32_t ld;
+    float scale;
+    int32_t accumulate;
+};
+
+int igemm_launch(const IgemmArgs& a, int maxM, int bn_tile, int copad, bool out_f32, hipStream_t st);
+int wgrad_launch(const WgradArgs& a, int apad, int ba_tile, hipStream_t st);
+
+int pack_weight_launch(const PackArgs& p, hipStream_t st);
+int unpack_grad_launch(const UnpackArgs& p, hipStream_t st);
+int nchw_to_nhwc_launch(const float* s, half_t* d, int N, int C, int HW, int Cp, hipStream_t st);
+int nhwc_to_nchw_launch(const half_t* s, float* d, int N, int C, int HW, int Cp, float scale, hipStream_t st);
+int rows_f32_to_f16_launch(const float* s, half_t* d, int M, int C, int Cp, float scale, hipStream_t st);
+int rows_f16_to_f32_launch(const half_t* s, float* d, int M, int C, int Cp, float scale, hipStream_t st);
+int reduce_slabs_launch(const float* slabs, int nslabs, int64_t slab_stride, int M, int C, int ld, const float* bias,
+                        int act, float* out32, int ld32, half_t* out16, int ld16, hipStream_t st);
+int permute_chw_launch(const float* s, float* d, int C, int HW, int to_engine, float scale, int accumulate,
+                       hipStream_t st);
+
+int bn_stats_launch(const half_t* x, int M, int C, float* sums, hipStream_t st);
+int bn_bwd_reduce_launch(const half_t* x, const half_t* dy, int M, int C, const float* mean, const float* rstd,
+                         const float* gamma, const float* beta, int relu, float* sums, hipStream_t st);
+int bn_finalize_launch(const float* sums, int C, float count, const float* gamma, const float* beta, float eps,
+                       float momentum, int updates, float* rm, float* rv, float* mean, float* rstd, float* scale,
+                       float* shift, hipStream_t st);
+int bn_apply_launch(const half_t* x, half_t* y, int M, int C, const float* scale, const float* shift, int relu,
+                    hipStream_t st);
+int bn_bwd_apply_launch(const half_t* x, const half_t* dy, half_t* dx, int M, int C, float count, const float* mean,
+                        const float* rstd, const float* gamma, const float* beta, int relu, const float* sums,
+                        hipStream_t st);
+int act_bwd_launch(const half_t* y, const half_t* dy, half_t* dpre, int M, int C, int act, float* colsum,
+                   hipStream_t st);
+
+int latent_fwd_launch(const float* head, const float* eps, int B, int Z, int zp, half_t* z16, float* kl_rows,
+                      float* kl_total, int sample, hipStream_t st);
+int latent_bwd_launch(const float* head, const float* eps, const float* dz, int ldz, float dz_unscale, float kl_w,
+                      int B, int Z, float out_scale, half_t* dhead16, float* dhead32, int sample, hipStream_t st);
+int feat_mse_launch(const half_t* feat, int B, int F, float* mse_rows, float* mse_total, half_t* dfeat, float gscale,
+                    hipStream_t st);
+int pixel_sq_launch(const half_t* x, const half_t* xt, int64_t npix, int C, int Cp, float* total, half_t* dxt,
+                    float gscale, hipStream_t st);
+int gan_head_launch(const float* logit, int ldl, int B, float* prob, float* scal, half_t* dlogit, int ldg,
+                    float gscale, hipStream_t st);
+int wae_logloss_launch(const float* logit, int ldl, int n, int one_minus, float w, float* total, float* prob,
+                       half_t* dlogit, int ldg, float gscale, hipStream_t st);
+int compose_gate_launch(float* scal, int* flags, float batch, float lambda_mse, float equilibrium, float margin,
+                        int gate_on, int force_dis, int force_dec, hipStream_t st);
+int axpby_f16_launch(const half_t* x, const half_t* y, half_t* out, int64_t n, float a, float b, hipStream_t st);
+int rmsprop_launch(float* p, const float* g, float* sq, int64_t n, float lr, float alpha, float eps, float gscale,
+                   float clamp, const int* flag, hipStream_t st);
+int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
+                float bc1, float bc2_sqrt, float gscale, float clamp, const int* flag, hipStream_t st);
+
+}  // namespace fmri

@@ -1,0 +1,193 @@
+// Layout / packing kernels: reference fp32 layouts <-> engine fp16 NHWC / packed-GEMM layouts.
+//
+//  * pack_weight : S[a*sa + ta*sta + b*sb + t(tb)*stb] (fp32) -> D[(ta,a)][(tb,b)] (fp16, zero padded)
+//                  with a tap selection t(tb) = (py + step*ty)*KW + (px + step*tx).  One kernel covers
+//                  Conv2d / ConvTranspose2d / Linear weights in forward and data-gradient orientation,
+//                  including the (C,H,W)->(H,W,C) permutation at the conv->fc flatten
+//                  (reference models/vae_gan.py:89,127,181) and the 4 parity classes of the
+//                  stride-2 transposed convolution.
+//  * unpack_grad : the inverse map for fp32 weight gradients (packed -> reference layout, scaled).
+//  * image / vector casts between NCHW fp32 and channel-padded NHWC fp16.
+#include "kernels.h"
+
+namespace fmri {
+
+__global__ void pack_weight_kernel(const PackArgs p) {
+    const int64_t total = (int64_t)p.rows_pad * p.kpad;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int row = (int)(i / p.kpad);
+        const int k = (int)(i - (int64_t)row * p.kpad);
+        float v = 0.f;
+        const int ta = row / p.A, a = row - ta * p.A;
+        const int tb = k / p.Bp, b = k - tb * p.Bp;
+        if (ta < p.TA && tb < p.TH * p.TW && b < p.B) {
+            const int ty = tb / p.TW, tx = tb - ty * p.TW;
+            const int t = (p.py + p.step * ty) * p.KW + (p.px + p.step * tx);
+            v = p.src[a * p.sa + ta * p.sta + b * p.sb + t * p.stb];
+        }
+        p.dst[i] = (half_t)v;
+    }
+}
+
+__global__ void unpack_grad_kernel(const UnpackArgs p) {
+    const int ntb = p.TH * p.TW;
+    const int64_t total = (int64_t)p.TA * p.A * ntb * p.B;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        // enumerate destination-friendly: b fastest is not contiguous in dst in general; keep simple
+        int64_t r = i;
+        const int b = (int)(r % p.B); r /= p.B;
+        const int tb = (int)(r % ntb); r /= ntb;
+        const int a = (int)(r % p.A); r /= p.A;
+        const int ta = (int)r;
+        const int ty = tb / p.TW, tx = tb - ty * p.TW;
+        const int t = (p.py + p.step * ty) * p.KW + (p.px + p.step * tx);
+        const float v = p.src[(int64_t)(ta * p.A + a) * p.ld + tb * p.Bp + b] * p.scale;
+        float* d = p.dst + a * p.sa + ta * p.sta + b * p.sb + t * p.stb;
+        if (p.accumulate) *d += v; else *d = v;
+    }
+}
+
+// NCHW fp32 -> NHWC fp16 with channel padding (zero fill).  One thread per (pixel, 8-channel chunk).
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, half_t* __restrict__ dst, int N, int C, int HW,
+                                    int Cp) {
+    const int64_t total = (int64_t)N * HW * (Cp / 8);
+    const int cch = Cp / 8;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % cch);
+        const int64_t pix = i / cch;
+        const int n = (int)(pix / HW);
+        const int hw = (int)(pix - (int64_t)n * HW);
+        h8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = ch * 8 + j;
+            v[j] = c < C ? (half_t)src[((int64_t)n * C + c) * HW + hw] : (half_t)0.f;
+        }
+        *(h8*)(dst + pix * Cp + ch * 8) = v;
+    }
+}
+
+// NHWC fp16 (channel stride Cp) -> NCHW fp32 (C channels), scaled.
+__global__ void nhwc_to_nchw_kernel(const half_t* __restrict__ src, float* __restrict__ dst, int N, int C, int HW,
+                                    int Cp, float scale) {
+    const int64_t total = (int64_t)N * C * HW;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int hw = (int)(i % HW);
+        const int64_t nc = i / HW;
+        const int c = (int)(nc % C);
+        const int n = (int)(nc / C);
+        dst[i] = (float)src[((int64_t)n * HW + hw) * Cp + c] * scale;
+    }
+}
+
+// rows fp32 [M][C] -> fp16 [M][Cp] (zero padded), scaled
+__global__ void rows_f32_to_f16_kernel(const float* __restrict__ src, half_t* __restrict__ dst, int M, int C, int Cp,
+                                       float scale) {
+    const int64_t total = (int64_t)M * Cp;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cp);
+        const int64_t m = i / Cp;
+        dst[i] = c < C ? (half_t)(src[m * C + c] * scale) : (half_t)0.f;
+    }
+}
+
+// rows fp16 [M][Cp] -> fp32 [M][C], scaled
+__global__ void rows_f16_to_f32_kernel(const half_t* __restrict__ src, float* __restrict__ dst, int M, int C, int Cp,
+                                       float scale) {
+    const int64_t total = (int64_t)M * C;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int64_t m = i / C;
+        dst[i] = (float)src[m * Cp + c] * scale;
+    }
+}
+
+// sum of split-K slabs (+ optional bias, activation) -> fp32 and/or fp16 rows
+__global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int nslabs, int64_t slab_stride, int M, int C,
+                                    int ld, const float* __restrict__ bias, int act, float* __restrict__ out32,
+                                    int ld32, half_t* __restrict__ out16, int ld16) {
+    const int64_t total = (int64_t)M * ld;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % ld);
+        const int64_t m = i / ld;
+        float v = 0.f;
+        if (c < C) {
+            for (int s = 0; s < nslabs; ++s) v += slabs[s * slab_stride + i];
+            if (bias) v += bias[c];
+            v = act_apply(v, act);
+        }
+        if (out32 && c < C) out32[m * ld32 + c] = v;
+        if (out16 && c < ld16) out16[m * ld16 + c] = (half_t)v;
+    }
+}
+
+// permute a per-feature vector between reference (C,HW) order and engine (HW,C) order
+__global__ void permute_chw_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int HW,
+                                   int to_engine, float scale, int accumulate) {
+    const int total = C * HW;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int c = i / HW, hw = i - c * HW;   // i indexes reference order
+        const int e = hw * C + c;                // engine order
+        if (to_engine) {
+            dst[e] = src[i] * scale;
+        } else {
+            if (accumulate) dst[i] += src[e] * scale; else dst[i] = src[e] * scale;
+        }
+    }
+}
+
+static inline int nblocks(int64_t total, int threads = 256, int cap = 4096) {
+    int64_t b = (total + threads - 1) / threads;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+int pack_weight_launch(const PackArgs& p, hipStream_t st) {
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(nblocks((int64_t)p.rows_pad * p.kpad)), dim3(256), 0, st, p);
+    return hipGetLastError() == hipSuccess ? OK : E_LAUNCH;
+}
+int unpack_grad_launch(const UnpackArgs& p, hipStream_t st) {
+    const int64_t total = (int64_t)p.TA * p.A * p.TH * p.TW * p.B;
+    hipLaunchKernelGGL(unpack_grad_kernel, dim3(nblocks(total)), dim3(256), 0, st, p);
+    return hipGetLastError() == hipSuccess ? OK : E_LAUNCH;
+}
+int nchw_to_nhwc_launch(const float* s, half_t* d, int N, int C, int HW, int Cp, hipStream_t st) {
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(nblocks((int64_t)N * HW * (Cp / 8))), dim3(256), 0, st, s, d, N, C,
+                       HW, Cp);
+    return hipGetLastError() == hipSuccess ? OK : E_LAUNCH;
+}
+int nhwc_to_nchw_launch(const half_t* s, float* d, int N, int C, int HW, int Cp, float scale, hipStream_t st) {
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(nblocks((int64_t)N * C * HW)), dim3(256), 0, st, s, d, N, C, HW, Cp,
+                       scale);
+    return hipGetLastError() == hipSuccess ? OK : E_LAUNCH;
+}
+int rows_f32_to_f16_launch(const float* s, half_t* d, int M, int C, int Cp, float scale, hipStream_t st) {
+    hipLaunchKernelGGL(rows_f32_to_f16_kernel, dim3(nblocks((int64_t)M * Cp)), dim3(256), 0, st, s, d, M, C, Cp, scale);
+    return hipGetLastError() == hipSuccess ? OK : E_LAUNCH;
+}
+int rows_f16_to_f32_launch(const half_t* s, float* d, int M, int C, int Cp, float scale, hipStream_t st) {
+    hipLaunchKernelGGL(rows_f16_to_f32_kernel, dim3(nblocks((int64_t)M * C)), dim3(256), 0, st, s, d, M, C, Cp, scale);
+    return hipGetLastError() == hipSuccess ? OK : E_LAUNCH;
+}
+int reduce_slabs_launch(const float* slabs, int nslabs, int64_t slab_stride, int M, int C, int ld, const float* bias,
+                        int act, float* out32, int ld32, half_t* out16, int ld16, hipStream_t st) {
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(nblocks((int64_t)M * ld)), dim3(256), 0, st, slabs, nslabs,
+                       slab_stride, M, C, ld, bias, act, out32, ld32, out16, ld16);
+    return hipGetLastError() == hipSuccess ? OK : E_LAUNCH;
+}
+int permute_chw_launch(const float* s, float* d, int C, int HW, int to_engine, float scale, int accumulate,
+                       hipStream_t st) {
+    hipLaunchKernelGGL(permute_chw_kernel, dim3(nblocks((int64_t)C * HW)), dim3(256), 0, st, s, d, C, HW, to_engine,
+                       scale, accumulate);
+    return hipGetLastError() == hipSuccess ? OK : E_LAUNCH;
+}
+
+}  // namespace fmri

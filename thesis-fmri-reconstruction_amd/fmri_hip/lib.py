@@ -1,0 +1,112 @@
+"""ctypes binding of libfmri_hip.so (C ABI: include/fmri_hip.h).
+
+There is no fallback: if the shared library is missing or a kernel returns an error the caller gets a
+RuntimeError.  PyTorch is used only as the allocator / stream provider (tensor.data_ptr(),
+torch.cuda.current_stream()).
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfmri_hip.so")
+
+_i, _f, _l, _p = C.c_int, C.c_float, C.c_int64, C.c_void_p
+
+# name -> argtypes (restype is int unless noted)
+_SIGS = {
+    "fmri_tconv_class": [_i, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i),
+                         C.POINTER(_i), C.POINTER(_l)],
+    "fmri_kpad": [_i, _i],
+    "fmri_pack_weight": [_p, _p, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "fmri_unpack_grad": [_p, _p, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p],
+    "fmri_igemm": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _l, _i, _p],
+    "fmri_wgrad": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "fmri_nchw_to_nhwc": [_p, _p, _i, _i, _i, _i, _p],
+    "fmri_nhwc_to_nchw": [_p, _p, _i, _i, _i, _i, _f, _p],
+    "fmri_rows_f32_to_f16": [_p, _p, _i, _i, _i, _f, _p],
+    "fmri_rows_f16_to_f32": [_p, _p, _i, _i, _i, _f, _p],
+    "fmri_reduce_slabs": [_p, _i, _l, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p],
+    "fmri_permute_chw": [_p, _p, _i, _i, _i, _f, _i, _p],
+    "fmri_bn_stats": [_p, _i, _i, _p, _p],
+    "fmri_bn_finalize": [_p, _i, _f, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p, _p, _p],
+    "fmri_bn_apply": [_p, _p, _i, _i, _p, _p, _i, _p],
+    "fmri_bn_bwd_reduce": [_p, _p, _i, _i, _p, _p, _p, _p, _i, _p, _p],
+    "fmri_bn_bwd_apply": [_p, _p, _p, _i, _i, _f, _p, _p, _p, _p, _i, _p, _p],
+    "fmri_act_bwd": [_p, _p, _p, _i, _i, _i, _p, _p],
+    "fmri_latent_fwd": [_p, _p, _i, _i, _i, _p, _p, _p, _i, _p],
+    "fmri_latent_bwd": [_p, _p, _p, _i, _f, _f, _i, _i, _f, _p, _p, _i, _p],
+    "fmri_feat_mse": [_p, _i, _i, _p, _p, _p, _f, _p],
+    "fmri_pixel_sq": [_p, _p, _l, _i, _i, _p, _p, _f, _p],
+    "fmri_gan_head": [_p, _i, _i, _p, _p, _p, _i, _f, _p],
+    "fmri_wae_logloss": [_p, _i, _i, _i, _f, _p, _p, _p, _i, _f, _p],
+    "fmri_compose_gate": [_p, _p, _f, _f, _f, _f, _i, _i, _i, _p],
+    "fmri_axpby_f16": [_p, _p, _p, _l, _f, _f, _p],
+    "fmri_rmsprop": [_p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _p],
+    "fmri_adam": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _f, _f, _f, _p, _p],
+}
+
+EXPORTS = sorted(list(_SIGS) + ["fmri_version", "fmri_last_error_string", "fmri_test_fastdiv"])
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m fmri_hip.build` (hipcc --offload-arch=gfx950). "
+            "The engine has no CPU / eager fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, args in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = _i
+    lib.fmri_version.restype = _i
+    lib.fmri_last_error_string.restype = C.c_char_p
+    lib.fmri_last_error_string.argtypes = [_i]
+    lib.fmri_test_fastdiv.restype = C.c_uint32
+    lib.fmri_test_fastdiv.argtypes = [C.c_uint32, C.c_uint32]
+    _lib = lib
+    return lib
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def check(code, what=""):
+    if code != 0:
+        msg = load().fmri_last_error_string(code).decode()
+        raise RuntimeError(f"fmri_hip: {what} failed: {msg} ({code})")
+
+
+def call(name, *args):
+    """Invoke an entry point on torch's current stream and raise on error."""
+    lib = load()
+    code = getattr(lib, name)(*args, stream())
+    if code != 0:
+        check(code, name)
+
+
+def tconv_class(k, pad, cy, cx, ci, rows_pad):
+    lib = load()
+    py, px, th, tw, kpad = _i(), _i(), _i(), _i(), _i()
+    woff = _l()
+    check(lib.fmri_tconv_class(k, pad, cy, cx, ci, rows_pad, py, px, th, tw, kpad, woff), "fmri_tconv_class")
+    return dict(py=py.value, px=px.value, th=th.value, tw=tw.value, kpad=kpad.value, w_off=woff.value)
+
+
+def kpad(taps, ci):
+    return load().fmri_kpad(taps, ci)

@@ -1,0 +1,404 @@
+"""Sub-networks of the VAE/GAN as explicit forward / backward passes over the HIP operators.
+
+Mirrors (reference models/vae_gan.py): Encoder :63-96, Decoder :99-132, Discriminator :135-187,
+CognitiveEncoder :190-232, WaeDiscriminator :499-529.  Parameter names/shapes are the reference
+state-dict entries; activations are fp16 NHWC, statistics/losses/master weights fp32.
+
+Backward passes are written by hand (no autograd inside the engine): each returns/accumulates exactly
+the gradients the training-step bodies consume, and supports several cotangent "streams" through one
+saved forward pass (the two-stream trick of SURVEY 8a-14).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+from . import lib
+from .ops import (ACT_NONE, ACT_RELU, ACT_TANH, BatchNorm, ConvLayer, DenseLayer, act_backward, pad8)
+from .params import (ArchConfig, FlatGroup, cognitive_encoder_spec, decoder_spec, discriminator_spec, encoder_spec,
+                     wae_discriminator_spec)
+
+_P = lib.ptr
+
+
+class FusedHeads:
+    """l_mu | l_var as one N = 2z GEMM (models/vae_gan.py:84-85,91-92): weights are concatenated into a
+    scratch fp32 matrix that is refreshed whenever the master parameters change."""
+
+    def __init__(self, group: FlatGroup, k_in: int, z: int):
+        self.group, self.z, self.k_in = group, z, k_in
+        dev = group.device
+        self.wcat = torch.empty(2 * z, k_in, dtype=torch.float32, device=dev)
+        self.bcat = torch.empty(2 * z, dtype=torch.float32, device=dev)
+        self.gw = torch.zeros(2 * z, k_in, dtype=torch.float32, device=dev)
+        self.dense = DenseLayer(_Versioned(group), (self.wcat, self.gw), (self.bcat, None), k_in, 2 * z)
+        self._v = -1
+
+    def _sync(self):
+        if self._v != self.group.version:
+            v = self.group.views
+            z = self.z
+            self.wcat[:z].copy_(v["l_mu.weight"])
+            self.wcat[z:].copy_(v["l_var.weight"])
+            self.bcat[:z].copy_(v["l_mu.bias"])
+            self.bcat[z:].copy_(v["l_var.bias"])
+            self._v = self.group.version
+
+    def forward(self, h16):
+        self._sync()
+        _, head32 = self.dense.forward(h16, ACT_NONE, want16=False, want32=True)
+        return head32                                   # [B, 2z] fp32 (mu | logvar), bias added
+
+    def backward(self, h16, dhead16, scale, need_dgrad=True):
+        self._sync()
+        g = self.group.grads
+        z = self.z
+        self.gw.zero_()
+        self.dense.wgrad(h16, dhead16, scale)
+        g["l_mu.weight"].add_(self.gw[:z])
+        g["l_var.weight"].add_(self.gw[z:])
+        bs = dhead16.float().sum(0) * (1.0 / scale)
+        g["l_mu.bias"].add_(bs[:z])
+        g["l_var.bias"].add_(bs[z:2 * z])
+        if need_dgrad:
+            dh, _ = self.dense.dgrad(dhead16)
+            return dh
+        return None
+
+
+class _Versioned:
+    """Adapter so scratch-weight layers follow the owning group's version counter."""
+
+    def __init__(self, group):
+        self._g = group
+
+    @property
+    def version(self):
+        return self._g.version
+
+
+# ------------------------------------------------------------------------------------------------
+class EncoderNet:
+    def __init__(self, cfg: ArchConfig, device, channel_in: int = 3):
+        self.cfg = cfg
+        self.group = FlatGroup(encoder_spec(cfg, channel_in), device)
+        g = self.group
+        self.convs, self.bns = [], []
+        cin = channel_in
+        for i, c in enumerate(cfg.encoder_channels[:3]):
+            self.convs.append(ConvLayer(g, f"conv.{i}.conv.weight", None, "conv", cin, c, cfg.kernel_size, cfg.stride,
+                                        cfg.padding))
+            self.bns.append(BatchNorm(g, f"conv.{i}.bn.", c))
+            cin = c
+        self.size = cin
+        hw = cfg.fc_input * cfg.fc_input
+        self.fc = DenseLayer(g, "fc.0.weight", None, hw * cin, cfg.fc_output, in_perm=(cin, hw))
+        self.fc_bn = BatchNorm(g, "fc.1.", cfg.fc_output)
+        self.heads = FusedHeads(g, cfg.fc_output, cfg.latent_dim)
+
+    def all_bns(self):
+        return self.bns + [self.fc_bn]
+
+    def forward(self, x16: torch.Tensor, train_stats: bool = True):
+        """x16 [B,H,W,8] fp16 -> (head32 [B,2z], ctx)."""
+        acts, raws, svs = [x16], [], []
+        h = x16
+        upd = 1 if train_stats else 0
+        for conv, bn in zip(self.convs, self.bns):
+            raw = conv.forward(h)
+            h, sv = bn.forward(raw, relu=True, updates=upd)
+            raws.append(raw)
+            svs.append(sv)
+            acts.append(h)
+        flat = h.reshape(h.shape[0], -1)
+        raw_fc, _ = self.fc.forward(flat)
+        hfc, svfc = self.fc_bn.forward(raw_fc, relu=True, updates=upd)
+        head32 = self.heads.forward(hfc)
+        return head32, dict(acts=acts, raws=raws, svs=svs, flat=flat, raw_fc=raw_fc, hfc=hfc, svfc=svfc)
+
+    def backward(self, ctx, dhead16: torch.Tensor, scale: float):
+        """Accumulate encoder parameter gradients of (1/scale)*<dhead16, head>."""
+        dh = self.heads.backward(ctx["hfc"], dhead16, scale)
+        draw_fc, _ = self.fc_bn.backward(ctx["raw_fc"], dh, ctx["svfc"], True, scale)
+        self.fc.wgrad(ctx["flat"], draw_fc, scale)
+        dflat, _ = self.fc.dgrad(draw_fc)
+        d = dflat.reshape(ctx["acts"][3].shape)
+        for i in (2, 1, 0):
+            draw, _ = self.bns[i].backward(ctx["raws"][i], d, ctx["svs"][i], True, scale)
+            self.convs[i].wgrad(ctx["acts"][i], draw, scale)
+            if i > 0:
+                _, hi, wi, _ = ctx["acts"][i].shape
+                d = self.convs[i].dgrad(draw, hi, wi)
+
+
+class CognitiveEncoderNet:
+    def __init__(self, cfg: ArchConfig, n_voxels: int, device):
+        self.cfg, self.n_voxels = cfg, n_voxels
+        self.group = FlatGroup(cognitive_encoder_spec(cfg, n_voxels), device)
+        g = self.group
+        self.fc1 = DenseLayer(g, "fc1.0.weight", None, n_voxels, 1024)
+        self.fc1_bn = BatchNorm(g, "fc1.1.", 1024)
+        self.heads = FusedHeads(g, 1024, cfg.latent_dim)
+
+    def all_bns(self):
+        return [self.fc1_bn]
+
+    def forward(self, fmri16: torch.Tensor, train_stats: bool = True):
+        raw, _ = self.fc1.forward(fmri16)
+        h, sv = self.fc1_bn.forward(raw, relu=True, updates=1 if train_stats else 0)
+        return self.heads.forward(h), dict(x=fmri16, raw=raw, h=h, sv=sv)
+
+    def backward(self, ctx, dhead16, scale):
+        dh = self.heads.backward(ctx["h"], dhead16, scale)
+        draw, _ = self.fc1_bn.backward(ctx["raw"], dh, ctx["sv"], True, scale)
+        self.fc1.wgrad(ctx["x"], draw, scale)
+
+
+# ------------------------------------------------------------------------------------------------
+class DecoderNet:
+    def __init__(self, cfg: ArchConfig, device, size: Optional[int] = None):
+        self.cfg = cfg
+        size = cfg.encoder_channels[2] if size is None else size
+        self.group = FlatGroup(decoder_spec(cfg, size), device)
+        g = self.group
+        hw = cfg.fc_input * cfg.fc_input
+        self.size0 = size
+        self.fc = DenseLayer(g, "fc.0.weight", None, cfg.latent_dim, hw * size, out_perm=(size, hw))
+        self.fc_bn = BatchNorm(g, "fc.1.", hw * size, perm=(size, hw))
+        chans = [(size, size), (size, cfg.decoder_channels[1]), (cfg.decoder_channels[1], cfg.decoder_channels[2])]
+        self.deconvs, self.bns = [], []
+        for i, (ci, co) in enumerate(chans):
+            self.deconvs.append(ConvLayer(g, f"conv.{i}.conv.weight", None, "deconv", ci, co, cfg.kernel_size,
+                                          cfg.stride, cfg.padding, 1 if cfg.output_pad_dec[i] else 0))
+            self.bns.append(BatchNorm(g, f"conv.{i}.bn.", co))
+        self.c3 = ConvLayer(g, "conv.3.0.weight", "conv.3.0.bias", "conv", cfg.decoder_channels[2],
+                            cfg.decoder_channels[3], 5, 1, 2)
+
+    def all_bns(self):
+        return [self.fc_bn] + self.bns
+
+    def forward(self, z16: torch.Tensor, groups: int, out: Optional[torch.Tensor] = None, train_stats: bool = True):
+        """z16 [G*B, zp]: G independent decoder calls (own BN batch statistics each, reference
+        models/vae_gan.py:279,282) executed as one batch.  Returns (images fp16 [G*B,H,W,8], ctx)."""
+        GB = z16.shape[0]
+        B = GB // groups
+        f = self.cfg.fc_input
+        upd = 1 if train_stats else 0
+        raw_fc, _ = self.fc.forward(z16)
+        act_fc = torch.empty_like(raw_fc)
+        sv_fc = []
+        for gi in range(groups):
+            _, sv = self.fc_bn.forward(raw_fc[gi * B:(gi + 1) * B], True, upd, out=act_fc[gi * B:(gi + 1) * B])
+            sv_fc.append(sv)
+        h = act_fc.reshape(GB, f, f, self.size0)
+        acts, raws, svs = [h], [], []
+        for dc, bn in zip(self.deconvs, self.bns):
+            raw = dc.forward(h)
+            act = torch.empty_like(raw)
+            sl = []
+            for gi in range(groups):
+                _, sv = bn.forward(raw[gi * B:(gi + 1) * B], True, upd, out=act[gi * B:(gi + 1) * B])
+                sl.append(sv)
+            raws.append(raw)
+            svs.append(sl)
+            acts.append(act)
+            h = act
+        y = self.c3.forward(h, ACT_TANH, out=out)
+        return y, dict(z=z16, raw_fc=raw_fc, sv_fc=sv_fc, acts=acts, raws=raws, svs=svs, y=y, B=B, groups=groups)
+
+    def backward(self, ctx, cot: torch.Tensor, entries: List[dict]):
+        """cot [E*B,H,W,8] fp16 stacks E cotangent blocks w.r.t. the decoder output; entries[e] =
+        dict(g=<forward group whose activations it belongs to>, scale=<float>, train=<accumulate param grads>,
+        need_dz=<bool>).  Returns {e: dz fp32 [B, z] (true scale)} for entries with need_dz."""
+        B = ctx["B"]
+        E = len(entries)
+        rows = lambda t, i: t[i * B:(i + 1) * B]
+        y = ctx["y"]
+        dpre = torch.empty_like(cot)
+        for e, en in enumerate(entries):
+            colsum = None
+            if en["train"]:
+                colsum = torch.zeros(pad8(self.c3.cout), dtype=torch.float32, device=cot.device)
+            act_backward(rows(y, en["g"]), rows(cot, e), ACT_TANH, colsum, out=rows(dpre, e))
+            if en["train"]:
+                self.c3.bg.add_(colsum[:self.c3.cout], alpha=1.0 / en["scale"])
+                self.c3.wgrad(rows(ctx["acts"][3], en["g"]), rows(dpre, e), en["scale"])
+        _, hi, wi, _ = ctx["acts"][3].shape
+        d = self.c3.dgrad(dpre, hi, wi)
+        for i in (2, 1, 0):
+            draw = torch.empty_like(d)
+            for e, en in enumerate(entries):
+                self.bns[i].backward(rows(ctx["raws"][i], en["g"]), rows(d, e), ctx["svs"][i][en["g"]], True,
+                                     en["scale"] if en["train"] else None, out=rows(draw, e))
+                if en["train"]:
+                    self.deconvs[i].wgrad(rows(ctx["acts"][i], en["g"]), rows(draw, e), en["scale"])
+            _, hi, wi, _ = ctx["acts"][i].shape
+            d = self.deconvs[i].dgrad(draw, hi, wi)
+        dflat = d.reshape(E * B, -1)
+        draw_fc = torch.empty_like(dflat)
+        out = {}
+        for e, en in enumerate(entries):
+            self.fc_bn.backward(rows(ctx["raw_fc"], en["g"]), rows(dflat, e), ctx["sv_fc"][en["g"]], True,
+                                en["scale"] if en["train"] else None, out=rows(draw_fc, e))
+            if en["train"]:
+                self.fc.wgrad(rows(ctx["z"], en["g"]), rows(draw_fc, e), en["scale"])
+            if en.get("need_dz"):
+                _, dz32 = self.fc.dgrad(rows(draw_fc, e).contiguous(), want32=True)
+                out[e] = dz32 * (1.0 / en["scale"])
+        return out
+
+
+# ------------------------------------------------------------------------------------------------
+class DiscriminatorNet:
+    def __init__(self, cfg: ArchConfig, device, recon_level: int = 3):
+        if recon_level != 3:
+            raise NotImplementedError("the HIP engine implements recon_level=3 (the reference default)")
+        self.cfg = cfg
+        self.group = FlatGroup(discriminator_spec(cfg), device)
+        g = self.group
+        d = cfg.discrim_channels
+        self.c0 = ConvLayer(g, "conv.0.0.weight", "conv.0.0.bias", "conv", 3, d[0], 5, cfg.stride_gan, 2)
+        self.convs, self.bns = [], []
+        cin = d[0]
+        for i in (1, 2, 3):
+            self.convs.append(ConvLayer(g, f"conv.{i}.conv.weight", None, "conv", cin, d[i], cfg.kernel_size,
+                                        cfg.stride, cfg.padding))
+            self.bns.append(BatchNorm(g, f"conv.{i}.bn.", d[i]))
+            cin = d[i]
+        hw = cfg.fc_input_gan * cfg.fc_input_gan
+        self.fc0 = DenseLayer(g, "fc.0.weight", None, hw * cin, cfg.fc_output_gan, in_perm=(cin, hw))
+        self.fc_bn = BatchNorm(g, "fc.1.", cfg.fc_output_gan)
+        self.fc3 = DenseLayer(g, "fc.3.weight", "fc.3.bias", cfg.fc_output_gan, 1)
+
+    def all_bns(self):
+        return self.bns + [self.fc_bn]
+
+    def forward(self, x16: torch.Tensor, train_stats: bool = True):
+        """x16 [3B,H,W,8] = cat(orig, predicted, sampled).  One pass produces both reference outputs:
+        the raw conv-3 features ('REC', models/vae_gan.py:166-173) and the class logits ('GAN', :176-183).
+        Conv BN layers receive the reference's two running-stat updates per step."""
+        a0 = self.c0.forward(x16, ACT_RELU)
+        acts, raws, svs = [a0], [], []
+        h = a0
+        for conv, bn in zip(self.convs, self.bns):
+            raw = conv.forward(h)
+            h, sv = bn.forward(raw, relu=True, updates=2 if train_stats else 0)
+            raws.append(raw)
+            svs.append(sv)
+            acts.append(h)
+        flat = h.reshape(h.shape[0], -1)
+        raw_fc, _ = self.fc0.forward(flat)
+        hfc, svfc = self.fc_bn.forward(raw_fc, relu=True, updates=1 if train_stats else 0)
+        _, logit32 = self.fc3.forward(hfc, ACT_NONE, want16=False, want32=True)
+        ctx = dict(x=x16, acts=acts, raws=raws, svs=svs, flat=flat, raw_fc=raw_fc, hfc=hfc, svfc=svfc)
+        return raws[2], logit32, ctx
+
+    def backward(self, ctx, dlogit16: Optional[torch.Tensor], scale_a: float, dfeat16: Optional[torch.Tensor],
+                 scale_b: float, train: bool, img_rows: Optional[slice]):
+        """Two cotangent streams through one saved forward:
+             A: d(sum bce)/d logit  (dlogit16 [3B,8], scale_a) -- accumulates discriminator grads if ``train``
+             B: d(sum mse)/d raw conv-3 features (dfeat16 [3B,h,w,c], scale_b) -- data gradient only
+           Returns (dimg_A, dimg_B): cotangents w.r.t. input images ``img_rows`` (None if not requested)."""
+        n3 = ctx["x"].shape[0]
+        streams = []
+        if dlogit16 is not None:
+            if train:
+                self.fc3.wgrad(ctx["hfc"], dlogit16, scale_a)
+                self.fc3.bias_grad(dlogit16, scale_a)
+            dh, _ = self.fc3.dgrad(dlogit16)
+            draw_fc, _ = self.fc_bn.backward(ctx["raw_fc"], dh, ctx["svfc"], True, scale_a if train else None)
+            if train:
+                self.fc0.wgrad(ctx["flat"], draw_fc, scale_a)
+            dflat, _ = self.fc0.dgrad(draw_fc)
+            d3 = dflat.reshape(ctx["acts"][3].shape)
+            draw3, _ = self.bns[2].backward(ctx["raws"][2], d3, ctx["svs"][2], True, scale_a if train else None)
+            streams.append(dict(d=draw3, scale=scale_a, train=train))
+        if dfeat16 is not None:
+            streams.append(dict(d=dfeat16.reshape(ctx["raws"][2].shape), scale=scale_b, train=False))
+        S = len(streams)
+        d = torch.cat([s["d"] for s in streams], 0) if S > 1 else streams[0]["d"]
+        rows = lambda t, i: t[i * n3:(i + 1) * n3]
+        # conv3 .. conv1
+        for li in (2, 1, 0):
+            if li < 2:   # BN+ReLU backward of block li+1 happened already for li == 2
+                pass
+            for si, s in enumerate(streams):
+                if s["train"]:
+                    self.convs[li].wgrad(ctx["acts"][li], rows(d, si), s["scale"])
+            _, hi, wi, _ = ctx["acts"][li].shape
+            dact = self.convs[li].dgrad(d, hi, wi)
+            if li > 0:
+                dn = torch.empty_like(dact)
+                for si, s in enumerate(streams):
+                    self.bns[li - 1].backward(ctx["raws"][li - 1], rows(dact, si), ctx["svs"][li - 1], True,
+                                              s["scale"] if s["train"] else None, out=rows(dn, si))
+                d = dn
+            else:
+                d = dact
+        # conv0: bias + ReLU
+        a0 = ctx["acts"][0]
+        dpre = torch.empty_like(d)
+        outs = []
+        for si, s in enumerate(streams):
+            colsum = None
+            if s["train"]:
+                colsum = torch.zeros(self.c0.coutp, dtype=torch.float32, device=d.device)
+            act_backward(a0, rows(d, si), ACT_RELU, colsum, out=rows(dpre, si))
+            if s["train"]:
+                self.c0.bg.add_(colsum[:self.c0.cout], alpha=1.0 / s["scale"])
+                self.c0.wgrad(ctx["x"], rows(dpre, si), s["scale"])
+            if img_rows is not None:
+                _, hi, wi, _ = ctx["x"].shape
+                outs.append(self.c0.dgrad(rows(dpre, si)[img_rows].contiguous(), hi, wi))
+            else:
+                outs.append(None)
+        res = [None, None]
+        k = 0
+        if dlogit16 is not None:
+            res[0] = outs[k]
+            k += 1
+        if dfeat16 is not None:
+            res[1] = outs[k]
+        return res[0], res[1]
+
+
+# ------------------------------------------------------------------------------------------------
+class WaeDiscriminatorNet:
+    """Latent-space discriminator MLP z -> 512 -> 512 -> 512 -> 512 -> 1 (models/vae_gan.py:499-529)."""
+
+    def __init__(self, cfg: ArchConfig, device, dim_h: int = 512):
+        self.cfg = cfg
+        self.group = FlatGroup(wae_discriminator_spec(cfg, dim_h), device)
+        dims = [cfg.latent_dim, dim_h, dim_h, dim_h, dim_h, 1]
+        self.layers = [DenseLayer(self.group, f"main.{idx}.weight", f"main.{idx}.bias", dims[j], dims[j + 1])
+                       for j, idx in enumerate((0, 2, 4, 6, 8))]
+
+    def all_bns(self):
+        return []
+
+    def forward(self, z16: torch.Tensor):
+        hs = [z16]
+        h = z16
+        for l in self.layers[:-1]:
+            h, _ = l.forward(h, ACT_RELU)
+            hs.append(h)
+        _, logit32 = self.layers[-1].forward(h, ACT_NONE, want16=False, want32=True)
+        return logit32, dict(hs=hs)
+
+    def backward(self, ctx, dlogit16, scale, train: bool, need_dz: bool):
+        d = dlogit16
+        hs = ctx["hs"]
+        for j in range(4, -1, -1):
+            l = self.layers[j]
+            if train:
+                l.wgrad(hs[j], d, scale)
+                l.bias_grad(d, scale)
+            if j == 0 and not need_dz:
+                return None
+            if j == 0:
+                _, dz32 = l.dgrad(d, want32=True)
+                return dz32 * (1.0 / scale)
+            dn, _ = l.dgrad(d)
+            d = act_backward(hs[j], dn, ACT_RELU)
+        return None

@@ -1,0 +1,483 @@
+"""Layer-level operators of the engine: thin Python objects that own packed fp16 weights and enqueue
+the HIP kernels of libfmri_hip.so (C ABI in include/fmri_hip.h) on torch's current stream.
+
+Activations are fp16 NHWC tensors ``[N, H, W, Cp]`` (Cp = channels padded to 8; dense activations are
+``[M, Kp]``).  Cotangents are fp16 too and carry an explicit python-float ``scale`` (stored = true*scale)
+chosen by the step code so that they stay inside fp16's normal range; weight gradients are unscaled when
+they are unpacked into the fp32 ``.grad`` buffers.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
+
+import torch
+
+from . import lib
+
+ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
+MODE_CONV, MODE_TCONV2, MODE_CONV_FLIP = 0, 1, 2
+
+_P = lib.ptr
+
+
+def pad8(c: int) -> int:
+    return (c + 7) // 8 * 8
+
+
+def ceil_to(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
+
+
+def tile_for(c: int) -> int:
+    return 128 if c >= 128 else (64 if c >= 64 else 32)
+
+
+_ZERO = {}
+
+
+def zero_page(device) -> torch.Tensor:
+    key = str(device)
+    if key not in _ZERO:
+        _ZERO[key] = torch.zeros(256, dtype=torch.float16, device=device)
+    return _ZERO[key]
+
+
+def require_gpu(t: torch.Tensor):
+    if not t.is_cuda:
+        raise RuntimeError("fmri_hip: the HIP engine needs tensors on an MI355X device (no CPU fallback)")
+
+
+# ------------------------------------------------------------------------------------------------
+# packed weights
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class PackSpec:
+    """dst[(ta*A+a)][(tb*Bp+b)] = src[a*sa + ta*sta + b*sb + t(tb)*stb] (see csrc/layout.hip)."""
+    sa: int
+    sta: int
+    A: int
+    TA: int
+    sb: int
+    stb: int
+    B: int
+    KW: int = 1
+    py: int = 0
+    px: int = 0
+    step: int = 1
+    TH: int = 1
+    TW: int = 1
+
+    @property
+    def rows(self):
+        return self.TA * self.A
+
+    @property
+    def kcols(self):
+        return self.TH * self.TW * pad8(self.B)
+
+
+class PackedWeight:
+    """fp16 GEMM-layout copy of one fp32 master weight in one orientation (1 or 4 class blocks)."""
+
+    def __init__(self, master: torch.Tensor, group, specs: List[PackSpec], rows_pad: int, kpads: List[int],
+                 offsets: List[int]):
+        self.master, self.group = master, group
+        self.specs, self.rows_pad, self.kpads, self.offsets = specs, rows_pad, kpads, offsets
+        total = offsets[-1] + rows_pad * kpads[-1]
+        self.buf = torch.empty(total, dtype=torch.float16, device=master.device)
+        self.version = -1
+
+    def get(self) -> torch.Tensor:
+        if self.version != self.group.version:
+            for sp, kp, off in zip(self.specs, self.kpads, self.offsets):
+                lib.call("fmri_pack_weight", _P(self.master), self.buf.data_ptr() + 2 * off, sp.sa, sp.sta, sp.sb,
+                         sp.stb, sp.A, sp.TA, sp.B, sp.KW, sp.py, sp.px, sp.step, sp.TH, sp.TW, self.rows_pad, kp)
+            self.version = self.group.version
+        return self.buf
+
+
+def _single(master, group, sp: PackSpec, tile: int) -> PackedWeight:
+    rows_pad = ceil_to(sp.rows, tile)
+    return PackedWeight(master, group, [sp], rows_pad, [ceil_to(sp.kcols, 64)], [0])
+
+
+def _tconv(master, group, k, pad, sa, A, sb, B, tile) -> PackedWeight:
+    """4 parity-class blocks for a stride-2 transposed convolution producing A channels from B channels."""
+    rows_pad = ceil_to(A, tile)
+    specs, kpads, offs = [], [], []
+    for cy in range(2):
+        for cx in range(2):
+            g = lib.tconv_class(k, pad, cy, cx, pad8(B), rows_pad)
+            specs.append(PackSpec(sa=sa, sta=0, A=A, TA=1, sb=sb, stb=1, B=B, KW=k, py=g["py"], px=g["px"], step=2,
+                                  TH=g["th"], TW=g["tw"]))
+            kpads.append(g["kpad"])
+            offs.append(g["w_off"])
+    return PackedWeight(master, group, specs, rows_pad, kpads, offs)
+
+
+def _choose_splits(blocks: int, ksteps: int) -> int:
+    if blocks >= 192 or ksteps < 8:
+        return 1
+    s = min(ksteps // 4, (512 + blocks - 1) // blocks)
+    s = max(s, 1)
+    per = (ksteps + s - 1) // s
+    return (ksteps + per - 1) // per
+
+
+def run_igemm(x, pw: PackedWeight, out, bias, N, Hi, Wi, Ci, Ho, Wo, CoStore, Co, k, stride, pad, mode, act, out_f32,
+              splits, slab_stride, tile):
+    lib.call("fmri_igemm", _P(x), _P(pw.get()), _P(out), _P(bias), _P(zero_page(x.device)), N, Hi, Wi, Ci, Ho, Wo,
+             CoStore, Co, k, stride, pad, mode, act, 1 if out_f32 else 0, splits, slab_stride, tile)
+
+
+def run_wgrad(P, Q, N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad):
+    """Returns the packed fp32 gradient [apad][ldo]."""
+    ba = tile_for(A)
+    apad = ceil_to(A, ba)
+    ldo = ceil_to(k * k * Bc, 128)
+    tiles = (ldo // 128) * (apad // ba)
+    steps = (N * Yc * Xc + 63) // 64
+    splits = 1
+    if tiles < 512 and steps >= 16:
+        splits = min(steps // 8, (1024 + tiles - 1) // tiles)
+        splits = max(splits, 1)
+    if splits > 1:
+        out = torch.zeros(apad, ldo, dtype=torch.float32, device=P.device)
+    else:
+        out = torch.empty(apad, ldo, dtype=torch.float32, device=P.device)
+    lib.call("fmri_wgrad", _P(P), _P(Q), _P(out), _P(zero_page(P.device)), N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad,
+             apad, ba, ldo, splits, 1 if splits > 1 else 0)
+    return out, ldo
+
+
+def unpack_grad(packed, grad_view, sp: PackSpec, ld: int, scale: float):
+    lib.call("fmri_unpack_grad", _P(packed), _P(grad_view), sp.sa, sp.sta, sp.sb, sp.stb, sp.A, sp.TA, sp.B, sp.KW,
+             sp.py, sp.px, sp.step, sp.TH, sp.TW, ld, float(scale), 1)
+
+
+# ------------------------------------------------------------------------------------------------
+# convolution layers
+# ------------------------------------------------------------------------------------------------
+class ConvLayer:
+    """nn.Conv2d(k, stride, pad) (kind='conv', weight [Cout][Cin][k][k]) or
+    nn.ConvTranspose2d(k, 2, pad, output_padding) (kind='deconv', weight [Cin][Cout][k][k])."""
+
+    def __init__(self, group, wkey: str, bkey: Optional[str], kind: str, cin: int, cout: int, k: int, stride: int,
+                 pad: int, out_pad: int = 0):
+        self.group, self.kind = group, kind
+        self.w = group.views[wkey]
+        self.wg = group.grads[wkey]
+        self.b = group.views[bkey] if bkey else None
+        self.bg = group.grads[bkey] if bkey else None
+        self.cin, self.cout, self.k, self.stride, self.pad, self.out_pad = cin, cout, k, stride, pad, out_pad
+        self.cinp, self.coutp = pad8(cin), pad8(cout)
+        kk = k * k
+        self.t_out, self.t_in = tile_for(cout), tile_for(cin)
+        if kind == "conv":
+            # forward: rows co, reduce (tap, ci)
+            self.pw_f = _single(self.w, group, PackSpec(sa=cin * kk, sta=0, A=cout, TA=1, sb=kk, stb=1, B=cin, KW=k,
+                                                        TH=k, TW=k), self.t_out)
+            if stride == 2:
+                self.pw_d = _tconv(self.w, group, k, pad, sa=kk, A=cin, sb=cin * kk, B=cout, tile=self.t_in)
+            else:
+                self.pw_d = _single(self.w, group, PackSpec(sa=kk, sta=0, A=cin, TA=1, sb=cin * kk, stb=1, B=cout,
+                                                            KW=k, TH=k, TW=k), self.t_in)
+            self.gspec = PackSpec(sa=cin * kk, sta=0, A=cout, TA=1, sb=kk, stb=1, B=cin, KW=k, TH=k, TW=k)
+        else:
+            if stride != 2:
+                raise ValueError("deconv layers are stride 2")
+            self.pw_f = _tconv(self.w, group, k, pad, sa=kk, A=cout, sb=cout * kk, B=cin, tile=self.t_out)
+            self.pw_d = _single(self.w, group, PackSpec(sa=cout * kk, sta=0, A=cin, TA=1, sb=kk, stb=1, B=cout, KW=k,
+                                                        TH=k, TW=k), self.t_in)
+            self.gspec = PackSpec(sa=cout * kk, sta=0, A=cin, TA=1, sb=kk, stb=1, B=cout, KW=k, TH=k, TW=k)
+
+    def out_hw(self, hi: int, wi: int) -> Tuple[int, int]:
+        if self.kind == "conv":
+            f = lambda v: (v + 2 * self.pad - self.k) // self.stride + 1
+        else:
+            f = lambda v: (v - 1) * self.stride - 2 * self.pad + self.k + self.out_pad
+        return f(hi), f(wi)
+
+    def forward(self, x: torch.Tensor, act: int = ACT_NONE, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        N, Hi, Wi, C = x.shape
+        assert C == self.cinp and x.dtype == torch.float16 and x.is_contiguous()
+        Ho, Wo = self.out_hw(Hi, Wi)
+        if out is None:
+            out = torch.empty(N, Ho, Wo, self.coutp, dtype=torch.float16, device=x.device)
+        mode = MODE_CONV if self.kind == "conv" else MODE_TCONV2
+        run_igemm(x, self.pw_f, out, self.b, N, Hi, Wi, self.cinp, Ho, Wo, self.coutp, self.cout, self.k,
+                  self.stride, self.pad, mode, act, False, 1, 0, self.t_out)
+        return out
+
+    def dgrad(self, dy: torch.Tensor, hi: int, wi: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Cotangent w.r.t. the layer input (same scale as dy)."""
+        N, Ho, Wo, C = dy.shape
+        assert C == self.coutp and dy.is_contiguous()
+        if out is None:
+            out = torch.empty(N, hi, wi, self.cinp, dtype=torch.float16, device=dy.device)
+        if self.kind == "conv":
+            mode = MODE_TCONV2 if self.stride == 2 else MODE_CONV_FLIP
+            run_igemm(dy, self.pw_d, out, None, N, Ho, Wo, self.coutp, hi, wi, self.cinp, self.cin, self.k,
+                      self.stride, self.pad, mode, ACT_NONE, False, 1, 0, self.t_in)
+        else:
+            run_igemm(dy, self.pw_d, out, None, N, Ho, Wo, self.coutp, hi, wi, self.cinp, self.cin, self.k, 2,
+                      self.pad, MODE_CONV, ACT_NONE, False, 1, 0, self.t_in)
+        return out
+
+    def wgrad(self, x: torch.Tensor, dy: torch.Tensor, scale: float):
+        """weight.grad += (1/scale) * dW(x, dy)."""
+        N, Hi, Wi, _ = x.shape
+        _, Ho, Wo, _ = dy.shape
+        if self.kind == "conv":
+            packed, ldo = run_wgrad(dy, x, N, Ho, Wo, self.coutp, Hi, Wi, self.cinp, self.k, self.stride, self.pad)
+        else:
+            packed, ldo = run_wgrad(x, dy, N, Hi, Wi, self.cinp, Ho, Wo, self.coutp, self.k, 2, self.pad)
+        unpack_grad(packed, self.wg, self.gspec, ldo, 1.0 / scale)
+
+
+# ------------------------------------------------------------------------------------------------
+# dense layers
+# ------------------------------------------------------------------------------------------------
+class DenseLayer:
+    """nn.Linear(K -> Nout), weight [Nout][K].
+
+    in_perm=(C, HW):  the K inputs are a flattened conv map stored (H,W,C) in the engine but (C,H,W) in the
+                      reference weight (models/vae_gan.py:89,181).
+    out_perm=(C, HW): the Nout outputs are reshaped to a conv map (models/vae_gan.py:127); the engine emits
+                      them in (H,W,C) order.
+    """
+
+    def __init__(self, group, wkey, bkey, k_in: int, n_out: int, in_perm=None, out_perm=None):
+        self.group = group
+        if isinstance(wkey, str):
+            self.w, self.wg = group.views[wkey], group.grads[wkey]
+            self.b = group.views[bkey] if bkey else None
+            self.bg = group.grads[bkey] if bkey else None
+        else:                       # explicit (weight, grad) / (bias, grad) tensor pairs (fused heads)
+            self.w, self.wg = wkey
+            self.b, self.bg = bkey if bkey else (None, None)
+        self.k_in, self.n_out = k_in, n_out
+        self.kp, self.np_ = pad8(k_in), pad8(n_out)
+        self.t_out, self.t_in = tile_for(n_out), tile_for(k_in)
+        K, Nn = k_in, n_out
+        if in_perm:
+            C, HW = in_perm
+            assert C * HW == K and C % 8 == 0
+            f = PackSpec(sa=K, sta=0, A=Nn, TA=1, sb=HW, stb=1, B=C, KW=HW, TH=1, TW=HW)
+            d = PackSpec(sa=HW, sta=1, A=C, TA=HW, sb=K, stb=0, B=Nn)
+            g = f
+        elif out_perm:
+            C, HW = out_perm
+            assert C * HW == Nn and C % 8 == 0
+            f = PackSpec(sa=HW * K, sta=K, A=C, TA=HW, sb=1, stb=0, B=K)
+            d = PackSpec(sa=1, sta=0, A=K, TA=1, sb=HW * K, stb=K, B=C, KW=HW, TH=1, TW=HW)
+            g = f
+        else:
+            f = PackSpec(sa=K, sta=0, A=Nn, TA=1, sb=1, stb=0, B=K)
+            d = PackSpec(sa=1, sta=0, A=K, TA=1, sb=K, stb=0, B=Nn)
+            g = f
+        self.pw_f = _single(self.w, group, f, self.t_out)
+        self.pw_d = _single(self.w, group, d, self.t_in)
+        self.gspec = g
+
+    def _gemm(self, x, pw, M, Ci, Co, CoStore, tile, bias, act, want16, want32):
+        ksteps = ceil_to(Ci, 64) // 64
+        blocks = ((M + 127) // 128) * (ceil_to(Co, tile) // tile)
+        splits = _choose_splits(blocks, ksteps)
+        dev = x.device
+        if splits == 1 and not want32:
+            out = torch.empty(M, CoStore, dtype=torch.float16, device=dev)
+            run_igemm(x, pw, out, bias, M, 1, 1, Ci, 1, 1, CoStore, Co, 1, 1, 0, MODE_CONV, act, False, 1, 0, tile)
+            return out, None
+        slabs = torch.empty(splits, M, CoStore, dtype=torch.float32, device=dev)
+        run_igemm(x, pw, slabs, None, M, 1, 1, Ci, 1, 1, CoStore, Co, 1, 1, 0, MODE_CONV, ACT_NONE, True, splits,
+                  M * CoStore, tile)
+        o16 = torch.empty(M, CoStore, dtype=torch.float16, device=dev) if want16 else None
+        o32 = torch.empty(M, Co, dtype=torch.float32, device=dev) if want32 else None
+        lib.call("fmri_reduce_slabs", _P(slabs), splits, M * CoStore, M, Co, CoStore, _P(bias), act, _P(o32), Co,
+                 _P(o16), CoStore)
+        return o16, o32
+
+    def forward(self, x: torch.Tensor, act: int = ACT_NONE, want16: bool = True, want32: bool = False):
+        """x [M, Kp] fp16 -> (out16 [M, Np] or None, out32 [M, Nout] or None); bias (if any) and act fused."""
+        M, Kp = x.shape
+        assert Kp == self.kp and x.is_contiguous()
+        return self._gemm(x, self.pw_f, M, self.kp, self.n_out, self.np_, self.t_out, self.b, act, want16, want32)
+
+    def dgrad(self, dy: torch.Tensor, want32: bool = False):
+        """dy [M, Np] -> dx [M, Kp] (fp16, same scale) and/or fp32 [M, K]."""
+        M, Np = dy.shape
+        assert Np == self.np_ and dy.is_contiguous()
+        return self._gemm(dy, self.pw_d, M, self.np_, self.k_in, self.kp, self.t_in, None, ACT_NONE, not want32,
+                          want32)
+
+    def wgrad(self, x: torch.Tensor, dy: torch.Tensor, scale: float):
+        M = x.shape[0]
+        packed, ldo = run_wgrad(dy, x, M, 1, 1, self.np_, 1, 1, self.kp, 1, 1, 0)
+        unpack_grad(packed, self.wg, self.gspec, ldo, 1.0 / scale)
+
+    def bias_grad(self, dy: torch.Tensor, scale: float):
+        if self.bg is not None:
+            self.bg.add_(dy[:, :self.n_out].float().sum(0), alpha=1.0 / scale)
+
+
+# ------------------------------------------------------------------------------------------------
+# batch norm
+# ------------------------------------------------------------------------------------------------
+class BNSaved:
+    __slots__ = ("mean", "rstd", "scale", "shift", "count")
+
+
+class BatchNorm:
+    """Train-mode BatchNorm2d/1d(momentum=0.9) (+ReLU) over fp16 rows [M, C].
+
+    ``perm=(C0, HW)``: the C = C0*HW features are stored in engine order (HW, C0) while the reference
+    parameter / running-stat vectors are in (C0, HW) order (decoder.fc.1, models/vae_gan.py:108,127).
+    ``reducer``: optional callable all-reducing a fp32 tensor in place and returning the world size
+    (SyncBN for data-parallel runs).
+    """
+
+    def __init__(self, group, prefix: str, C: int, perm=None):
+        self.group, self.prefix, self.C, self.perm = group, prefix, C, perm
+        self.gamma, self.beta = group.views[prefix + "weight"], group.views[prefix + "bias"]
+        self.ggamma, self.gbeta = group.grads[prefix + "weight"], group.grads[prefix + "bias"]
+        self.rm, self.rv = group.bufs[prefix + "running_mean"], group.bufs[prefix + "running_var"]
+        self.nbt = group.bufs[prefix + "num_batches_tracked"]
+        self.reducer = None
+        self._v = -1
+        if perm:
+            dev = self.gamma.device
+            self.gamma_e = torch.empty(C, dtype=torch.float32, device=dev)
+            self.beta_e = torch.empty(C, dtype=torch.float32, device=dev)
+            self.rm_e = torch.empty(C, dtype=torch.float32, device=dev)
+            self.rv_e = torch.empty(C, dtype=torch.float32, device=dev)
+
+    def _params(self):
+        if not self.perm:
+            return self.gamma, self.beta, self.rm, self.rv
+        if self._v != self.group.version:
+            c0, hw = self.perm
+            for s, d in ((self.gamma, self.gamma_e), (self.beta, self.beta_e)):
+                lib.call("fmri_permute_chw", _P(s), _P(d), c0, hw, 1, 1.0, 0)
+            self._v = self.group.version
+        return self.gamma_e, self.beta_e, self.rm_e, self.rv_e
+
+    def _running_in(self):
+        if self.perm:
+            c0, hw = self.perm
+            lib.call("fmri_permute_chw", _P(self.rm), _P(self.rm_e), c0, hw, 1, 1.0, 0)
+            lib.call("fmri_permute_chw", _P(self.rv), _P(self.rv_e), c0, hw, 1, 1.0, 0)
+
+    def _running_out(self):
+        if self.perm:
+            c0, hw = self.perm
+            lib.call("fmri_permute_chw", _P(self.rm_e), _P(self.rm), c0, hw, 0, 1.0, 0)
+            lib.call("fmri_permute_chw", _P(self.rv_e), _P(self.rv), c0, hw, 0, 1.0, 0)
+
+    def forward(self, raw: torch.Tensor, relu: bool = True, updates: int = 1, out: Optional[torch.Tensor] = None):
+        C = self.C
+        x2 = raw.reshape(-1, C)
+        M = x2.shape[0]
+        dev = raw.device
+        gamma, beta, rm, rv = self._params()
+        sums = torch.zeros(2, C, dtype=torch.float32, device=dev)
+        lib.call("fmri_bn_stats", _P(x2), M, C, _P(sums))
+        count = float(M)
+        if self.reducer is not None:
+            count *= self.reducer(sums)
+        sv = BNSaved()
+        buf = torch.empty(4, C, dtype=torch.float32, device=dev)
+        sv.mean, sv.rstd, sv.scale, sv.shift, sv.count = buf[0], buf[1], buf[2], buf[3], count
+        if updates > 0:
+            self._running_in()
+        lib.call("fmri_bn_finalize", _P(sums), C, count, _P(gamma), _P(beta), 1e-5, 0.9, updates,
+                 _P(rm) if updates > 0 else None, _P(rv) if updates > 0 else None, _P(sv.mean), _P(sv.rstd),
+                 _P(sv.scale), _P(sv.shift))
+        if updates > 0:
+            self._running_out()
+            self.nbt += updates
+        if out is None:
+            out = torch.empty_like(raw)
+        lib.call("fmri_bn_apply", _P(x2), _P(out), M, C, _P(sv.scale), _P(sv.shift), 1 if relu else 0)
+        return out, sv
+
+    def backward(self, raw: torch.Tensor, dy: torch.Tensor, sv: BNSaved, relu: bool = True,
+                 param_scale: Optional[float] = None, out: Optional[torch.Tensor] = None):
+        """dx through (ReLU o BN) with batch statistics; if ``param_scale`` is given, gamma/beta grads are
+        accumulated as (1/param_scale) * sums."""
+        C = self.C
+        x2 = raw.reshape(-1, C)
+        g2 = dy.reshape(-1, C)
+        M = x2.shape[0]
+        gamma, beta, _, _ = self._params()
+        sums = torch.zeros(2, C, dtype=torch.float32, device=raw.device)
+        lib.call("fmri_bn_bwd_reduce", _P(x2), _P(g2), M, C, _P(sv.mean), _P(sv.rstd), _P(gamma), _P(beta),
+                 1 if relu else 0, _P(sums))
+        if param_scale is not None:       # local sums: the gradient all-reduce (SUM) adds the other ranks
+            self.accumulate_param_grads(sums, param_scale)
+        if self.reducer is not None:
+            self.reducer(sums)
+        if out is None:
+            out = torch.empty_like(dy)
+        lib.call("fmri_bn_bwd_apply", _P(x2), _P(g2), _P(out), M, C, sv.count, _P(sv.mean), _P(sv.rstd), _P(gamma),
+                 _P(beta), 1 if relu else 0, _P(sums))
+        return out, sums
+
+    def accumulate_param_grads(self, sums: torch.Tensor, scale: float):
+        inv = 1.0 / scale
+        if self.perm:
+            c0, hw = self.perm
+            lib.call("fmri_permute_chw", _P(sums[1]), _P(self.ggamma), c0, hw, 0, inv, 1)
+            lib.call("fmri_permute_chw", _P(sums[0]), _P(self.gbeta), c0, hw, 0, inv, 1)
+        else:
+            self.ggamma.add_(sums[1], alpha=inv)
+            self.gbeta.add_(sums[0], alpha=inv)
+
+
+# ------------------------------------------------------------------------------------------------
+# misc helpers
+# ------------------------------------------------------------------------------------------------
+def images_to_nhwc(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """NCHW fp32 -> NHWC fp16 (channels padded to 8)."""
+    require_gpu(x)
+    N, C, H, W = x.shape
+    x = x.contiguous().float()
+    cp = pad8(C)
+    if out is None:
+        out = torch.empty(N, H, W, cp, dtype=torch.float16, device=x.device)
+    lib.call("fmri_nchw_to_nhwc", _P(x), _P(out), N, C, H * W, cp)
+    return out
+
+
+def nhwc_to_images(x16: torch.Tensor, C: int, scale: float = 1.0) -> torch.Tensor:
+    N, H, W, cp = x16.shape
+    out = torch.empty(N, C, H, W, dtype=torch.float32, device=x16.device)
+    lib.call("fmri_nhwc_to_nchw", _P(x16), _P(out), N, C, H * W, cp, float(scale))
+    return out
+
+
+def rows_to_f16(x: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+    require_gpu(x)
+    M, Cc = x.shape
+    x = x.contiguous().float()
+    out = torch.empty(M, pad8(Cc), dtype=torch.float16, device=x.device)
+    lib.call("fmri_rows_f32_to_f16", _P(x), _P(out), M, Cc, pad8(Cc), float(scale))
+    return out
+
+
+def act_backward(y: torch.Tensor, dy: torch.Tensor, act: int, colsum: Optional[torch.Tensor] = None,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    C = y.shape[-1]
+    M = y.numel() // C
+    if out is None:
+        out = torch.empty_like(dy)
+    lib.call("fmri_act_bwd", _P(y), _P(dy), _P(out), M, C, act, _P(colsum))
+    return out
+
+
+def axpby(x: torch.Tensor, y: Optional[torch.Tensor], a: float, b: float, out: Optional[torch.Tensor] = None):
+    if out is None:
+        out = torch.empty_like(x)
+    lib.call("fmri_axpby_f16", _P(x), _P(y), _P(out), x.numel(), float(a), float(b))
+    return out

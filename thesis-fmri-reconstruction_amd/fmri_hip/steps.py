@@ -1,0 +1,243 @@
+"""Fused training steps: our restatement of the inline loop bodies of the reference scripts.
+
+    Stage1Step   train/train_vgan_stage1.py:316-432   (mode 'vae-gan')
+    Stage2Step   train/train_vgan_stage2.py:321-407
+    Stage3Step   train/train_vgan_stage3.py:324-411
+    WaeStage1Step train/train_wae_stage1.py:259-311
+
+Contract: one forward -> the three gradient sets, each of its own loss w.r.t. its own
+sub-network, all evaluated at the pre-update weights -> gated optimizer steps.  The discriminator is run
+once (REC+GAN fused, BN running stats updated twice like the reference); its backward carries two
+cotangent streams (A = d L_dis, B = d sum(mse)) so that decoder gets lambda*B-(1-lambda)*A and the
+encoder gets B (+KL) from a single saved forward.  Nothing in a step synchronises with the host: the
+equilibrium gate is evaluated on the device and gates the fused optimizer kernels through a flag.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import lib
+from .nets import CognitiveEncoderNet, DecoderNet, DiscriminatorNet, EncoderNet, WaeDiscriminatorNet
+from .ops import axpby, images_to_nhwc, nhwc_to_images, pad8, require_gpu, rows_to_f16
+from .params import ArchConfig
+
+_P = lib.ptr
+
+# slots of the fp32 scalar block written by the loss kernels (see csrc/loss.hip compose_gate_kernel)
+S_BCE_O, S_BCE_P, S_BCE_S, S_KL, S_MSE, S_NLE, S_LENC, S_LDIS, S_LDEC = range(9)
+LOG_KEYS = ("bce_orig", "bce_pred", "bce_samp", "kl", "mse", "nle", "loss_encoder", "loss_discriminator",
+            "loss_decoder")
+
+
+@dataclass
+class GanHyper:
+    """configs/gan_config.py:19-31."""
+    lr: float = 1e-4
+    lambda_mse: float = 1e-6
+    margin: float = 0.35
+    equilibrium: float = 0.68
+    alpha: float = 0.9
+    eps: float = 1e-8
+
+
+@dataclass
+class Scales:
+    """Static power-of-two scales that keep fp16 cotangents in range (stored = true * scale)."""
+    a: float = 1024.0      # d L_dis stream through the discriminator
+    b: float = 64.0        # d sum(mse) stream through discriminator / decoder
+    dec: float = 4096.0    # lambda*B - (1-lambda)*A through the decoder
+    enc: float = 64.0      # encoder backward
+
+
+class _Optim:
+    """Fused RMSprop / Adam over a FlatGroup, optionally gated by a device flag."""
+
+    def __init__(self, group, kind="rmsprop", lr=1e-4, alpha=0.9, eps=1e-8, betas=(0.5, 0.999)):
+        self.g, self.kind, self.lr, self.alpha, self.eps, self.betas = group, kind, lr, alpha, eps, betas
+        self.s1 = torch.zeros_like(group.data)
+        self.s2 = torch.zeros_like(group.data) if kind == "adam" else None
+        self.t = 0
+
+    def step(self, flag: Optional[torch.Tensor] = None, clamp: float = 0.0):
+        g = self.g
+        if self.kind == "rmsprop":
+            lib.call("fmri_rmsprop", _P(g.data), _P(g.grad), _P(self.s1), g.numel, self.lr, self.alpha, self.eps, 1.0,
+                     clamp, _P(flag))
+        else:
+            self.t += 1
+            b1, b2 = self.betas
+            lib.call("fmri_adam", _P(g.data), _P(g.grad), _P(self.s1), _P(self.s2), g.numel, self.lr, b1, b2,
+                     self.eps, 1.0 - b1 ** self.t, float(np.sqrt(1.0 - b2 ** self.t)), 1.0, clamp, _P(flag))
+        g.version += 1
+
+
+class _Dist:
+    """Data-parallel glue (one process per GPU, RCCL): SUM all-reduce of flat gradients / loss scalars and
+    the SyncBN statistic exchange.  Inactive (world size 1) unless torch.distributed is initialised."""
+
+    def __init__(self, enabled: bool, sync_bn: bool = True):
+        import torch.distributed as dist
+        self.dist = dist
+        self.on = enabled and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.world = dist.get_world_size() if self.on else 1
+        self.sync_bn = sync_bn
+
+    def all_reduce(self, t: torch.Tensor):
+        if self.on:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+
+    def bn_reducer(self):
+        if not (self.on and self.sync_bn):
+            return None
+
+        def red(sums):
+            self.dist.all_reduce(sums, op=self.dist.ReduceOp.SUM)
+            return self.world
+        return red
+
+
+def _attach_reducers(nets, d: _Dist):
+    r = d.bn_reducer()
+    for n in nets:
+        for bn in n.all_bns():
+            bn.reducer = r
+
+
+class Stage1Step:
+    """Stage-I VAE/GAN step (image -> image)."""
+
+    def __init__(self, cfg: ArchConfig, device, hp: GanHyper = GanHyper(), scales: Scales = Scales(),
+                 distributed: bool = False, sync_bn: bool = True):
+        self.cfg, self.hp, self.sc = cfg, hp, scales
+        self.device = torch.device(device)
+        self.enc = EncoderNet(cfg, device)
+        self.dec = DecoderNet(cfg, device, self.enc.size)
+        self.dis = DiscriminatorNet(cfg, device)
+        self.opt_enc = _Optim(self.enc.group, "rmsprop", hp.lr, hp.alpha, hp.eps)
+        self.opt_dec = _Optim(self.dec.group, "rmsprop", hp.lr, hp.alpha, hp.eps)
+        self.opt_dis = _Optim(self.dis.group, "rmsprop", hp.lr, hp.alpha, hp.eps)
+        self.scal = torch.zeros(16, dtype=torch.float32, device=device)
+        self.flags = torch.zeros(2, dtype=torch.int32, device=device)
+        self.dd = _Dist(distributed, sync_bn)
+        _attach_reducers((self.enc, self.dec, self.dis), self.dd)
+        self.last: Dict[str, torch.Tensor] = {}
+
+    # ---- parameters -----------------------------------------------------------------------------
+    def load_recipe(self, seed: int, perturb: bool = False):
+        rs = np.random.RandomState(seed)
+        for n in (self.enc, self.dec, self.dis):
+            n.group.load_recipe(rs, perturb)
+
+    def state_dict(self):
+        sd = {}
+        sd.update(self.enc.group.state_dict("encoder."))
+        sd.update(self.dec.group.state_dict("decoder."))
+        sd.update(self.dis.group.state_dict("discriminator."))
+        return sd
+
+    def load_state_dict(self, sd):
+        self.enc.group.load_state_dict(sd, "encoder.")
+        self.dec.group.load_state_dict(sd, "decoder.")
+        self.dis.group.load_state_dict(sd, "discriminator.")
+
+    # ---- the step ---------------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor, eps: torch.Tensor, z_p: torch.Tensor):
+        require_gpu(x)
+        cfg, sc = self.cfg, self.sc
+        B, _, H, W = x.shape
+        Z, zp = cfg.latent_dim, pad8(cfg.latent_dim)
+        dev = x.device
+        self.scal.zero_()
+        disc_in = torch.empty(3 * B, H, W, 8, dtype=torch.float16, device=dev)
+        images_to_nhwc(x, out=disc_in[:B])
+        head32, ectx = self.enc.forward(disc_in[:B])
+        z16 = torch.empty(2 * B, zp, dtype=torch.float16, device=dev)
+        eps = eps.contiguous().float()
+        lib.call("fmri_latent_fwd", _P(head32), _P(eps), B, Z, zp, _P(z16), None, _P(self.scal[S_KL:]), 1)
+        lib.call("fmri_rows_f32_to_f16", _P(z_p.contiguous().float()), _P(z16[B:]), B, Z, zp, 1.0)
+        _, dctx = self.dec.forward(z16, 2, out=disc_in[B:])
+        feat, logit32, sctx = self.dis.forward(disc_in)
+        F = feat[0].numel()
+        prob = torch.empty(3 * B, dtype=torch.float32, device=dev)
+        dlogit16 = torch.empty(3 * B, 8, dtype=torch.float16, device=dev)
+        lib.call("fmri_gan_head", _P(logit32), 1, B, _P(prob), _P(self.scal), _P(dlogit16), 8, sc.a)
+        dfeat16 = torch.empty_like(feat)
+        lib.call("fmri_feat_mse", _P(feat), B, F, None, _P(self.scal[S_MSE:]), _P(dfeat16), sc.b)
+        lib.call("fmri_pixel_sq", _P(disc_in[:B]), _P(disc_in[B:2 * B]), B * H * W, 3, 8, _P(self.scal[S_NLE:]), None,
+                 1.0)
+        self.dd.all_reduce(self.scal)
+        self.fw = dict(B=B, H=H, W=W, disc_in=disc_in, head32=head32, eps=eps, ectx=ectx, dctx=dctx, sctx=sctx,
+                       feat=feat, prob=prob, dlogit16=dlogit16, dfeat16=dfeat16)
+        return self.fw
+
+    def gate(self, B_global: int):
+        hp = self.hp
+        lib.call("fmri_compose_gate", _P(self.scal), _P(self.flags), float(B_global), hp.lambda_mse, hp.equilibrium,
+                 hp.margin, 1, -1, -1)
+
+    def backward(self):
+        fw, sc, hp, cfg = self.fw, self.sc, self.hp, self.cfg
+        B, H, W = fw["B"], fw["H"], fw["W"]
+        Z = cfg.latent_dim
+        dev = fw["disc_in"].device
+        for n in (self.enc, self.dec, self.dis):
+            n.group.zero_grad()
+        dimg_a, dimg_b = self.dis.backward(fw["sctx"], fw["dlogit16"], sc.a, fw["dfeat16"], sc.b, True,
+                                           slice(B, 3 * B))
+        cot = torch.empty(3 * B, H, W, 8, dtype=torch.float16, device=dev)
+        lam = hp.lambda_mse
+        axpby(dimg_b, dimg_a, sc.dec * lam / sc.b, -sc.dec * (1.0 - lam) / sc.a, out=cot[:2 * B])
+        cot[2 * B:].copy_(dimg_b[:B])
+        entries = [dict(g=0, scale=sc.dec, train=True), dict(g=1, scale=sc.dec, train=True),
+                   dict(g=0, scale=sc.b, train=False, need_dz=True)]
+        dz = self.dec.backward(fw["dctx"], cot, entries)[2]
+        dhead16 = torch.empty(B, 2 * Z, dtype=torch.float16, device=dev)
+        lib.call("fmri_latent_bwd", _P(fw["head32"]), _P(fw["eps"]), _P(dz), Z, 1.0, 1.0, B, Z, sc.enc, _P(dhead16),
+                 None, 1)
+        self.enc.backward(fw["ectx"], dhead16, sc.enc)
+        for n in (self.dis, self.dec, self.enc):
+            self.dd.all_reduce(n.group.grad)
+
+    def apply(self):
+        self.opt_enc.step(None)
+        self.opt_dec.step(self.flags[1:2])
+        self.opt_dis.step(self.flags[0:1])
+
+    def step(self, x, eps, z_p):
+        """One full training step; returns the device scalar block (see LOG_KEYS) without syncing."""
+        fw = self.forward(x, eps, z_p)
+        self.gate(fw["B"] * self.dd.world)
+        self.backward()
+        self.apply()
+        return self.scal
+
+    # ---- reference-shaped views of the last forward (API / parity tests) -----------------------------
+    def outputs(self):
+        fw, cfg = self.fw, self.cfg
+        B, Z = fw["B"], cfg.latent_dim
+        d = fw["disc_in"]
+        feat = fw["feat"]
+        n3, h, w, c = feat.shape
+        return dict(
+            x_tilde=nhwc_to_images(d[B:2 * B], 3), x_p=nhwc_to_images(d[2 * B:], 3),
+            disc_class=fw["prob"].reshape(3 * B, 1).clone(),
+            disc_layer=nhwc_to_images(feat, c).reshape(n3, -1),
+            mus=fw["head32"][:, :Z].clone(), log_variances=fw["head32"][:, Z:].clone())
+
+    def logs(self):
+        v = self.scal.tolist()
+        out = {k: v[i] for i, k in enumerate(LOG_KEYS)}
+        f = self.flags.tolist()
+        out["train_dis"], out["train_dec"] = bool(f[0]), bool(f[1])
+        return out
+
+    def named_grads(self):
+        out = {}
+        for pre, n in (("encoder.", self.enc), ("decoder.", self.dec), ("discriminator.", self.dis)):
+            for k, v in n.group.grads.items():
+                out[pre + k] = v
+        return out

@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Stage-I VAE/GAN training step, 64x64x3 stimuli, latent 128, batch 256 per GPU
+(BASELINE.json configs[1]), images/sec, on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = one full pass of the hot path over one synthetic batch already resident in HBM:
+forward (encoder, 2x decoder, fused REC+GAN discriminator), losses, two-stream backward giving the three
+gradient sets, SUM all-reduce over RCCL (N > 1), gated RMSprop updates, fp16 weight re-pack.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "thesis-fmri-reconstruction_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+FLOP_PER_IMAGE = 13.81e9          # SURVEY 8(d) / BASELINE.md 3: algorithmic Stage-I step FLOPs per image
+MFMA_PEAK_TFLOPS = 2500.0         # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md
+
+
+def host_cores() -> int:
+    """CPU threads this process may really use: affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(p) + 0.5)))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("FMRI_CPU_THREADS", "64"))))
+
+
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(batch: int, steps: int):
+    """Oracle (CPU restatement pinned to the reference) timed on this host's cores: the 'literal' variant
+    (three full backward traversals, what train_vgan_stage1.py:410-432 does)."""
+    from oracle import vaegan_oracle as O
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    cfg = O.ArchCfg.px64()
+    P = O.fill_state(O.vaegan_spec(cfg), 0, False)
+    data = O.synth_batch(batch, cfg, seed=1234, steps=1)
+    opts = {n: O.OptState(kind="rmsprop", lr=1e-4) for n in ("encoder", "decoder", "discriminator")}
+    args = (data["x"], data["noise"][0, 0], data["noise"][0, 1], cfg)
+    log(f"cpu baseline: {cores} threads, batch {batch}")
+    t0 = time.perf_counter()
+    O.stage1_step(P, opts, *args, literal=True)            # warm-up
+    warm = time.perf_counter() - t0
+    log(f"cpu baseline warm-up step {warm:.1f}s")
+    steps = max(1, min(steps, int(25.0 / max(warm, 1e-3))))   # bound the sample to ~25 s of CPU work
+    t0 = time.perf_counter()
+    for i in range(steps):
+        O.stage1_step(P, opts, *args, literal=True)
+        log(f"cpu baseline step {i + 1}/{steps}")
+    dt = time.perf_counter() - t0
+    return dict(value=round(batch * steps / dt, 3), unit="images/sec", cores=cores, kind="port",
+                sample=f"{steps} literal Stage-I steps (3 full backward traversals) of the CPU oracle at batch {batch} "
+                       f"(BASELINE configs[0]) after 1 warm-up, torch {torch.__version__} fp32, {cores} threads")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU (weak scaling)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--local-bn", action="store_true", help="per-rank BN statistics (no SyncBN exchange)")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from fmri_hip import lib, ops
+    from fmri_hip.params import ArchConfig
+    from fmri_hip.steps import Stage1Step
+    lib.load()
+
+    cfg = ArchConfig.px64()
+    B = a.batch
+    st = Stage1Step(cfg, dev, distributed=world > 1, sync_bn=not a.local_bn)
+    st.load_recipe(0, False)
+    x = torch.from_numpy(np.random.RandomState(1234 + rank).uniform(-1, 1, (B, 3, 64, 64)).astype(np.float32)).to(dev)
+    nz = torch.from_numpy(np.random.RandomState(1236 + rank).standard_normal((2, B, cfg.latent_dim))
+                          .astype(np.float32)).to(dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    log(f"rank {rank}/{world}: model built, batch {B}; host cores {host_cores()} (cpu_count {os.cpu_count()})")
+    for i in range(a.warmup):
+        st.step(x, nz[0], nz[1])
+        if i == 0:
+            torch.cuda.synchronize()
+            log("first step done")
+    barrier()
+    log("warm-up done")
+    ops.PROFILE = [] if rank == 0 else None
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        st.step(x, nz[0], nz[1])
+    barrier()
+    dt = time.perf_counter() - t0
+    log(f"timed region done: {1e3 * dt / a.steps:.2f} ms/step")
+    prof, ops.PROFILE = ops.PROFILE, None
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    logs = st.logs()
+
+    if rank == 0:
+        value = world * B * a.steps / dt
+        # dominant kernel = igemm_kernel<128,2,2,false> (all conv/deconv fwd+dgrad with >=128 output channels)
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in prof)
+        fl = sum(f for _, _, f in prof)
+        nl = max(len(prof), 1)
+        achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        out = {
+            "metric": "images/sec Stage-I VAE/GAN 64x64 bs256", "value": round(value, 1), "unit": "images/sec",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "Stage-I VAE/GAN training step, 64x64x3 random images, latent 128, "
+                                   "RMSprop x3, random-init weights (BASELINE configs[1])",
+                       "batch_per_gpu": B, "global_batch": B * world,
+                       "parallelism": f"dp{world}" + ("" if world == 1 else ("-localbn" if a.local_bn else "-syncbn"))},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "kernel": "fmri::igemm_kernel<128,2,2,false>",
+                         "launches_per_step": nl // max(a.steps, 1),
+                         "avg_launch_ms": round(ms / nl, 4),
+                         "avg_launch_gflop": round(fl / nl / 1e9, 2)},
+            "step_mfma_frac": round(value / world * FLOP_PER_IMAGE / 1e12 / MFMA_PEAK_TFLOPS, 4),
+            "losses_last_step": {k: logs[k] for k in ("loss_encoder", "loss_decoder", "loss_discriminator", "kl")},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(32, 3)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -80,41 +80,64 @@ int fmri_permute_chw(const float* src, float* dst, int C, int HW, int to_engine,
                      void* stream);
 
 /* ---- batch norm (train mode, momentum 0.9; models/vae_gan.py:21,54,81,108,158) -------------------- */
-int fmri_bn_stats(const void* x, int M, int C, float* sums2C, void* stream);
+/* reductions write per-block partials to a caller workspace of fmri_bn_ws_floats(M, C) floats (any smaller
+ * size >= 2*C also works, with fewer blocks) and fold them into sums2C = [sum a | sum b], 2*C floats. */
+int64_t fmri_bn_ws_floats(int M, int C);
+int fmri_bn_stats(const void* x, int M, int C, float* sums2C, float* ws, int64_t ws_floats, void* stream);
 int fmri_bn_finalize(const float* sums2C, int C, float count, const float* gamma, const float* beta, float eps,
                      float momentum, int updates, float* running_mean, float* running_var, float* mean, float* rstd,
                      float* scale, float* shift, void* stream);
 int fmri_bn_apply(const void* x, void* y, int M, int C, const float* scale, const float* shift, int relu,
                   void* stream);
 int fmri_bn_bwd_reduce(const void* x, const void* dy, int M, int C, const float* mean, const float* rstd,
-                       const float* gamma, const float* beta, int relu, float* sums2C, void* stream);
+                       const float* gamma, const float* beta, int relu, float* sums2C, float* ws,
+                       int64_t ws_floats, void* stream);
 int fmri_bn_bwd_apply(const void* x, const void* dy, void* dx, int M, int C, float count, const float* mean,
                       const float* rstd, const float* gamma, const float* beta, int relu, const float* sums2C,
                       void* stream);
-int fmri_act_bwd(const void* y, const void* dy, void* dpre, int M, int C, int act, float* colsum, void* stream);
+/* dpre = dy * act'(y) (ReLU / tanh); if colsum2C != NULL its first C floats receive the column sums of dpre */
+int fmri_act_bwd(const void* y, const void* dy, void* dpre, int M, int C, int act, float* colsum2C, float* ws,
+                 int64_t ws_floats, void* stream);
 
 /* ---- latent / losses (models/vae_gan.py:266-269, :302-320; train_vgan_stage1.py:368-404) ----------- */
 int fmri_latent_fwd(const float* head, const float* eps, int B, int Z, int zp, void* z16, float* kl_rows,
                     float* kl_total, int sample, void* stream);
 int fmri_latent_bwd(const float* head, const float* eps, const float* dz, int ldz, float dz_unscale, float kl_w,
-                    int B, int Z, float out_scale, void* dhead16, float* dhead32, int sample, void* stream);
-int fmri_feat_mse(const void* feat, int B, int F, float* mse_rows, float* mse_total, void* dfeat, float gscale,
-                  void* stream);
+                    const float* kl_dev, int B, int Z, float out_scale, void* dhead16, float* dhead32, int sample,
+                    void* stream);
+int fmri_feat_mse(const void* feat, int B, int F, float* mse_rows, float* mse_total, void* stream);
 int fmri_pixel_sq(const void* x, const void* xt, int64_t npix, int C, int Cp, float* total, void* dxt, float gscale,
                   void* stream);
-int fmri_gan_head(const float* logit, int ldl, int B, float* prob, float* scal3, void* dlogit, int ldg, float gscale,
-                  void* stream);
+/* scal: float block, slots [0..2] += bce sums (orig, pred, sampled), [9] += sum (d bce / d logit)^2 */
+int fmri_gan_head(const float* logit, int ldl, int B, float* prob, float* scal, void* stream);
 int fmri_wae_logloss(const float* logit, int ldl, int n, int one_minus, float w, float* total, float* prob,
                      void* dlogit, int ldg, float gscale, void* stream);
-int fmri_compose_gate(float* scal, int* flags, float batch, float lambda_mse, float equilibrium, float margin,
-                      int gate_on, int force_dis, int force_dec, void* stream);
-int fmri_axpby_f16(const void* x, const void* y, void* out, int64_t n, float a, float b, void* stream);
+/* scal slots: in [0..5] bce_o,bce_p,bce_s,kl,mse,nle and [9] dl2; out [6..8] loss_encoder/discriminator/decoder,
+ * [10] nA = 1/rms(d bce/d logit), [11] nB = 1/rms(d mse/d feature), [12] nA/nB, [13] 1.0; flags = {train_dis, train_dec} */
+int fmri_compose_gate(float* scal, int* flags, float batch, float nfeat, float lambda_mse, float equilibrium,
+                      float margin, int gate_on, int force_dis, int force_dec, void* stream);
+/* starting cotangents of the two back-propagated streams, fp16, multiplied by gscale * (*norm) (norm: device float) */
+int fmri_gan_head_bwd(const float* logit, int ldl, int B, void* dlogit, int ldg, float gscale, const float* norm,
+                      void* stream);
+int fmri_feat_mse_bwd(const void* feat, int B, int F, void* dfeat, float gscale, const float* norm, void* stream);
+/* out = a * (*a_dev) * x + b * y   (fp16 tensors, fp32 math; y and a_dev may be NULL) */
+int fmri_axpby_f16(const void* x, const void* y, void* out, int64_t n, float a, float b, const float* a_dev,
+                   void* stream);
 
-/* ---- optimizers over flat fp32 buffers (train_vgan_stage1.py:275-283; train_wae_stage1.py:221-224) --- */
+/* device-side unit-RMS re-normalisation of an fp32 cotangent before an fp16 backward pass:
+ *   fmri_sumsq : *acc += sum x^2 (all-reduce acc across ranks if data parallel)
+ *   fmri_renorm: f = 1/sqrt(*sumsq/count); out16 = x*f*scale; *factor_out = (*factor_in)*f */
+int fmri_sumsq(const float* x, int64_t n, float* acc, void* stream);
+int fmri_renorm(const float* x, void* out16, int64_t n, float scale, const float* sumsq, float count,
+                const float* factor_in, float* factor_out, void* stream);
+
+/* ---- optimizers over flat fp32 buffers (train_vgan_stage1.py:275-283; train_wae_stage1.py:221-224) ---
+ * g_true = g * gscale / (*gdev) (gdev: device float or NULL), clamped to +-clamp if clamp > 0; the whole
+ * update is skipped when flag != NULL and *flag == 0 (device-side equilibrium gate). */
 int fmri_rmsprop(float* p, const float* g, float* sq, int64_t n, float lr, float alpha, float eps, float gscale,
-                 float clamp, const int* flag, void* stream);
+                 const float* gdev, float clamp, const int* flag, void* stream);
 int fmri_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
-              float bc1, float bc2_sqrt, float gscale, float clamp, const int* flag, void* stream);
+              float bc1, float bc2_sqrt, float gscale, const float* gdev, float clamp, const int* flag, void* stream);
 
 #ifdef __cplusplus
 }

@@ -73,4 +73,5 @@ def test_argument_validation_without_gpu(lib):
     assert lib.fmri_igemm(z, z, z, None, z, 1, 4, 4, 8, 4, 4, 8, 8, 5, 1, 2, 0, 0, 0, 1, 0, 48, None) == -2
     # split-K needs fp32 slabs
     assert lib.fmri_igemm(z, z, z, None, z, 1, 4, 4, 8, 4, 4, 8, 8, 5, 1, 2, 0, 0, 0, 2, 0, 32, None) == -1
-    assert L.load().fmri_bn_stats(None, 4, 8, None, None) == -1
+    assert L.load().fmri_bn_stats(None, 4, 8, None, None, 0, None) == -1
+    assert L.load().fmri_bn_ws_floats(786432, 128) >= 2 * 128

@@ -209,8 +209,9 @@ def test_dense_forward_dgrad_wgrad(M, K, N, in_perm, out_perm):
     _close(from_engine_in(dx32.cpu()), xr.grad, "dense dgrad fp32", tol=1e-3)
     layer.wgrad(x16, dy16, 2.0)
     _close(g.grads["w"].cpu() * 2.0, wr.grad, "dense wgrad", tol=3e-3)
-    layer.bias_grad(dy16, 2.0)
-    _close(g.grads["b"].cpu() * 2.0, dy.sum(0), "dense bias grad")
+    if not out_perm:
+        layer.bias_grad(dy16, 2.0)
+        _close(g.grads["b"].cpu() * 2.0, dy.sum(0), "dense bias grad")
 
 
 @pytest.mark.parametrize("M,C", [(3 * 64 * 64, 32), (600, 128), (2 * 13 * 13, 256), (7, 1024), (5, 16384), (12, 512)])
@@ -302,9 +303,13 @@ def test_loss_kernels():
     loss.backward()
     dh16 = torch.empty(B, 2 * Z, dtype=torch.float16, device=DEV)
     dh32 = torch.empty(B, 2 * Z, device=DEV)
-    lib.call("fmri_latent_bwd", P(hd), P(ed), P(dz.to(DEV)), Z, 1.0, 1.0, B, Z, 16.0, P(dh16), P(dh32), 1)
+    lib.call("fmri_latent_bwd", P(hd), P(ed), P(dz.to(DEV)), Z, 1.0, 1.0, None, B, Z, 16.0, P(dh16), P(dh32), 1)
     _close(dh32.cpu(), hr.grad, "dhead32", tol=1e-4)
     _close(dh16.float().cpu() / 16.0, hr.grad, "dhead16")
+    # device-side normalisation factor n: dz carries n, the KL term is multiplied by n inside the kernel
+    nrm = torch.tensor([3.0], device=DEV)
+    lib.call("fmri_latent_bwd", P(hd), P(ed), P((dz * 3.0).to(DEV)), Z, 1.0, 1.0, P(nrm), B, Z, 1.0, None, P(dh32), 1)
+    _close(dh32.cpu() / 3.0, hr.grad, "dhead32 normalised", tol=1e-4)
     # GAN head
     logit = torch.randn(3 * B) * 2
     p_ref = torch.sigmoid(logit)
@@ -317,10 +322,14 @@ def test_loss_kernels():
     scal = torch.zeros(16, device=DEV)
     prob = torch.empty(3 * B, device=DEV)
     dl16 = torch.empty(3 * B, 8, dtype=torch.float16, device=DEV)
-    lib.call("fmri_gan_head", P(logit.to(DEV)), 1, B, P(prob), P(scal), P(dl16), 8, 32.0)
+    lgd = logit.to(DEV)
+    lib.call("fmri_gan_head", P(lgd), 1, B, P(prob), P(scal))
     _close(prob.cpu(), p_ref, "prob", tol=1e-5)
     _close(scal[:3].cpu(), torch.stack([bo.sum(), bp.sum(), bs.sum()]).detach(), "bce sums", tol=1e-5)
-    _close(dl16[:, 0].float().cpu() / 32.0, lr_.grad, "dlogit")
+    assert abs(scal[9].item() - lr_.grad.pow(2).sum().item()) < 1e-4 * lr_.grad.pow(2).sum().item()
+    nrm = torch.tensor([0.5], device=DEV)
+    lib.call("fmri_gan_head_bwd", P(lgd), 1, B, P(dl16), 8, 32.0, P(nrm))
+    _close(dl16[:, 0].float().cpu() / 16.0, lr_.grad, "dlogit")
     assert (dl16[:, 1:] == 0).all()
     # feature mse
     Fd = 16384
@@ -332,17 +341,21 @@ def test_loss_kernels():
     rows = torch.zeros(B, device=DEV)
     tot = torch.zeros(1, device=DEV)
     df = torch.empty_like(f16)
-    lib.call("fmri_feat_mse", P(f16), B, Fd, P(rows), P(tot), P(df), 4.0)
+    lib.call("fmri_feat_mse", P(f16), B, Fd, P(rows), P(tot))
     _close(rows.cpu(), mse.detach(), "mse rows", tol=1e-4)
-    _close(df.float().cpu() / 4.0, fr.grad, "dfeat")
-    # gate
-    scal = torch.tensor([0.4 * B, 0.2 * B, 0.5 * B, 7.0, 11.0, 3.0] + [0.0] * 10, device=DEV)
+    nrm = torch.tensor([2.0], device=DEV)
+    lib.call("fmri_feat_mse_bwd", P(f16), B, Fd, P(df), 4.0, P(nrm))
+    _close(df.float().cpu() / 8.0, fr.grad, "dfeat")
+    # gate + stream normalisation factors
+    scal = torch.tensor([0.4 * B, 0.2 * B, 0.5 * B, 7.0, 11.0, 3.0, 0, 0, 0, 12.0] + [0.0] * 6, device=DEV)
     flags = torch.zeros(2, dtype=torch.int32, device=DEV)
-    lib.call("fmri_compose_gate", P(scal), P(flags), float(B), 1e-6, 0.68, 0.35, 1, -1, -1)
+    lib.call("fmri_compose_gate", P(scal), P(flags), float(B), 100.0, 1e-6, 0.68, 0.35, 1, -1, -1)
     s = scal.cpu()
     assert flags.tolist() == [0, 1]                     # bce_pred mean 0.2 < 0.33 -> discriminator paused
     assert abs(s[6] - 18.0) < 1e-5 and abs(s[7] - 1.1 * B) < 1e-5
     assert abs(s[8] - (1e-6 * 11.0 - (1 - 1e-6) * 1.1 * B)) < 1e-5
+    na, nb = 1 / np.sqrt(12.0 / (3 * B)), 1 / np.sqrt(2 * 11.0 / (B * 100.0))
+    assert abs(s[10] - na) < 1e-4 * na and abs(s[11] - nb) < 1e-4 * nb and abs(s[12] - na / nb) < 1e-4 * na / nb
 
 
 def test_optimizers_match_torch():
@@ -360,11 +373,13 @@ def test_optimizers_match_torch():
     for g in grads:
         pt.grad = g.clone()
         opt.step()
-        lib.call("fmri_rmsprop", P(pd), P(g.to(DEV)), P(sq), n, 1e-4, 0.9, 1e-8, 1.0, 0.0, P(flag))
+        # gradient stored with a device-side factor 4 that the kernel divides out again
+        four = torch.tensor([4.0], device=DEV)
+        lib.call("fmri_rmsprop", P(pd), P((g * 4.0).to(DEV)), P(sq), n, 1e-4, 0.9, 1e-8, 1.0, P(four), 0.0, P(flag))
     assert torch.allclose(pd.cpu(), pt.detach(), rtol=1e-6, atol=1e-7)
     flag.zero_()
     before = pd.clone()
-    lib.call("fmri_rmsprop", P(pd), P(grads[0].to(DEV)), P(sq), n, 1e-4, 0.9, 1e-8, 1.0, 0.0, P(flag))
+    lib.call("fmri_rmsprop", P(pd), P(grads[0].to(DEV)), P(sq), n, 1e-4, 0.9, 1e-8, 1.0, None, 0.0, P(flag))
     assert torch.equal(pd, before)                       # gated off
     # Adam(0.5, 0.999)
     pt = p0.clone().requires_grad_(True)
@@ -374,5 +389,5 @@ def test_optimizers_match_torch():
         pt.grad = g.clone()
         opt.step()
         lib.call("fmri_adam", P(pd), P(g.to(DEV)), P(m), P(v), n, 1e-4, 0.5, 0.999, 1e-8, 1 - 0.5 ** t,
-                 float(np.sqrt(1 - 0.999 ** t)), 1.0, 0.0, None)
+                 float(np.sqrt(1 - 0.999 ** t)), 1.0, None, 0.0, None)
     assert torch.allclose(pd.cpu(), pt.detach(), rtol=2e-6, atol=1e-7)

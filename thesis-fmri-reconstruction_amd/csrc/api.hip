@@ -203,9 +203,11 @@ int fmri_permute_chw(const float* src, float* dst, int C, int HW, int to_engine,
     return permute_chw_launch(src, dst, C, HW, to_engine, scale, accumulate, S(stream));
 }
 
-int fmri_bn_stats(const void* x, int M, int C, float* sums2C, void* stream) {
+int64_t fmri_bn_ws_floats(int M, int C) { return (M < 1 || C < 8) ? 0 : bn_ws_floats(M, C); }
+
+int fmri_bn_stats(const void* x, int M, int C, float* sums2C, float* ws, int64_t ws_floats, void* stream) {
     if (!x || !sums2C || (C & 7) || M < 1) return FMRI_E_BADARG;
-    return bn_stats_launch((const half_t*)x, M, C, sums2C, S(stream));
+    return bn_stats_launch((const half_t*)x, M, C, sums2C, ws, ws_floats, S(stream));
 }
 int fmri_bn_finalize(const float* sums2C, int C, float count, const float* gamma, const float* beta, float eps,
                      float momentum, int updates, float* running_mean, float* running_var, float* mean, float* rstd,
@@ -220,10 +222,11 @@ int fmri_bn_apply(const void* x, void* y, int M, int C, const float* scale, cons
     return bn_apply_launch((const half_t*)x, (half_t*)y, M, C, scale, shift, relu, S(stream));
 }
 int fmri_bn_bwd_reduce(const void* x, const void* dy, int M, int C, const float* mean, const float* rstd,
-                       const float* gamma, const float* beta, int relu, float* sums2C, void* stream) {
-    if (!x || !dy || (C & 7)) return FMRI_E_BADARG;
-    return bn_bwd_reduce_launch((const half_t*)x, (const half_t*)dy, M, C, mean, rstd, gamma, beta, relu, sums2C,
-                                S(stream));
+                       const float* gamma, const float* beta, int relu, float* sums2C, float* ws,
+                       int64_t ws_floats, void* stream) {
+    if (!x || !dy || !sums2C || (C & 7)) return FMRI_E_BADARG;
+    return bn_bwd_reduce_launch((const half_t*)x, (const half_t*)dy, M, C, mean, rstd, gamma, beta, relu, sums2C, ws,
+                                ws_floats, S(stream));
 }
 int fmri_bn_bwd_apply(const void* x, const void* dy, void* dx, int M, int C, float count, const float* mean,
                       const float* rstd, const float* gamma, const float* beta, int relu, const float* sums2C,
@@ -232,9 +235,11 @@ int fmri_bn_bwd_apply(const void* x, const void* dy, void* dx, int M, int C, flo
     return bn_bwd_apply_launch((const half_t*)x, (const half_t*)dy, (half_t*)dx, M, C, count, mean, rstd, gamma, beta,
                                relu, sums2C, S(stream));
 }
-int fmri_act_bwd(const void* y, const void* dy, void* dpre, int M, int C, int act, float* colsum, void* stream) {
+int fmri_act_bwd(const void* y, const void* dy, void* dpre, int M, int C, int act, float* colsum2C, float* ws,
+                 int64_t ws_floats, void* stream) {
     if (!y || !dy || !dpre || (C & 7)) return FMRI_E_BADARG;
-    return act_bwd_launch((const half_t*)y, (const half_t*)dy, (half_t*)dpre, M, C, act, colsum, S(stream));
+    return act_bwd_launch((const half_t*)y, (const half_t*)dy, (half_t*)dpre, M, C, act, colsum2C, ws, ws_floats,
+                          S(stream));
 }
 
 int fmri_latent_fwd(const float* head, const float* eps, int B, int Z, int zp, void* z16, float* kl_rows,
@@ -243,50 +248,69 @@ int fmri_latent_fwd(const float* head, const float* eps, int B, int Z, int zp, v
     return latent_fwd_launch(head, eps, B, Z, zp, (half_t*)z16, kl_rows, kl_total, sample, S(stream));
 }
 int fmri_latent_bwd(const float* head, const float* eps, const float* dz, int ldz, float dz_unscale, float kl_w,
-                    int B, int Z, float out_scale, void* dhead16, float* dhead32, int sample, void* stream) {
+                    const float* kl_dev, int B, int Z, float out_scale, void* dhead16, float* dhead32, int sample,
+                    void* stream) {
     if (!head || (sample && !eps)) return FMRI_E_BADARG;
-    return latent_bwd_launch(head, eps, dz, ldz, dz_unscale, kl_w, B, Z, out_scale, (half_t*)dhead16, dhead32, sample,
-                             S(stream));
+    return latent_bwd_launch(head, eps, dz, ldz, dz_unscale, kl_w, kl_dev, B, Z, out_scale, (half_t*)dhead16, dhead32,
+                             sample, S(stream));
 }
-int fmri_feat_mse(const void* feat, int B, int F, float* mse_rows, float* mse_total, void* dfeat, float gscale,
-                  void* stream) {
+int fmri_feat_mse(const void* feat, int B, int F, float* mse_rows, float* mse_total, void* stream) {
     if (!feat || (F & 7)) return FMRI_E_BADARG;
-    return feat_mse_launch((const half_t*)feat, B, F, mse_rows, mse_total, (half_t*)dfeat, gscale, S(stream));
+    return feat_mse_launch((const half_t*)feat, B, F, mse_rows, mse_total, S(stream));
+}
+int fmri_feat_mse_bwd(const void* feat, int B, int F, void* dfeat, float gscale, const float* norm, void* stream) {
+    if (!feat || !dfeat || (F & 7)) return FMRI_E_BADARG;
+    return feat_mse_bwd_launch((const half_t*)feat, B, F, (half_t*)dfeat, gscale, norm, S(stream));
 }
 int fmri_pixel_sq(const void* x, const void* xt, int64_t npix, int C, int Cp, float* total, void* dxt, float gscale,
                   void* stream) {
     if (!x || !xt) return FMRI_E_BADARG;
     return pixel_sq_launch((const half_t*)x, (const half_t*)xt, npix, C, Cp, total, (half_t*)dxt, gscale, S(stream));
 }
-int fmri_gan_head(const float* logit, int ldl, int B, float* prob, float* scal3, void* dlogit, int ldg, float gscale,
-                  void* stream) {
-    if (!logit || !scal3) return FMRI_E_BADARG;
-    return gan_head_launch(logit, ldl, B, prob, scal3, (half_t*)dlogit, ldg, gscale, S(stream));
+int fmri_gan_head(const float* logit, int ldl, int B, float* prob, float* scal, void* stream) {
+    if (!logit || !scal) return FMRI_E_BADARG;
+    return gan_head_launch(logit, ldl, B, prob, scal, S(stream));
+}
+int fmri_gan_head_bwd(const float* logit, int ldl, int B, void* dlogit, int ldg, float gscale, const float* norm,
+                      void* stream) {
+    if (!logit || !dlogit) return FMRI_E_BADARG;
+    return gan_head_bwd_launch(logit, ldl, B, (half_t*)dlogit, ldg, gscale, norm, S(stream));
 }
 int fmri_wae_logloss(const float* logit, int ldl, int n, int one_minus, float w, float* total, float* prob,
                      void* dlogit, int ldg, float gscale, void* stream) {
     if (!logit) return FMRI_E_BADARG;
     return wae_logloss_launch(logit, ldl, n, one_minus, w, total, prob, (half_t*)dlogit, ldg, gscale, S(stream));
 }
-int fmri_compose_gate(float* scal, int* flags, float batch, float lambda_mse, float equilibrium, float margin,
-                      int gate_on, int force_dis, int force_dec, void* stream) {
+int fmri_compose_gate(float* scal, int* flags, float batch, float nfeat, float lambda_mse, float equilibrium,
+                      float margin, int gate_on, int force_dis, int force_dec, void* stream) {
     if (!scal || !flags) return FMRI_E_BADARG;
-    return compose_gate_launch(scal, flags, batch, lambda_mse, equilibrium, margin, gate_on, force_dis, force_dec,
-                               S(stream));
+    return compose_gate_launch(scal, flags, batch, nfeat, lambda_mse, equilibrium, margin, gate_on, force_dis,
+                               force_dec, S(stream));
 }
-int fmri_axpby_f16(const void* x, const void* y, void* out, int64_t n, float a, float b, void* stream) {
+int fmri_axpby_f16(const void* x, const void* y, void* out, int64_t n, float a, float b, const float* a_dev,
+                   void* stream) {
     if (!x || !out || (n & 7)) return FMRI_E_BADARG;
-    return axpby_f16_launch((const half_t*)x, (const half_t*)y, (half_t*)out, n, a, b, S(stream));
+    return axpby_f16_launch((const half_t*)x, (const half_t*)y, (half_t*)out, n, a, b, a_dev, S(stream));
+}
+int fmri_sumsq(const float* x, int64_t n, float* acc, void* stream) {
+    if (!x || !acc) return FMRI_E_BADARG;
+    return sumsq_launch(x, n, acc, S(stream));
+}
+int fmri_renorm(const float* x, void* out16, int64_t n, float scale, const float* sumsq, float count,
+                const float* factor_in, float* factor_out, void* stream) {
+    if (!x || !out16 || !sumsq || count <= 0.f) return FMRI_E_BADARG;
+    return renorm_launch(x, (half_t*)out16, n, scale, sumsq, count, factor_in, factor_out, S(stream));
 }
 int fmri_rmsprop(float* p, const float* g, float* sq, int64_t n, float lr, float alpha, float eps, float gscale,
-                 float clamp, const int* flag, void* stream) {
+                 const float* gdev, float clamp, const int* flag, void* stream) {
     if (!p || !g || !sq) return FMRI_E_BADARG;
-    return rmsprop_launch(p, g, sq, n, lr, alpha, eps, gscale, clamp, flag, S(stream));
+    return rmsprop_launch(p, g, sq, n, lr, alpha, eps, gscale, gdev, clamp, flag, S(stream));
 }
 int fmri_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
-              float bc1, float bc2_sqrt, float gscale, float clamp, const int* flag, void* stream) {
+              float bc1, float bc2_sqrt, float gscale, const float* gdev, float clamp, const int* flag,
+              void* stream) {
     if (!p || !g || !m || !v) return FMRI_E_BADARG;
-    return adam_launch(p, g, m, v, n, lr, b1, b2, eps, bc1, bc2_sqrt, gscale, clamp, flag, S(stream));
+    return adam_launch(p, g, m, v, n, lr, b1, b2, eps, bc1, bc2_sqrt, gscale, gdev, clamp, flag, S(stream));
 }
 
 }  // extern "C"

@@ -38,9 +38,11 @@ int reduce_slabs_launch(const float* slabs, int nslabs, int64_t slab_stride, int
 int permute_chw_launch(const float* s, float* d, int C, int HW, int to_engine, float scale, int accumulate,
                        hipStream_t st);
 
-int bn_stats_launch(const half_t* x, int M, int C, float* sums, hipStream_t st);
+int64_t bn_ws_floats(int M, int C);
+int bn_stats_launch(const half_t* x, int M, int C, float* sums, float* ws, int64_t ws_floats, hipStream_t st);
 int bn_bwd_reduce_launch(const half_t* x, const half_t* dy, int M, int C, const float* mean, const float* rstd,
-                         const float* gamma, const float* beta, int relu, float* sums, hipStream_t st);
+                         const float* gamma, const float* beta, int relu, float* sums, float* ws, int64_t ws_floats,
+                         hipStream_t st);
 int bn_finalize_launch(const float* sums, int C, float count, const float* gamma, const float* beta, float eps,
                        float momentum, int updates, float* rm, float* rv, float* mean, float* rstd, float* scale,
                        float* shift, hipStream_t st);
@@ -49,27 +51,35 @@ int bn_apply_launch(const half_t* x, half_t* y, int M, int C, const float* scale
 int bn_bwd_apply_launch(const half_t* x, const half_t* dy, half_t* dx, int M, int C, float count, const float* mean,
                         const float* rstd, const float* gamma, const float* beta, int relu, const float* sums,
                         hipStream_t st);
-int act_bwd_launch(const half_t* y, const half_t* dy, half_t* dpre, int M, int C, int act, float* colsum,
-                   hipStream_t st);
+int act_bwd_launch(const half_t* y, const half_t* dy, half_t* dpre, int M, int C, int act, float* colsum, float* ws,
+                   int64_t ws_floats, hipStream_t st);
 
 int latent_fwd_launch(const float* head, const float* eps, int B, int Z, int zp, half_t* z16, float* kl_rows,
                       float* kl_total, int sample, hipStream_t st);
 int latent_bwd_launch(const float* head, const float* eps, const float* dz, int ldz, float dz_unscale, float kl_w,
-                      int B, int Z, float out_scale, half_t* dhead16, float* dhead32, int sample, hipStream_t st);
-int feat_mse_launch(const half_t* feat, int B, int F, float* mse_rows, float* mse_total, half_t* dfeat, float gscale,
-                    hipStream_t st);
+                      const float* kl_dev, int B, int Z, float out_scale, half_t* dhead16, float* dhead32, int sample,
+                      hipStream_t st);
+int feat_mse_launch(const half_t* feat, int B, int F, float* mse_rows, float* mse_total, hipStream_t st);
+int feat_mse_bwd_launch(const half_t* feat, int B, int F, half_t* dfeat, float gscale, const float* norm,
+                        hipStream_t st);
 int pixel_sq_launch(const half_t* x, const half_t* xt, int64_t npix, int C, int Cp, float* total, half_t* dxt,
                     float gscale, hipStream_t st);
-int gan_head_launch(const float* logit, int ldl, int B, float* prob, float* scal, half_t* dlogit, int ldg,
-                    float gscale, hipStream_t st);
+int gan_head_launch(const float* logit, int ldl, int B, float* prob, float* scal, hipStream_t st);
+int gan_head_bwd_launch(const float* logit, int ldl, int B, half_t* dlogit, int ldg, float gscale, const float* norm,
+                        hipStream_t st);
 int wae_logloss_launch(const float* logit, int ldl, int n, int one_minus, float w, float* total, float* prob,
                        half_t* dlogit, int ldg, float gscale, hipStream_t st);
-int compose_gate_launch(float* scal, int* flags, float batch, float lambda_mse, float equilibrium, float margin,
-                        int gate_on, int force_dis, int force_dec, hipStream_t st);
-int axpby_f16_launch(const half_t* x, const half_t* y, half_t* out, int64_t n, float a, float b, hipStream_t st);
+int compose_gate_launch(float* scal, int* flags, float batch, float nfeat, float lambda_mse, float equilibrium,
+                        float margin, int gate_on, int force_dis, int force_dec, hipStream_t st);
+int axpby_f16_launch(const half_t* x, const half_t* y, half_t* out, int64_t n, float a, float b, const float* pa,
+                     hipStream_t st);
+int sumsq_launch(const float* x, int64_t n, float* acc, hipStream_t st);
+int renorm_launch(const float* x, half_t* out, int64_t n, float scale, const float* sumsq, float count,
+                  const float* factor_in, float* factor_out, hipStream_t st);
 int rmsprop_launch(float* p, const float* g, float* sq, int64_t n, float lr, float alpha, float eps, float gscale,
-                   float clamp, const int* flag, hipStream_t st);
+                   const float* gdev, float clamp, const int* flag, hipStream_t st);
 int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
-                float bc1, float bc2_sqrt, float gscale, float clamp, const int* flag, hipStream_t st);
+                float bc1, float bc2_sqrt, float gscale, const float* gdev, float clamp, const int* flag,
+                hipStream_t st);
 
 }  // namespace fmri

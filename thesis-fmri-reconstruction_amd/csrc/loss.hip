@@ -5,9 +5,19 @@
 //   VaeGan.loss              models/vae_gan.py:302-320     nle, kl, feature mse, 3 x bce (eps 1e-3 in the log)
 //   loss composition + gate  train/train_vgan_stage1.py:368-404
 //   RMSprop / Adam updates   train/train_vgan_stage1.py:275-283, train/train_wae_stage1.py:221-224
+//
+// fp16 cotangents: the two back-propagated streams start from very different, training-dependent
+// magnitudes (d bce/d logit vs. d mse/d feature).  Each stream is therefore normalised ON THE DEVICE to
+// unit RMS at its starting point (norm factors nA, nB in the scalar block, derived from all-reduced sums so
+// every data-parallel rank uses the same factor); everything downstream is linear, so the factor is divided
+// out again by the fused optimizer kernels.  No host synchronisation is involved.
 #include "kernels.h"
 
 namespace fmri {
+
+// scalar block layout (floats) -- keep in sync with fmri_hip/steps.py
+enum Slot { S_BCE_O = 0, S_BCE_P = 1, S_BCE_S = 2, S_KL = 3, S_MSE = 4, S_NLE = 5, S_LENC = 6, S_LDIS = 7,
+            S_LDEC = 8, S_DL2 = 9, S_NA = 10, S_NB = 11, S_RATIO = 12, S_ONE = 13 };
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -52,13 +62,15 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(const float* __restrict
     }
 }
 
-// backward: dhead[row] = [ dz + kl_w*mu | dz*eps*0.5*exp(0.5 lv) + kl_w*0.5*(exp(lv)-1) ] * out_scale
-// dz arrives as fp32 [B][ldz] scaled by 1/dz_scale_inv (dz_true = dz * dz_unscale).
+// backward: dhead[row] = ([ g + w*mu | g*eps*0.5*exp(0.5 lv) + w*0.5*(exp(lv)-1) ]) * out_scale
+//   g = dz * dz_unscale (dz may be null), w = kl_w * (*kl_dev) (kl_dev may be null -> 1): when dz carries a
+//   device normalisation factor n the KL term is multiplied by the same n so the sum stays consistent.
 __global__ void latent_bwd_kernel(const float* __restrict__ head, const float* __restrict__ eps,
-                                  const float* __restrict__ dz, int ldz, float dz_unscale, float kl_w, int B, int Z,
-                                  float out_scale, half_t* __restrict__ dhead16, float* __restrict__ dhead32,
-                                  int sample) {
+                                  const float* __restrict__ dz, int ldz, float dz_unscale, float kl_w,
+                                  const float* __restrict__ kl_dev, int B, int Z, float out_scale,
+                                  half_t* __restrict__ dhead16, float* __restrict__ dhead32, int sample) {
     const int64_t total = (int64_t)B * Z;
+    const float w = kl_w * (kl_dev ? *kl_dev : 1.f);
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
         const int j = (int)(i % Z);
@@ -66,8 +78,8 @@ __global__ void latent_bwd_kernel(const float* __restrict__ head, const float* _
         const float mu = head[row * 2 * Z + j];
         const float lv = head[row * 2 * Z + Z + j];
         const float g = dz ? dz[row * ldz + j] * dz_unscale : 0.f;
-        const float dmu = g + kl_w * mu;
-        float dlv = kl_w * 0.5f * (__expf(lv) - 1.f);
+        const float dmu = g + w * mu;
+        float dlv = w * 0.5f * (__expf(lv) - 1.f);
         if (sample) dlv += g * eps[row * Z + j] * 0.5f * __expf(0.5f * lv);
         if (dhead16) {
             dhead16[row * 2 * Z + j] = (half_t)(dmu * out_scale);
@@ -80,12 +92,9 @@ __global__ void latent_bwd_kernel(const float* __restrict__ head, const float* _
     }
 }
 
-// ---- feature-matching term: mse_b = sum_f 0.5 (f_o - f_p)^2 over the raw conv3 features and its
-// cotangent w.r.t. the 3B feature rows (orig: +d, pred: -d, sampled: 0), scaled for fp16 storage.
-// one block per sample.
+// ---- feature-matching term: mse_b = sum_f 0.5 (f_o - f_p)^2 over the raw conv-3 features. one block / sample
 __global__ __launch_bounds__(256) void feat_mse_kernel(const half_t* __restrict__ feat, int B, int F,
-                                                       float* __restrict__ mse_rows, float* __restrict__ mse_total,
-                                                       half_t* __restrict__ dfeat, float gscale) {
+                                                       float* __restrict__ mse_rows, float* __restrict__ mse_total) {
     __shared__ float sh[4];
     const int b = blockIdx.x;
     const half_t* fo = feat + (int64_t)b * F;
@@ -94,25 +103,41 @@ __global__ __launch_bounds__(256) void feat_mse_kernel(const half_t* __restrict_
     for (int i = threadIdx.x * 8; i < F; i += 256 * 8) {
         const h8 o = *(const h8*)(fo + i);
         const h8 p = *(const h8*)(fp + i);
-        h8 d, nd, z;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float df = (float)o[j] - (float)p[j];
             s += 0.5f * df * df;
-            d[j] = (half_t)(df * gscale);
-            nd[j] = (half_t)(-df * gscale);
-            z[j] = (half_t)0.f;
-        }
-        if (dfeat) {
-            *(h8*)(dfeat + (int64_t)b * F + i) = d;
-            *(h8*)(dfeat + (int64_t)(B + b) * F + i) = nd;
-            *(h8*)(dfeat + (int64_t)(2 * B + b) * F + i) = z;
         }
     }
     s = block_sum_256(s, sh);
     if (threadIdx.x == 0) {
         if (mse_rows) mse_rows[b] = s;
         if (mse_total) atomicAdd(mse_total, s);
+    }
+}
+
+// cotangent of sum(mse) w.r.t. the 3B feature rows: orig +d, pred -d, sampled 0; times gscale * (*norm)
+__global__ __launch_bounds__(256) void feat_mse_bwd_kernel(const half_t* __restrict__ feat, int B, int F,
+                                                           half_t* __restrict__ dfeat, float gscale,
+                                                           const float* __restrict__ norm) {
+    const int b = blockIdx.x;
+    const float sc = gscale * (norm ? *norm : 1.f);
+    const half_t* fo = feat + (int64_t)b * F;
+    const half_t* fp = feat + (int64_t)(B + b) * F;
+    for (int i = threadIdx.x * 8; i < F; i += 256 * 8) {
+        const h8 o = *(const h8*)(fo + i);
+        const h8 p = *(const h8*)(fp + i);
+        h8 d, nd, z;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float df = ((float)o[j] - (float)p[j]) * sc;
+            d[j] = (half_t)df;
+            nd[j] = (half_t)(-df);
+            z[j] = (half_t)0.f;
+        }
+        *(h8*)(dfeat + (int64_t)b * F + i) = d;
+        *(h8*)(dfeat + (int64_t)(B + b) * F + i) = nd;
+        *(h8*)(dfeat + (int64_t)(2 * B + b) * F + i) = z;
     }
 }
 
@@ -138,37 +163,47 @@ __global__ __launch_bounds__(256) void pixel_sq_kernel(const half_t* __restrict_
     if (threadIdx.x == 0 && total) atomicAdd(total, s);
 }
 
+__device__ __forceinline__ void gan_terms(float l, int part, float& p, float& bce, float& dl) {
+    p = 1.f / (1.f + expf(-l));
+    if (part == 0) {
+        bce = -logf(p + 1e-3f);
+        dl = -p * (1.f - p) / (p + 1e-3f);
+    } else {
+        bce = -logf(1.f - p + 1e-3f);
+        dl = p * (1.f - p) / (1.f - p + 1e-3f);
+    }
+}
+
 // ---- discriminator class head: logits (fp32 [3B], bias already added) -> sigmoid, the three BCE sums
-// (eps 1e-3 inside the log, models/vae_gan.py:316-318) and d(sum bce)/d logit (scaled, fp16 row stride ldg)
-// scal layout (floats): [0]=bce_orig [1]=bce_pred [2]=bce_samp
+// (eps 1e-3 inside the log, models/vae_gan.py:316-318) and sum of squared d(bce)/d(logit) (for the stream norm).
+// scal: [S_BCE_O..S_BCE_S] += bce sums, [S_DL2] += sum dl^2
 __global__ __launch_bounds__(256) void gan_head_kernel(const float* __restrict__ logit, int ldl, int B,
-                                                       float* __restrict__ prob, float* __restrict__ scal,
-                                                       half_t* __restrict__ dlogit, int ldg, float gscale,
-                                                       int pred_is_sampled /* DCGAN: unused */) {
+                                                       float* __restrict__ prob, float* __restrict__ scal) {
     __shared__ float sh[4];
-    float s[3] = {0.f, 0.f, 0.f};
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 3 * B; i += gridDim.x * blockDim.x) {
-        const float l = logit[(int64_t)i * ldl];
-        const float p = 1.f / (1.f + expf(-l));
+        float p, bce, dl;
         const int part = i / B;
-        float bce, dl;
-        if (part == 0) {
-            bce = -logf(p + 1e-3f);
-            dl = -p * (1.f - p) / (p + 1e-3f);
-        } else {
-            bce = -logf(1.f - p + 1e-3f);
-            dl = p * (1.f - p) / (1.f - p + 1e-3f);
-        }
+        gan_terms(logit[(int64_t)i * ldl], part, p, bce, dl);
         s[part] += bce;
+        s[3] += dl * dl;
         if (prob) prob[i] = p;
-        if (dlogit) {
-            for (int c = 0; c < ldg; ++c) dlogit[(int64_t)i * ldg + c] = (half_t)(c == 0 ? dl * gscale : 0.f);
-        }
     }
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < 4; ++k) {
         const float r = block_sum_256(s[k], sh);
-        if (threadIdx.x == 0) atomicAdd(scal + k, r);
+        if (threadIdx.x == 0) atomicAdd(scal + (k < 3 ? k : (int)S_DL2), r);
+    }
+}
+
+// d(sum bce)/d logit * gscale * (*norm) -> fp16 rows of stride ldg (column 0; others zero)
+__global__ void gan_head_bwd_kernel(const float* __restrict__ logit, int ldl, int B, half_t* __restrict__ dlogit,
+                                    int ldg, float gscale, const float* __restrict__ norm) {
+    const float sc = gscale * (norm ? *norm : 1.f);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 3 * B; i += gridDim.x * blockDim.x) {
+        float p, bce, dl;
+        gan_terms(logit[(int64_t)i * ldl], i / B, p, bce, dl);
+        for (int c = 0; c < ldg; ++c) dlogit[(int64_t)i * ldg + c] = (half_t)(c == 0 ? dl * sc : 0.f);
     }
 }
 
@@ -194,17 +229,27 @@ __global__ __launch_bounds__(256) void wae_logloss_kernel(const float* __restric
     if (threadIdx.x == 0 && total) atomicAdd(total, s);
 }
 
-// ---- loss composition + equilibrium gate, one thread.  scal (floats):
-//  in : [0]=bce_o [1]=bce_p [2]=bce_s [3]=kl [4]=mse [5]=nle
-//  out: [6]=loss_encoder [7]=loss_discriminator [8]=loss_decoder ; flags[0]=train_dis flags[1]=train_dec
-__global__ void compose_gate_kernel(float* __restrict__ scal, int* __restrict__ flags, float batch, float lambda_mse,
-                                    float equilibrium, float margin, int gate_on, int force_dis, int force_dec) {
+// ---- loss composition + equilibrium gate + stream normalisation factors, one thread.
+//  in : bce_o, bce_p, bce_s, kl, mse, nle, dl2 (all already summed over the global batch)
+//  out: loss_encoder, loss_discriminator, loss_decoder; nA = 1/rms(dlogit), nB = 1/rms(dfeat), ratio = nA/nB;
+//       flags[0] = train_dis, flags[1] = train_dec
+__global__ void compose_gate_kernel(float* __restrict__ scal, int* __restrict__ flags, float batch, float nfeat,
+                                    float lambda_mse, float equilibrium, float margin, int gate_on, int force_dis,
+                                    int force_dec) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const float bo = scal[0], bp = scal[1], bs = scal[2];
+    const float bo = scal[S_BCE_O], bp = scal[S_BCE_P], bs = scal[S_BCE_S];
     const float l_dis = bo + bp + bs;
-    scal[6] = scal[3] + scal[4];
-    scal[7] = l_dis;
-    scal[8] = lambda_mse * scal[4] - (1.f - lambda_mse) * l_dis;
+    scal[S_LENC] = scal[S_KL] + scal[S_MSE];
+    scal[S_LDIS] = l_dis;
+    scal[S_LDEC] = lambda_mse * scal[S_MSE] - (1.f - lambda_mse) * l_dis;
+    const float rms_a = sqrtf(scal[S_DL2] / (3.f * batch));
+    const float rms_b = sqrtf(2.f * scal[S_MSE] / (batch * nfeat));
+    const float na = 1.f / fmaxf(rms_a, 1e-20f);
+    const float nb = 1.f / fmaxf(rms_b, 1e-20f);
+    scal[S_NA] = na;
+    scal[S_NB] = nb;
+    scal[S_RATIO] = na / nb;
+    scal[S_ONE] = 1.f;
     int train_dis = 1, train_dec = 1;
     if (gate_on) {
         const float mo = bo / batch, mp = bp / batch;
@@ -218,32 +263,56 @@ __global__ void compose_gate_kernel(float* __restrict__ scal, int* __restrict__ 
     flags[1] = train_dec;
 }
 
-// ---- out = a*x + b*y over fp16 (cotangent mixing, fp32 math); y may be null
+// ---- out = a*(*pa)*x + b*y over fp16 (cotangent mixing, fp32 math); y / pa may be null
 __global__ void axpby_f16_kernel(const half_t* __restrict__ x, const half_t* __restrict__ y, half_t* __restrict__ out,
-                                 int64_t n8, float a, float b) {
+                                 int64_t n8, float a, float b, const float* __restrict__ pa) {
+    const float aa = a * (pa ? *pa : 1.f);
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
         const h8 xv = *(const h8*)(x + i * 8);
         h8 o;
         if (y) {
             const h8 yv = *(const h8*)(y + i * 8);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (half_t)(a * (float)xv[j] + b * (float)yv[j]);
+            for (int j = 0; j < 8; ++j) o[j] = (half_t)(aa * (float)xv[j] + b * (float)yv[j]);
         } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (half_t)(a * (float)xv[j]);
+            for (int j = 0; j < 8; ++j) o[j] = (half_t)(aa * (float)xv[j]);
         }
         *(h8*)(out + i * 8) = o;
     }
 }
 
+// ---- device-side re-normalisation of a cotangent before it enters an fp16 backward pass:
+//   sumsq_kernel : *acc += sum x^2           (acc can then be all-reduced across data-parallel ranks)
+//   renorm_kernel: f = 1/rms, out16 = x * f * scale;  *factor_out = (*factor_in) * f  (factor_in may be null)
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ acc) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        s += x[i] * x[i];
+    s = block_sum_256(s, sh);
+    if (threadIdx.x == 0) atomicAdd(acc, s);
+}
+
+__global__ void renorm_kernel(const float* __restrict__ x, half_t* __restrict__ out, int64_t n, float scale,
+                              const float* __restrict__ sumsq, float count, const float* __restrict__ factor_in,
+                              float* __restrict__ factor_out) {
+    const float f = 1.f / fmaxf(sqrtf(*sumsq / count), 1e-20f);
+    const float sc = f * scale;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (half_t)(x[i] * sc);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && factor_out) *factor_out = (factor_in ? *factor_in : 1.f) * f;
+}
+
 // ---- fused optimizers over a flat fp32 parameter buffer; `flag` (device int, may be null) gates the
-// whole update so the equilibrium gate never needs a host sync.  g is multiplied by gscale, then clamped.
+// whole update so the equilibrium gate never needs a host sync.  g_true = g * gscale / (*gdev), then clamped.
 __global__ void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ sq, int64_t n,
-                               float lr, float alpha, float eps, float gscale, float clamp,
-                               const int* __restrict__ flag) {
+                               float lr, float alpha, float eps, float gscale, const float* __restrict__ gdev,
+                               float clamp, const int* __restrict__ flag) {
     if (flag && *flag == 0) return;
+    const float gs = gscale / (gdev ? *gdev : 1.f);
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float gg = g[i] * gscale;
+        float gg = g[i] * gs;
         if (clamp > 0.f) gg = fminf(fmaxf(gg, -clamp), clamp);
         const float s = alpha * sq[i] + (1.f - alpha) * gg * gg;
         sq[i] = s;
@@ -253,10 +322,12 @@ __global__ void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ 
 
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps, float bc1,
-                            float bc2_sqrt, float gscale, float clamp, const int* __restrict__ flag) {
+                            float bc2_sqrt, float gscale, const float* __restrict__ gdev, float clamp,
+                            const int* __restrict__ flag) {
     if (flag && *flag == 0) return;
+    const float gs = gscale / (gdev ? *gdev : 1.f);
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float gg = g[i] * gscale;
+        float gg = g[i] * gs;
         if (clamp > 0.f) gg = fminf(fmaxf(gg, -clamp), clamp);
         const float mm = b1 * m[i] + (1.f - b1) * gg;
         const float vv = b2 * v[i] + (1.f - b2) * gg * gg;
@@ -281,14 +352,19 @@ int latent_fwd_launch(const float* head, const float* eps, int B, int Z, int zp,
     return LAUNCH_OK();
 }
 int latent_bwd_launch(const float* head, const float* eps, const float* dz, int ldz, float dz_unscale, float kl_w,
-                      int B, int Z, float out_scale, half_t* dhead16, float* dhead32, int sample, hipStream_t st) {
+                      const float* kl_dev, int B, int Z, float out_scale, half_t* dhead16, float* dhead32, int sample,
+                      hipStream_t st) {
     hipLaunchKernelGGL(latent_bwd_kernel, dim3(nblk((int64_t)B * Z)), dim3(256), 0, st, head, eps, dz, ldz,
-                       dz_unscale, kl_w, B, Z, out_scale, dhead16, dhead32, sample);
+                       dz_unscale, kl_w, kl_dev, B, Z, out_scale, dhead16, dhead32, sample);
     return LAUNCH_OK();
 }
-int feat_mse_launch(const half_t* feat, int B, int F, float* mse_rows, float* mse_total, half_t* dfeat, float gscale,
-                    hipStream_t st) {
-    hipLaunchKernelGGL(feat_mse_kernel, dim3(B), dim3(256), 0, st, feat, B, F, mse_rows, mse_total, dfeat, gscale);
+int feat_mse_launch(const half_t* feat, int B, int F, float* mse_rows, float* mse_total, hipStream_t st) {
+    hipLaunchKernelGGL(feat_mse_kernel, dim3(B), dim3(256), 0, st, feat, B, F, mse_rows, mse_total);
+    return LAUNCH_OK();
+}
+int feat_mse_bwd_launch(const half_t* feat, int B, int F, half_t* dfeat, float gscale, const float* norm,
+                        hipStream_t st) {
+    hipLaunchKernelGGL(feat_mse_bwd_kernel, dim3(B), dim3(256), 0, st, feat, B, F, dfeat, gscale, norm);
     return LAUNCH_OK();
 }
 int pixel_sq_launch(const half_t* x, const half_t* xt, int64_t npix, int C, int Cp, float* total, half_t* dxt,
@@ -297,10 +373,14 @@ int pixel_sq_launch(const half_t* x, const half_t* xt, int64_t npix, int C, int 
                        gscale);
     return LAUNCH_OK();
 }
-int gan_head_launch(const float* logit, int ldl, int B, float* prob, float* scal, half_t* dlogit, int ldg,
-                    float gscale, hipStream_t st) {
-    hipLaunchKernelGGL(gan_head_kernel, dim3(nblk(3 * (int64_t)B, 64)), dim3(256), 0, st, logit, ldl, B, prob, scal,
-                       dlogit, ldg, gscale, 0);
+int gan_head_launch(const float* logit, int ldl, int B, float* prob, float* scal, hipStream_t st) {
+    hipLaunchKernelGGL(gan_head_kernel, dim3(nblk(3 * (int64_t)B, 64)), dim3(256), 0, st, logit, ldl, B, prob, scal);
+    return LAUNCH_OK();
+}
+int gan_head_bwd_launch(const float* logit, int ldl, int B, half_t* dlogit, int ldg, float gscale, const float* norm,
+                        hipStream_t st) {
+    hipLaunchKernelGGL(gan_head_bwd_kernel, dim3(nblk(3 * (int64_t)B, 64)), dim3(256), 0, st, logit, ldl, B, dlogit,
+                       ldg, gscale, norm);
     return LAUNCH_OK();
 }
 int wae_logloss_launch(const float* logit, int ldl, int n, int one_minus, float w, float* total, float* prob,
@@ -309,26 +389,38 @@ int wae_logloss_launch(const float* logit, int ldl, int n, int one_minus, float 
                        prob, dlogit, ldg, gscale);
     return LAUNCH_OK();
 }
-int compose_gate_launch(float* scal, int* flags, float batch, float lambda_mse, float equilibrium, float margin,
-                        int gate_on, int force_dis, int force_dec, hipStream_t st) {
-    hipLaunchKernelGGL(compose_gate_kernel, dim3(1), dim3(64), 0, st, scal, flags, batch, lambda_mse, equilibrium,
-                       margin, gate_on, force_dis, force_dec);
+int compose_gate_launch(float* scal, int* flags, float batch, float nfeat, float lambda_mse, float equilibrium,
+                        float margin, int gate_on, int force_dis, int force_dec, hipStream_t st) {
+    hipLaunchKernelGGL(compose_gate_kernel, dim3(1), dim3(64), 0, st, scal, flags, batch, nfeat, lambda_mse,
+                       equilibrium, margin, gate_on, force_dis, force_dec);
     return LAUNCH_OK();
 }
-int axpby_f16_launch(const half_t* x, const half_t* y, half_t* out, int64_t n, float a, float b, hipStream_t st) {
-    hipLaunchKernelGGL(axpby_f16_kernel, dim3(nblk(n / 8)), dim3(256), 0, st, x, y, out, n / 8, a, b);
+int axpby_f16_launch(const half_t* x, const half_t* y, half_t* out, int64_t n, float a, float b, const float* pa,
+                     hipStream_t st) {
+    hipLaunchKernelGGL(axpby_f16_kernel, dim3(nblk(n / 8)), dim3(256), 0, st, x, y, out, n / 8, a, b, pa);
+    return LAUNCH_OK();
+}
+int sumsq_launch(const float* x, int64_t n, float* acc, hipStream_t st) {
+    hipLaunchKernelGGL(sumsq_kernel, dim3(nblk(n, 256)), dim3(256), 0, st, x, n, acc);
+    return LAUNCH_OK();
+}
+int renorm_launch(const float* x, half_t* out, int64_t n, float scale, const float* sumsq, float count,
+                  const float* factor_in, float* factor_out, hipStream_t st) {
+    hipLaunchKernelGGL(renorm_kernel, dim3(nblk(n, 256)), dim3(256), 0, st, x, out, n, scale, sumsq, count, factor_in,
+                       factor_out);
     return LAUNCH_OK();
 }
 int rmsprop_launch(float* p, const float* g, float* sq, int64_t n, float lr, float alpha, float eps, float gscale,
-                   float clamp, const int* flag, hipStream_t st) {
-    hipLaunchKernelGGL(rmsprop_kernel, dim3(nblk(n)), dim3(256), 0, st, p, g, sq, n, lr, alpha, eps, gscale, clamp,
-                       flag);
+                   const float* gdev, float clamp, const int* flag, hipStream_t st) {
+    hipLaunchKernelGGL(rmsprop_kernel, dim3(nblk(n)), dim3(256), 0, st, p, g, sq, n, lr, alpha, eps, gscale, gdev,
+                       clamp, flag);
     return LAUNCH_OK();
 }
 int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
-                float bc1, float bc2_sqrt, float gscale, float clamp, const int* flag, hipStream_t st) {
+                float bc1, float bc2_sqrt, float gscale, const float* gdev, float clamp, const int* flag,
+                hipStream_t st) {
     hipLaunchKernelGGL(adam_kernel, dim3(nblk(n)), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, bc1, bc2_sqrt,
-                       gscale, clamp, flag);
+                       gscale, gdev, clamp, flag);
     return LAUNCH_OK();
 }
 

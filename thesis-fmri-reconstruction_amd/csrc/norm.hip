@@ -2,25 +2,56 @@
 //
 // Replaces nn.BatchNorm2d / nn.BatchNorm1d(momentum=0.9) + ReLU of the reference blocks
 // (models/vae_gan.py:21,28-29,54,58-59,81,108,158) and their autograd backward:
-//   stats    : per-channel sum / sum-of-squares (fp32 atomics into [2][C])           -- HBM bound
+//   stats    : per-channel sum / sum-of-squares                                      -- HBM bound
 //   finalize : mean, rstd, scale/shift, running-stat update (momentum 0.9, unbiased running var,
 //              `updates` consecutive updates for the discriminator's REC+GAN double pass)
 //   apply    : y = relu(x*scale + shift)                                               -- HBM bound
 //   bwd_reduce / bwd_apply : dgamma, dbeta and dx through ReLU + BN (batch statistics)
 // The sums are kept outside the kernels so that a data-parallel run can all-reduce them (SyncBN).
+//
+// All streaming kernels use one thread mapping: a 256-thread block is CX chunk-columns (8 channels =
+// 16 bytes each) x RY row lanes; a thread keeps its channel chunk for the whole kernel, so the
+// per-channel parameters live in registers and a wave always touches whole contiguous rows.  Row loops
+// are unrolled x4 to keep 4 independent 16-byte loads in flight per lane.  Reductions write per-block
+// partials to a workspace and a second tiny kernel folds them (no float atomics: 2048 blocks adding
+// into the same 2*C words serialise at the memory side).
 #include "kernels.h"
 
 namespace fmri {
 
-// 2-D thread block: CX chunk-columns (8 channels each) x RY row lanes, CX*RY = 256.
-template <int MODE>  // 0: stats (sum x, sum x^2); 1: bwd reduce (sum g, sum g*xhat)
+struct RowGeom {
+    int cx_log2;
+    int gx, gy;
+};
+
+static RowGeom row_geometry(int M, int C, int max_gy) {
+    RowGeom g;
+    const int nch = C / 8;
+    g.cx_log2 = 0;
+    while ((1 << g.cx_log2) < nch && g.cx_log2 < 8) ++g.cx_log2;
+    const int CX = 1 << g.cx_log2, RY = 256 >> g.cx_log2;
+    g.gx = (nch + CX - 1) / CX;
+    int gy = (M + RY * 16 - 1) / (RY * 16);          // >= 16 rows per thread
+    int cap = 1024 / g.gx;                            // ~4 blocks per CU
+    if (cap < 1) cap = 1;
+    if (gy > cap) gy = cap;
+    if (gy > max_gy) gy = max_gy;
+    if (gy < 1) gy = 1;
+    g.gy = gy;
+    return g;
+}
+
+// MODE 0: sum x, sum x^2.  MODE 1: sum g, sum g*xhat (g = dy masked by the ReLU of the forward).
+// MODE 2: activation backward: dpre = dy*act'(y) written to `dout`, column sums of dpre.
+template <int MODE>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const half_t* __restrict__ x, const half_t* __restrict__ dy,
-                                                        int M, int C, int cx_log2, const float* __restrict__ mean,
+                                                        half_t* __restrict__ dout, int M, int C, int cx_log2,
+                                                        const float* __restrict__ mean,
                                                         const float* __restrict__ rstd,
                                                         const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, int relu,
-                                                        float* __restrict__ out /* [2][C] */) {
-    __shared__ float red[256 * 16];
+                                                        const float* __restrict__ beta, int relu_or_act,
+                                                        float* __restrict__ part /* [gridDim.y][2][C] */) {
+    __shared__ float red[256 * 17];
     const int CX = 1 << cx_log2;
     const int RY = 256 >> cx_log2;
     const int cx = threadIdx.x & (CX - 1);
@@ -39,36 +70,73 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const half_t* __restrict
                 ga[j] = gamma[chunk * 8 + j]; be[j] = beta[chunk * 8 + j];
             }
         }
-        for (int m = blockIdx.y * RY + ry; m < M; m += gridDim.y * RY) {
-            const h8 xv = *(const h8*)(x + (int64_t)m * C + chunk * 8);
+        const int stride = gridDim.y * RY;
+        const int64_t coff = (int64_t)chunk * 8;
+        auto body = [&](const h8& xv, const h8& gv, int m) {
             if (MODE == 0) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { const float f = (float)xv[j]; s0[j] += f; s1[j] += f * f; }
-            } else {
-                const h8 gv = *(const h8*)(dy + (int64_t)m * C + chunk * 8);
+            } else if (MODE == 1) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float xh = ((float)xv[j] - mu[j]) * rs[j];
                     float g = (float)gv[j];
-                    if (relu && !(xh * ga[j] + be[j] > 0.f)) g = 0.f;
+                    if (relu_or_act && !(xh * ga[j] + be[j] > 0.f)) g = 0.f;
                     s0[j] += g; s1[j] += g * xh;
                 }
+            } else {
+                h8 ov;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float yy = (float)xv[j];
+                    float g = (float)gv[j];
+                    if (relu_or_act == ACT_RELU) g = yy > 0.f ? g : 0.f;
+                    else if (relu_or_act == ACT_TANH) g = g * (1.f - yy * yy);
+                    ov[j] = (half_t)g;
+                    s0[j] += g;
+                }
+                *(h8*)(dout + (int64_t)m * C + coff) = ov;
             }
+        };
+        int m = blockIdx.y * RY + ry;
+        for (; m + 3 * stride < M; m += 4 * stride) {
+            h8 xv[4], gv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                xv[u] = *(const h8*)(x + (int64_t)(m + u * stride) * C + coff);
+                if (MODE != 0) gv[u] = *(const h8*)(dy + (int64_t)(m + u * stride) * C + coff);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) body(xv[u], gv[u], m + u * stride);
+        }
+        for (; m < M; m += stride) {
+            h8 xv = *(const h8*)(x + (int64_t)m * C + coff), gv;
+            if (MODE != 0) gv = *(const h8*)(dy + (int64_t)m * C + coff);
+            body(xv, gv, m);
         }
     }
+    if (part == nullptr) return;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { red[threadIdx.x * 16 + j] = s0[j]; red[threadIdx.x * 16 + 8 + j] = s1[j]; }
+    for (int j = 0; j < 8; ++j) { red[threadIdx.x * 17 + j] = s0[j]; red[threadIdx.x * 17 + 8 + j] = s1[j]; }
     __syncthreads();
-    // threads with ry == 0 finish their column: 16 values summed over RY lanes
-    if (ry == 0 && chunk < nch) {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            float s = 0.f;
-            for (int r = 0; r < RY; ++r) s += red[((r << cx_log2) + cx) * 16 + j];
-            const int c = chunk * 8 + (j & 7);
-            atomicAdd(out + (j >> 3) * C + c, s);
-        }
+    // 16 values per chunk column, summed over the RY row lanes; spread over the block's threads
+    for (int t = threadIdx.x; t < CX * 16; t += 256) {
+        const int c = t >> 4, j = t & 15;
+        const int ch = blockIdx.x * CX + c;
+        if (ch >= nch) continue;
+        float s = 0.f;
+        for (int r = 0; r < RY; ++r) s += red[((r << cx_log2) + c) * 17 + j];
+        part[((int64_t)blockIdx.y * 2 + (j >> 3)) * C + ch * 8 + (j & 7)] = s;
     }
+}
+
+// sums[i] = sum_p part[p][i], i < n (n = 2*C)
+__global__ void fold_partials_kernel(const float* __restrict__ part, int nparts, int n, float* __restrict__ sums) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * n + i];
+    sums[i] = s;
 }
 
 // one thread per channel
@@ -100,159 +168,143 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, int C, float 
     }
 }
 
-// y = act(x*scale + shift), flat over [M][C]
-__global__ void bn_apply_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, int64_t nchunks_total, int nch,
-                                const float* __restrict__ scale, const float* __restrict__ shift, int relu) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nchunks_total;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const int ch = (int)(i % nch);
-        const h8 xv = *(const h8*)(x + i * 8);
-        h8 yv;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float f = (float)xv[j] * scale[ch * 8 + j] + shift[ch * 8 + j];
-            if (relu) f = f > 0.f ? f : 0.f;
-            yv[j] = (half_t)f;
-        }
-        *(h8*)(y + i * 8) = yv;
-    }
-}
-
-// dx = gamma*rstd*(g - sum_g/M - xhat*sum_gx/M), g = dy*relu_mask
-__global__ void bn_bwd_apply_kernel(const half_t* __restrict__ x, const half_t* __restrict__ dy,
-                                    half_t* __restrict__ dx, int64_t nchunks_total, int nch, float inv_count,
-                                    const float* __restrict__ mean, const float* __restrict__ rstd,
-                                    const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
-                                    const float* __restrict__ sums /* [2][C] */, int C) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nchunks_total;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const int ch = (int)(i % nch);
-        const h8 xv = *(const h8*)(x + i * 8);
-        const h8 gv = *(const h8*)(dy + i * 8);
-        h8 ov;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int c = ch * 8 + j;
-            const float xh = ((float)xv[j] - mean[c]) * rstd[c];
-            float g = (float)gv[j];
-            if (relu && !(xh * gamma[c] + beta[c] > 0.f)) g = 0.f;
-            const float v = gamma[c] * rstd[c] * (g - sums[c] * inv_count - xh * sums[C + c] * inv_count);
-            ov[j] = (half_t)v;
-        }
-        *(h8*)(dx + i * 8) = ov;
-    }
-}
-
-// activation backward for (bias + act) layers without BN: dpre = dy * act'(y); optional column sums
-// (bias gradient) into colsum[C] via atomics.  act: ReLU (mask y>0) or tanh (1-y^2).
-__global__ __launch_bounds__(256) void act_bwd_kernel(const half_t* __restrict__ y, const half_t* __restrict__ dy,
-                                                      half_t* __restrict__ dpre, int M, int C, int cx_log2, int act,
-                                                      float* __restrict__ colsum) {
-    __shared__ float red[256 * 8];
+// MODE 0: y = act(x*scale + shift).   MODE 1: dx = gamma*rstd*(g - sum_g/M - xhat*sum_gx/M), g = dy*mask
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_stream_kernel(const half_t* __restrict__ x, const half_t* __restrict__ dy,
+                                                        half_t* __restrict__ out, int M, int C, int cx_log2,
+                                                        const float* __restrict__ p0, const float* __restrict__ p1,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, int relu, float inv_count,
+                                                        const float* __restrict__ sums) {
     const int CX = 1 << cx_log2;
     const int RY = 256 >> cx_log2;
     const int cx = threadIdx.x & (CX - 1);
     const int ry = threadIdx.x >> cx_log2;
     const int chunk = blockIdx.x * CX + cx;
-    const int nch = C >> 3;
-    float s0[8];
+    if (chunk >= (C >> 3)) return;
+    // MODE 0: a = scale, b = shift.  MODE 1: xhat = (x - b)*a with a = rstd, b = mean;
+    //         dx = k*(g - c0 - xhat*c1), k = gamma*rstd, c0 = sum_g/M, c1 = sum_gx/M
+    float a[8], b[8], k[8], c0[8], c1[8], ga[8], be[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s0[j] = 0.f;
-    if (chunk < nch) {
-        for (int m = blockIdx.y * RY + ry; m < M; m += gridDim.y * RY) {
-            const int64_t off = (int64_t)m * C + chunk * 8;
-            const h8 yv = *(const h8*)(y + off);
-            const h8 gv = *(const h8*)(dy + off);
-            h8 ov;
+    for (int j = 0; j < 8; ++j) {
+        const int c = chunk * 8 + j;
+        if (MODE == 0) {
+            a[j] = p0[c]; b[j] = p1[c];
+        } else {
+            const float mu = p0[c], rs = p1[c];
+            a[j] = rs; b[j] = mu; ga[j] = gamma[c]; be[j] = beta[c];
+            k[j] = ga[j] * rs; c0[j] = sums[c] * inv_count; c1[j] = sums[C + c] * inv_count;
+        }
+    }
+    const int stride = gridDim.y * RY;
+    const int64_t coff = (int64_t)chunk * 8;
+    auto body = [&](const h8& xv, const h8& gv, int m) {
+        h8 ov;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float yy = (float)yv[j];
+        for (int j = 0; j < 8; ++j) {
+            if (MODE == 0) {
+                float f = (float)xv[j] * a[j] + b[j];
+                if (relu) f = f > 0.f ? f : 0.f;
+                ov[j] = (half_t)f;
+            } else {
+                const float xh = ((float)xv[j] - b[j]) * a[j];
                 float g = (float)gv[j];
-                if (act == ACT_RELU) g = yy > 0.f ? g : 0.f;
-                else if (act == ACT_TANH) g = g * (1.f - yy * yy);
-                ov[j] = (half_t)g;
-                s0[j] += g;
+                if (relu && !(xh * ga[j] + be[j] > 0.f)) g = 0.f;
+                ov[j] = (half_t)(k[j] * (g - c0[j] - xh * c1[j]));
             }
-            *(h8*)(dpre + off) = ov;
         }
+        *(h8*)(out + (int64_t)m * C + coff) = ov;
+    };
+    int m = blockIdx.y * RY + ry;
+    for (; m + 3 * stride < M; m += 4 * stride) {
+        h8 xv[4], gv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            xv[u] = *(const h8*)(x + (int64_t)(m + u * stride) * C + coff);
+            if (MODE == 1) gv[u] = *(const h8*)(dy + (int64_t)(m + u * stride) * C + coff);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) body(xv[u], gv[u], m + u * stride);
     }
-    if (colsum) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) red[threadIdx.x * 8 + j] = s0[j];
-        __syncthreads();
-        if (ry == 0 && chunk < nch) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float s = 0.f;
-                for (int r = 0; r < RY; ++r) s += red[((r << cx_log2) + cx) * 8 + j];
-                atomicAdd(colsum + chunk * 8 + j, s);
-            }
-        }
+    for (; m < M; m += stride) {
+        h8 xv = *(const h8*)(x + (int64_t)m * C + coff), gv;
+        if (MODE == 1) gv = *(const h8*)(dy + (int64_t)m * C + coff);
+        body(xv, gv, m);
     }
 }
 
-static void reduce_geometry(int M, int C, int& cx_log2, dim3& grid) {
-    const int nch = C / 8;
-    cx_log2 = 0;
-    while ((1 << cx_log2) < nch && cx_log2 < 8) ++cx_log2;
-    const int CX = 1 << cx_log2, RY = 256 >> cx_log2;
-    const int gx = (nch + CX - 1) / CX;
-    int gy = (M + RY * 8 - 1) / (RY * 8);            // >= 8 rows per thread
-    const int cap = 2048 / (gx > 0 ? gx : 1);
-    if (gy > cap) gy = cap;
-    if (gy < 1) gy = 1;
-    grid = dim3(gx, gy);
+#define LAUNCH_OK() (hipGetLastError() == hipSuccess ? OK : E_LAUNCH)
+
+int64_t bn_ws_floats(int M, int C) {
+    const RowGeom g = row_geometry(M, C, 1 << 30);
+    return (int64_t)g.gy * 2 * C;
 }
 
-int bn_stats_launch(const half_t* x, int M, int C, float* sums, hipStream_t st) {
-    int cxl; dim3 grid;
-    reduce_geometry(M, C, cxl, grid);
-    hipLaunchKernelGGL((bn_reduce_kernel<0>), grid, dim3(256), 0, st, x, (const half_t*)nullptr, M, C, cxl,
-                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0,
-                       sums);
-    return hipGetLastError() == hipSuccess ? OK : E_LAUNCH;
+template <int MODE>
+static int reduce_launch(const half_t* x, const half_t* dy, half_t* dout, int M, int C, const float* mean,
+                         const float* rstd, const float* gamma, const float* beta, int flag, float* sums, float* ws,
+                         int64_t ws_floats, hipStream_t st) {
+    int max_gy = 1 << 30;
+    if (sums) {
+        if (!ws || ws_floats < 2 * (int64_t)C) return E_WORKSPACE;
+        max_gy = (int)(ws_floats / (2 * (int64_t)C));
+    }
+    const RowGeom g = row_geometry(M, C, max_gy);
+    hipLaunchKernelGGL((bn_reduce_kernel<MODE>), dim3(g.gx, g.gy), dim3(256), 0, st, x, dy, dout, M, C, g.cx_log2,
+                       mean, rstd, gamma, beta, flag, sums ? ws : (float*)nullptr);
+    if (sums) {
+        const int n = 2 * C;
+        hipLaunchKernelGGL(fold_partials_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ws, g.gy, n, sums);
+    }
+    return LAUNCH_OK();
+}
+
+int bn_stats_launch(const half_t* x, int M, int C, float* sums, float* ws, int64_t ws_floats, hipStream_t st) {
+    return reduce_launch<0>(x, nullptr, nullptr, M, C, nullptr, nullptr, nullptr, nullptr, 0, sums, ws, ws_floats,
+                            st);
 }
 int bn_bwd_reduce_launch(const half_t* x, const half_t* dy, int M, int C, const float* mean, const float* rstd,
-                         const float* gamma, const float* beta, int relu, float* sums, hipStream_t st) {
-    int cxl; dim3 grid;
-    reduce_geometry(M, C, cxl, grid);
-    hipLaunchKernelGGL((bn_reduce_kernel<1>), grid, dim3(256), 0, st, x, dy, M, C, cxl, mean, rstd, gamma, beta, relu,
-                       sums);
-    return hipGetLastError() == hipSuccess ? OK : E_LAUNCH;
+                         const float* gamma, const float* beta, int relu, float* sums, float* ws, int64_t ws_floats,
+                         hipStream_t st) {
+    return reduce_launch<1>(x, dy, nullptr, M, C, mean, rstd, gamma, beta, relu, sums, ws, ws_floats, st);
+}
+// colsum may be null (then no reduction is performed); colsum gets [2][C] (second half unused)
+int act_bwd_launch(const half_t* y, const half_t* dy, half_t* dpre, int M, int C, int act, float* colsum, float* ws,
+                   int64_t ws_floats, hipStream_t st) {
+    return reduce_launch<2>(y, dy, dpre, M, C, nullptr, nullptr, nullptr, nullptr, act, colsum, ws, ws_floats, st);
 }
 int bn_finalize_launch(const float* sums, int C, float count, const float* gamma, const float* beta, float eps,
                        float momentum, int updates, float* rm, float* rv, float* mean, float* rstd, float* scale,
                        float* shift, hipStream_t st) {
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, C, count, gamma, beta, eps,
                        momentum, updates, rm, rv, mean, rstd, scale, shift);
-    return hipGetLastError() == hipSuccess ? OK : E_LAUNCH;
+    return LAUNCH_OK();
 }
-static inline int nblk(int64_t total) {
-    int64_t b = (total + 255) / 256;
-    if (b > 8192) b = 8192;
-    if (b < 1) b = 1;
-    return (int)b;
+static RowGeom stream_geometry(int M, int C) {
+    RowGeom g = row_geometry(M, C, 1 << 30);
+    // streaming kernels have no per-block epilogue: allow more blocks for short row loops
+    const int RY = 256 >> g.cx_log2;
+    int gy = (M + RY * 8 - 1) / (RY * 8);
+    int cap = 2048 / g.gx;
+    if (cap < 1) cap = 1;
+    g.gy = gy > cap ? cap : (gy < 1 ? 1 : gy);
+    return g;
 }
 int bn_apply_launch(const half_t* x, half_t* y, int M, int C, const float* scale, const float* shift, int relu,
                     hipStream_t st) {
-    const int64_t n = (int64_t)M * (C / 8);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(nblk(n)), dim3(256), 0, st, x, y, n, C / 8, scale, shift, relu);
-    return hipGetLastError() == hipSuccess ? OK : E_LAUNCH;
+    const RowGeom g = stream_geometry(M, C);
+    hipLaunchKernelGGL((bn_stream_kernel<0>), dim3(g.gx, g.gy), dim3(256), 0, st, x, (const half_t*)nullptr, y, M, C,
+                       g.cx_log2, scale, shift, (const float*)nullptr, (const float*)nullptr, relu, 0.f,
+                       (const float*)nullptr);
+    return LAUNCH_OK();
 }
 int bn_bwd_apply_launch(const half_t* x, const half_t* dy, half_t* dx, int M, int C, float count, const float* mean,
                         const float* rstd, const float* gamma, const float* beta, int relu, const float* sums,
                         hipStream_t st) {
-    const int64_t n = (int64_t)M * (C / 8);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk(n)), dim3(256), 0, st, x, dy, dx, n, C / 8, 1.f / count, mean,
-                       rstd, gamma, beta, relu, sums, C);
-    return hipGetLastError() == hipSuccess ? OK : E_LAUNCH;
-}
-int act_bwd_launch(const half_t* y, const half_t* dy, half_t* dpre, int M, int C, int act, float* colsum,
-                   hipStream_t st) {
-    int cxl; dim3 grid;
-    reduce_geometry(M, C, cxl, grid);
-    hipLaunchKernelGGL(act_bwd_kernel, grid, dim3(256), 0, st, y, dy, dpre, M, C, cxl, act, colsum);
-    return hipGetLastError() == hipSuccess ? OK : E_LAUNCH;
+    const RowGeom g = stream_geometry(M, C);
+    hipLaunchKernelGGL((bn_stream_kernel<1>), dim3(g.gx, g.gy), dim3(256), 0, st, x, dy, dx, M, C, g.cx_log2, mean,
+                       rstd, gamma, beta, relu, 1.f / count, sums);
+    return LAUNCH_OK();
 }
 
 }  // namespace fmri

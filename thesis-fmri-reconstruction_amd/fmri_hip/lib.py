@@ -29,25 +29,29 @@ _SIGS = {
     "fmri_rows_f16_to_f32": [_p, _p, _i, _i, _i, _f, _p],
     "fmri_reduce_slabs": [_p, _i, _l, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p],
     "fmri_permute_chw": [_p, _p, _i, _i, _i, _f, _i, _p],
-    "fmri_bn_stats": [_p, _i, _i, _p, _p],
+    "fmri_bn_stats": [_p, _i, _i, _p, _p, _l, _p],
     "fmri_bn_finalize": [_p, _i, _f, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p, _p, _p],
     "fmri_bn_apply": [_p, _p, _i, _i, _p, _p, _i, _p],
-    "fmri_bn_bwd_reduce": [_p, _p, _i, _i, _p, _p, _p, _p, _i, _p, _p],
+    "fmri_bn_bwd_reduce": [_p, _p, _i, _i, _p, _p, _p, _p, _i, _p, _p, _l, _p],
     "fmri_bn_bwd_apply": [_p, _p, _p, _i, _i, _f, _p, _p, _p, _p, _i, _p, _p],
-    "fmri_act_bwd": [_p, _p, _p, _i, _i, _i, _p, _p],
+    "fmri_act_bwd": [_p, _p, _p, _i, _i, _i, _p, _p, _l, _p],
     "fmri_latent_fwd": [_p, _p, _i, _i, _i, _p, _p, _p, _i, _p],
-    "fmri_latent_bwd": [_p, _p, _p, _i, _f, _f, _i, _i, _f, _p, _p, _i, _p],
-    "fmri_feat_mse": [_p, _i, _i, _p, _p, _p, _f, _p],
+    "fmri_latent_bwd": [_p, _p, _p, _i, _f, _f, _p, _i, _i, _f, _p, _p, _i, _p],
+    "fmri_feat_mse": [_p, _i, _i, _p, _p, _p],
+    "fmri_feat_mse_bwd": [_p, _i, _i, _p, _f, _p, _p],
     "fmri_pixel_sq": [_p, _p, _l, _i, _i, _p, _p, _f, _p],
-    "fmri_gan_head": [_p, _i, _i, _p, _p, _p, _i, _f, _p],
+    "fmri_gan_head": [_p, _i, _i, _p, _p, _p],
+    "fmri_gan_head_bwd": [_p, _i, _i, _p, _i, _f, _p, _p],
     "fmri_wae_logloss": [_p, _i, _i, _i, _f, _p, _p, _p, _i, _f, _p],
-    "fmri_compose_gate": [_p, _p, _f, _f, _f, _f, _i, _i, _i, _p],
-    "fmri_axpby_f16": [_p, _p, _p, _l, _f, _f, _p],
-    "fmri_rmsprop": [_p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _p],
-    "fmri_adam": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _f, _f, _f, _p, _p],
+    "fmri_compose_gate": [_p, _p, _f, _f, _f, _f, _f, _i, _i, _i, _p],
+    "fmri_axpby_f16": [_p, _p, _p, _l, _f, _f, _p, _p],
+    "fmri_sumsq": [_p, _l, _p, _p],
+    "fmri_renorm": [_p, _p, _l, _f, _p, _f, _p, _p, _p],
+    "fmri_rmsprop": [_p, _p, _p, _l, _f, _f, _f, _f, _p, _f, _p, _p],
+    "fmri_adam": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _f, _f, _p, _f, _p, _p],
 }
 
-EXPORTS = sorted(list(_SIGS) + ["fmri_version", "fmri_last_error_string", "fmri_test_fastdiv"])
+EXPORTS = sorted(list(_SIGS) + ["fmri_version", "fmri_last_error_string", "fmri_test_fastdiv", "fmri_bn_ws_floats"])
 
 _lib = None
 
@@ -71,6 +75,8 @@ def load():
     lib.fmri_last_error_string.argtypes = [_i]
     lib.fmri_test_fastdiv.restype = C.c_uint32
     lib.fmri_test_fastdiv.argtypes = [C.c_uint32, C.c_uint32]
+    lib.fmri_bn_ws_floats.restype = _l
+    lib.fmri_bn_ws_floats.argtypes = [_i, _i]
     _lib = lib
     return lib
 

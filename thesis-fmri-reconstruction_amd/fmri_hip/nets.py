@@ -219,7 +219,7 @@ class DecoderNet:
         for e, en in enumerate(entries):
             colsum = None
             if en["train"]:
-                colsum = torch.zeros(pad8(self.c3.cout), dtype=torch.float32, device=cot.device)
+                colsum = torch.empty(2 * pad8(self.c3.cout), dtype=torch.float32, device=cot.device)
             act_backward(rows(y, en["g"]), rows(cot, e), ACT_TANH, colsum, out=rows(dpre, e))
             if en["train"]:
                 self.c3.bg.add_(colsum[:self.c3.cout], alpha=1.0 / en["scale"])
@@ -343,7 +343,7 @@ class DiscriminatorNet:
         for si, s in enumerate(streams):
             colsum = None
             if s["train"]:
-                colsum = torch.zeros(self.c0.coutp, dtype=torch.float32, device=d.device)
+                colsum = torch.empty(2 * self.c0.coutp, dtype=torch.float32, device=d.device)
             act_backward(a0, rows(d, si), ACT_RELU, colsum, out=rows(dpre, si))
             if s["train"]:
                 self.c0.bg.add_(colsum[:self.c0.cout], alpha=1.0 / s["scale"])

@@ -125,10 +125,23 @@ def _choose_splits(blocks: int, ksteps: int) -> int:
     return (ksteps + per - 1) // per
 
 
+# bench.py sets PROFILE to a list to time every launch of the dominant kernel instantiation
+# (igemm_kernel<128,2,2,false>) with HIP events on the launch stream: entries (start, end, algorithmic flops)
+PROFILE = None
+
+
 def run_igemm(x, pw: PackedWeight, out, bias, N, Hi, Wi, Ci, Ho, Wo, CoStore, Co, k, stride, pad, mode, act, out_f32,
-              splits, slab_stride, tile):
-    lib.call("fmri_igemm", _P(x), _P(pw.get()), _P(out), _P(bias), _P(zero_page(x.device)), N, Hi, Wi, Ci, Ho, Wo,
+              splits, slab_stride, tile, flops=0.0):
+    w = pw.get()
+    prof = PROFILE is not None and tile == 128 and not out_f32
+    if prof:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    lib.call("fmri_igemm", _P(x), _P(w), _P(out), _P(bias), _P(zero_page(x.device)), N, Hi, Wi, Ci, Ho, Wo,
              CoStore, Co, k, stride, pad, mode, act, 1 if out_f32 else 0, splits, slab_stride, tile)
+    if prof:
+        e1.record()
+        PROFILE.append((e0, e1, flops))
 
 
 def run_wgrad(P, Q, N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad):
@@ -207,8 +220,14 @@ class ConvLayer:
             out = torch.empty(N, Ho, Wo, self.coutp, dtype=torch.float16, device=x.device)
         mode = MODE_CONV if self.kind == "conv" else MODE_TCONV2
         run_igemm(x, self.pw_f, out, self.b, N, Hi, Wi, self.cinp, Ho, Wo, self.coutp, self.cout, self.k,
-                  self.stride, self.pad, mode, act, False, 1, 0, self.t_out)
+                  self.stride, self.pad, mode, act, False, 1, 0, self.t_out, self._flops(N, Hi, Wi, Ho, Wo))
         return out
+
+    def _flops(self, N, Hi, Wi, Ho, Wo):
+        """Algorithmic FLOPs of one pass (fwd == dgrad == wgrad): 2 * pixels * cin * cout * k^2, pixels = conv
+        output pixels (conv) or deconv input pixels (deconv)."""
+        pix = Ho * Wo if self.kind == "conv" else Hi * Wi
+        return 2.0 * N * pix * self.cin * self.cout * self.k * self.k
 
     def dgrad(self, dy: torch.Tensor, hi: int, wi: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Cotangent w.r.t. the layer input (same scale as dy)."""
@@ -216,13 +235,14 @@ class ConvLayer:
         assert C == self.coutp and dy.is_contiguous()
         if out is None:
             out = torch.empty(N, hi, wi, self.cinp, dtype=torch.float16, device=dy.device)
+        fl = self._flops(N, hi, wi, Ho, Wo)
         if self.kind == "conv":
             mode = MODE_TCONV2 if self.stride == 2 else MODE_CONV_FLIP
             run_igemm(dy, self.pw_d, out, None, N, Ho, Wo, self.coutp, hi, wi, self.cinp, self.cin, self.k,
-                      self.stride, self.pad, mode, ACT_NONE, False, 1, 0, self.t_in)
+                      self.stride, self.pad, mode, ACT_NONE, False, 1, 0, self.t_in, fl)
         else:
             run_igemm(dy, self.pw_d, out, None, N, Ho, Wo, self.coutp, hi, wi, self.cinp, self.cin, self.k, 2,
-                      self.pad, MODE_CONV, ACT_NONE, False, 1, 0, self.t_in)
+                      self.pad, MODE_CONV, ACT_NONE, False, 1, 0, self.t_in, fl)
         return out
 
     def wgrad(self, x: torch.Tensor, dy: torch.Tensor, scale: float):
@@ -288,7 +308,8 @@ class DenseLayer:
         dev = x.device
         if splits == 1 and not want32:
             out = torch.empty(M, CoStore, dtype=torch.float16, device=dev)
-            run_igemm(x, pw, out, bias, M, 1, 1, Ci, 1, 1, CoStore, Co, 1, 1, 0, MODE_CONV, act, False, 1, 0, tile)
+            run_igemm(x, pw, out, bias, M, 1, 1, Ci, 1, 1, CoStore, Co, 1, 1, 0, MODE_CONV, act, False, 1, 0, tile,
+                      2.0 * M * Ci * Co)
             return out, None
         slabs = torch.empty(splits, M, CoStore, dtype=torch.float32, device=dev)
         run_igemm(x, pw, slabs, None, M, 1, 1, Ci, 1, 1, CoStore, Co, 1, 1, 0, MODE_CONV, ACT_NONE, True, splits,
@@ -381,8 +402,9 @@ class BatchNorm:
         M = x2.shape[0]
         dev = raw.device
         gamma, beta, rm, rv = self._params()
-        sums = torch.zeros(2, C, dtype=torch.float32, device=dev)
-        lib.call("fmri_bn_stats", _P(x2), M, C, _P(sums))
+        sums = torch.empty(2, C, dtype=torch.float32, device=dev)
+        ws = _reduce_ws(M, C, dev)
+        lib.call("fmri_bn_stats", _P(x2), M, C, _P(sums), _P(ws), ws.numel())
         count = float(M)
         if self.reducer is not None:
             count *= self.reducer(sums)
@@ -411,9 +433,10 @@ class BatchNorm:
         g2 = dy.reshape(-1, C)
         M = x2.shape[0]
         gamma, beta, _, _ = self._params()
-        sums = torch.zeros(2, C, dtype=torch.float32, device=raw.device)
+        sums = torch.empty(2, C, dtype=torch.float32, device=raw.device)
+        ws = _reduce_ws(M, C, raw.device)
         lib.call("fmri_bn_bwd_reduce", _P(x2), _P(g2), M, C, _P(sv.mean), _P(sv.rstd), _P(gamma), _P(beta),
-                 1 if relu else 0, _P(sums))
+                 1 if relu else 0, _P(sums), _P(ws), ws.numel())
         if param_scale is not None:       # local sums: the gradient all-reduce (SUM) adds the other ranks
             self.accumulate_param_grads(sums, param_scale)
         if self.reducer is not None:
@@ -466,18 +489,31 @@ def rows_to_f16(x: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
     return out
 
 
+def _reduce_ws(M: int, C: int, device) -> torch.Tensor:
+    """Per-block partial-sum workspace of the BN / column-sum reductions."""
+    return torch.empty(lib.load().fmri_bn_ws_floats(M, C), dtype=torch.float32, device=device)
+
+
 def act_backward(y: torch.Tensor, dy: torch.Tensor, act: int, colsum: Optional[torch.Tensor] = None,
                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dpre = dy * act'(y).  ``colsum`` (fp32, >= 2*C floats): its first C entries receive sum_rows(dpre)."""
     C = y.shape[-1]
     M = y.numel() // C
     if out is None:
         out = torch.empty_like(dy)
-    lib.call("fmri_act_bwd", _P(y), _P(dy), _P(out), M, C, act, _P(colsum))
+    if colsum is not None:
+        assert colsum.numel() >= 2 * C
+        ws = _reduce_ws(M, C, y.device)
+        lib.call("fmri_act_bwd", _P(y), _P(dy), _P(out), M, C, act, _P(colsum), _P(ws), ws.numel())
+    else:
+        lib.call("fmri_act_bwd", _P(y), _P(dy), _P(out), M, C, act, None, None, 0)
     return out
 
 
-def axpby(x: torch.Tensor, y: Optional[torch.Tensor], a: float, b: float, out: Optional[torch.Tensor] = None):
+def axpby(x: torch.Tensor, y: Optional[torch.Tensor], a: float, b: float, out: Optional[torch.Tensor] = None,
+          a_dev: Optional[torch.Tensor] = None):
+    """out = a * (*a_dev) * x + b * y  (fp16 tensors; a_dev: optional device fp32 scalar)."""
     if out is None:
         out = torch.empty_like(x)
-    lib.call("fmri_axpby_f16", _P(x), _P(y), _P(out), x.numel(), float(a), float(b))
+    lib.call("fmri_axpby_f16", _P(x), _P(y), _P(out), x.numel(), float(a), float(b), _P(a_dev))
     return out

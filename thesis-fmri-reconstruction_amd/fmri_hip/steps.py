@@ -293,3 +293,154 @@ class Stage1Step(_GanStepBase):
             for k, v in n.group.grads.items():
                 out[pre + k] = v / f
         return out
+
+
+class CognitiveStep(_GanStepBase):
+    """Stage-II / Stage-III steps of the Dual-VAE/GAN (fMRI -> image), `VaeGanCognitive` wiring
+    (models/vae_gan.py:352-395) + the loop bodies train/train_vgan_stage2.py:321-407 (stage=2: decoder
+    frozen, teacher distillation, encoder + discriminator trained, no gate, grads clamped to +-1) and
+    train/train_vgan_stage3.py:324-411 (stage=3: cognitive encoder frozen, decoder + discriminator trained,
+    gate on, clamp +-1)."""
+
+    def __init__(self, cfg: ArchConfig, n_voxels: int, device, stage: int, hp: GanHyper = GanHyper(),
+                 scales: Scales = Scales(), distributed: bool = False, sync_bn: bool = True):
+        assert stage in (2, 3)
+        self.cfg, self.stage, self.n_voxels = cfg, stage, n_voxels
+        self.cog = CognitiveEncoderNet(cfg, n_voxels, device)
+        self.dec = DecoderNet(cfg, device, cfg.encoder_channels[2])
+        self.dis = DiscriminatorNet(cfg, device)
+        self.teacher_enc = EncoderNet(cfg, device) if stage == 2 else None
+        nets = [self.cog, self.dec, self.dis] + ([self.teacher_enc] if stage == 2 else [])
+        self._init_common(device, hp, scales, distributed, sync_bn, nets)
+        self.opt_enc = _Optim(self.cog.group, "rmsprop", hp.lr, hp.alpha, hp.eps)
+        self.opt_dec = _Optim(self.dec.group, "rmsprop", hp.lr, hp.alpha, hp.eps)
+        self.opt_dis = _Optim(self.dis.group, "rmsprop", hp.lr, hp.alpha, hp.eps)
+
+    def load_recipe(self, seed: int, perturb: bool = False):
+        """Teacher VaeGan weights from seed, cognitive encoder from seed+100 (the golden-fixture recipe)."""
+        rs = np.random.RandomState(seed)
+        enc_tmp = self.teacher_enc if self.teacher_enc is not None else EncoderNet(self.cfg, self.device)
+        for n in (enc_tmp, self.dec, self.dis):
+            n.group.load_recipe(rs, perturb)
+        self.cog.group.load_recipe(np.random.RandomState(seed + 100), perturb)
+
+    def state_dict(self):
+        sd = {}
+        sd.update(self.cog.group.state_dict("encoder."))
+        sd.update(self.dec.group.state_dict("decoder."))
+        sd.update(self.dis.group.state_dict("discriminator."))
+        if self.teacher_enc is not None:
+            sd.update(self.teacher_enc.group.state_dict("teacher_net.encoder."))
+            sd.update(self.dec.group.state_dict("teacher_net.decoder."))
+            sd.update(self.dis.group.state_dict("teacher_net.discriminator."))
+        return sd
+
+    def forward(self, fmri: torch.Tensor, image: torch.Tensor, eps: torch.Tensor, z_p: torch.Tensor,
+                eps_teacher: Optional[torch.Tensor] = None):
+        require_gpu(fmri)
+        cfg = self.cfg
+        B, _, H, W = image.shape
+        Z, zp = cfg.latent_dim, pad8(cfg.latent_dim)
+        dev = image.device
+        self.scal.zero_()
+        disc_in = torch.empty(3 * B, H, W, 8, dtype=torch.float16, device=dev)
+        fmri16 = rows_to_f16(fmri)
+        head32, cctx = self.cog.forward(fmri16)
+        eps = eps.contiguous().float()
+        if self.stage == 2:
+            # decoder groups in disc_in row order: 0 = teacher reconstruction ("real"), 1 = x_tilde, 2 = x_p
+            z16 = torch.empty(3 * B, zp, dtype=torch.float16, device=dev)
+            img16 = images_to_nhwc(image)
+            head_t, _ = self.teacher_enc.forward(img16)
+            lib.call("fmri_latent_fwd", _P(head_t), _P(eps_teacher.contiguous().float()), B, Z, zp, _P(z16[:B]), None,
+                     None, 1)
+            lib.call("fmri_latent_fwd", _P(head32), _P(eps), B, Z, zp, _P(z16[B:2 * B]), None,
+                     _P(self._slot(S_KL)), 1)
+            lib.call("fmri_rows_f32_to_f16", _P(z_p.contiguous().float()), _P(z16[2 * B:]), B, Z, zp, 1.0)
+            # reference call order of the decoder: x_tilde, teacher reconstruction, x_p (vae_gan.py:365,377,390)
+            _, dctx = self.dec.forward(z16, 3, out=disc_in, stat_order=(1, 0, 2))
+            g_tilde, g_p = 1, 2
+        else:
+            z16 = torch.empty(2 * B, zp, dtype=torch.float16, device=dev)
+            images_to_nhwc(image, out=disc_in[:B])
+            lib.call("fmri_latent_fwd", _P(head32), _P(eps), B, Z, zp, _P(z16[:B]), None, _P(self._slot(S_KL)), 1)
+            lib.call("fmri_rows_f32_to_f16", _P(z_p.contiguous().float()), _P(z16[B:]), B, Z, zp, 1.0)
+            _, dctx = self.dec.forward(z16, 2, out=disc_in[B:])
+            g_tilde, g_p = 0, 1
+        feat, logit32, sctx = self.dis.forward(disc_in)
+        prob, F = self._gan_losses(feat, logit32, B, disc_in[:B], disc_in[B:2 * B], H, W)
+        self.fw = dict(B=B, H=H, W=W, F=F, disc_in=disc_in, head32=head32, eps=eps, cctx=cctx, dctx=dctx, sctx=sctx,
+                       feat=feat, logit32=logit32, prob=prob, g_tilde=g_tilde, g_p=g_p)
+        return self.fw
+
+    def gate(self, B_global: int):
+        if self.stage == 2:
+            self._gate(B_global, self.fw["F"], False, 1, 0)          # train_dis = True, train_dec = False
+        else:
+            self._gate(B_global, self.fw["F"], True)
+
+    def backward(self):
+        fw, sc, hp, cfg = self.fw, self.sc, self.hp, self.cfg
+        B, H, W, Z = fw["B"], fw["H"], fw["W"], cfg.latent_dim
+        dev = fw["disc_in"].device
+        dlogit16, dfeat16 = self._start_cotangents(fw["feat"], fw["logit32"], B)
+        if self.stage == 2:
+            self.cog.group.zero_grad()
+            self.dis.group.zero_grad()
+            _, dimg_b = self.dis.backward(fw["sctx"], dlogit16, sc.a, dfeat16, sc.b, True, slice(B, 2 * B),
+                                          img_streams=(False, True))
+            entries = [dict(g=fw["g_tilde"], scale=sc.b, train=False, need_dz=True)]
+            dz = self.dec.backward(fw["dctx"], dimg_b, entries)[0]
+            dhead32 = torch.empty(B, 2 * Z, dtype=torch.float32, device=dev)
+            lib.call("fmri_latent_bwd", _P(fw["head32"]), _P(fw["eps"]), _P(dz), Z, 1.0, 1.0, _P(self._slot(S_NB)), B,
+                     Z, 1.0, None, _P(dhead32), 1)
+            dhead16 = self._renorm(dhead32, sc.enc, self._slot(S_NB), B * self.dd.world)
+            self.cog.backward(fw["cctx"], dhead16, sc.enc)
+            for n in (self.dis, self.cog):
+                self.dd.all_reduce(n.group.grad)
+        else:
+            self.dec.group.zero_grad()
+            self.dis.group.zero_grad()
+            dimg_a, dimg_b = self.dis.backward(fw["sctx"], dlogit16, sc.a, dfeat16, sc.b, True, slice(B, 3 * B))
+            lam = hp.lambda_mse
+            cot = axpby(dimg_b, dimg_a, sc.dec * lam / sc.b, -sc.dec * (1.0 - lam) / sc.a, a_dev=self._slot(S_RATIO))
+            entries = [dict(g=0, scale=sc.dec, train=True), dict(g=1, scale=sc.dec, train=True)]
+            self.dec.backward(fw["dctx"], cot, entries)
+            for n in (self.dis, self.dec):
+                self.dd.all_reduce(n.group.grad)
+
+    def apply(self):
+        if self.stage == 2:
+            self.opt_enc.step(None, clamp=1.0, gdev=self._slot(S_NE))
+            self.opt_dis.step(self.flags[0:1], clamp=1.0, gdev=self._slot(S_NA))
+        else:
+            self.opt_dec.step(self.flags[1:2], clamp=1.0, gdev=self._slot(S_NA))
+            self.opt_dis.step(self.flags[0:1], clamp=1.0, gdev=self._slot(S_NA))
+
+    def step(self, fmri, image, eps, z_p, eps_teacher=None):
+        fw = self.forward(fmri, image, eps, z_p, eps_teacher)
+        self.gate(fw["B"] * self.dd.world)
+        self.backward()
+        self.apply()
+        return self.scal
+
+    def outputs(self):
+        fw, cfg = self.fw, self.cfg
+        B, Z = fw["B"], cfg.latent_dim
+        d = fw["disc_in"]
+        feat = fw["feat"]
+        n3, h, w, c = feat.shape
+        return dict(gt_x=nhwc_to_images(d[:B], 3), x_tilde=nhwc_to_images(d[B:2 * B], 3),
+                    x_p=nhwc_to_images(d[2 * B:], 3), disc_class=fw["prob"].reshape(3 * B, 1).clone(),
+                    disc_layer=nhwc_to_images(feat, c).reshape(n3, -1),
+                    mus=fw["head32"][:, :Z].clone(), log_variances=fw["head32"][:, Z:].clone())
+
+    def named_grads(self):
+        s = self.scal.tolist()
+        groups = ((("encoder.", self.cog, s[S_NE]), ("discriminator.", self.dis, s[S_NA])) if self.stage == 2 else
+                  (("decoder.", self.dec, s[S_NA]), ("discriminator.", self.dis, s[S_NA])))
+        out = {}
+        for pre, n, f in groups:
+            for k, v in n.group.grads.items():
+                out[pre + k] = v / f
+        return out

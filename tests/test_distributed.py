@@ -1,0 +1,185 @@
+"""Data-parallel path (one process per GPU, SUM all-reduce + SyncBN), world size 2.
+
+CPU / gloo:
+  * the engine's distributed glue (`fmri_hip.steps._Dist`) reduces with SUM and reports the world size;
+  * the SyncBN scheme the HIP BatchNorm uses (all-reduce [sum x | sum x^2] forward and
+    [sum g | sum g*xhat] backward, parameter gradients from LOCAL sums, then one SUM all-reduce of the
+    flat gradient buffer) is numerically identical to a single process on the global batch, for losses
+    that are batch SUMS (train_vgan_stage1.py:369-372).
+GPU (2 ranks sharing the one GPU of the test box, gloo backend on device tensors):
+  * the real fused Stage-I step with distributed=True on two half batches reproduces the single-process
+    step on the full batch.
+"""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn.functional as F
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _init(rank, world, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    for p in (ROOT, os.path.join(ROOT, "thesis-fmri-reconstruction_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+
+
+class _SyncBNRelu(torch.autograd.Function):
+    """Python restatement of the engine's SyncBN (fmri_hip.ops.BatchNorm with a reducer + csrc/norm.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, reducer):
+        M, C = x.shape
+        sums = torch.stack([x.sum(0), (x * x).sum(0)])
+        count = float(M) * reducer(sums)
+        mean = sums[0] / count
+        var = (sums[1] / count - mean * mean).clamp_min(0)
+        rstd = torch.rsqrt(var + 1e-5)
+        xh = (x - mean) * rstd
+        pre = xh * gamma + beta
+        ctx.save_for_backward(xh, pre, gamma, rstd)
+        ctx.count, ctx.reducer = count, reducer
+        return pre.clamp_min(0)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xh, pre, gamma, rstd = ctx.saved_tensors
+        g = dy * (pre > 0)
+        sums = torch.stack([g.sum(0), (g * xh).sum(0)])
+        dgamma, dbeta = sums[1].clone(), sums[0].clone()       # LOCAL sums -> param grads
+        ctx.reducer(sums)                                      # global sums -> dx
+        dx = gamma * rstd * (g - sums[0] / ctx.count - xh * sums[1] / ctx.count)
+        return dx, dgamma, dbeta, None
+
+
+def _toy_loss(x, w1, gamma, beta, w2, reducer):
+    h = _SyncBNRelu.apply(F.linear(x, w1), gamma, beta, reducer)
+    return (F.linear(h, w2) ** 2).sum()            # a batch SUM, like every reference loss
+
+
+def _worker_cpu(rank, world, port, q):
+    _init(rank, world, port)
+    from fmri_hip.steps import _Dist
+    d = _Dist(True, True)
+    assert d.on and d.world == world
+    t = torch.full((3,), float(rank + 1))
+    d.all_reduce(t)
+    assert torch.equal(t, torch.full((3,), 3.0))
+    red = d.bn_reducer()
+    s = torch.tensor([[1.0, 2.0], [3.0, 4.0]]) * (rank + 1)
+    assert red(s) == world and torch.equal(s, torch.tensor([[3.0, 6.0], [9.0, 12.0]]))
+    # SyncBN + SUM-of-gradients == single process on the global batch
+    g = torch.Generator().manual_seed(0)
+    X = torch.randn(8, 6, generator=g, dtype=torch.float64)
+    W1 = torch.randn(5, 6, generator=g, dtype=torch.float64)
+    GA, BE = torch.rand(5, generator=g, dtype=torch.float64) + 0.5, torch.randn(5, generator=g, dtype=torch.float64)
+    W2 = torch.randn(3, 5, generator=g, dtype=torch.float64)
+    ps = [p.clone().requires_grad_(True) for p in (W1, GA, BE, W2)]
+    loss = _toy_loss(X[rank * 4:(rank + 1) * 4], ps[0], ps[1], ps[2], ps[3], red)
+    loss.backward()
+    flat = torch.cat([p.grad.reshape(-1) for p in ps])
+    lsum = loss.detach().clone().reshape(1)
+    d.all_reduce(flat)
+    d.all_reduce(lsum)
+    pr = [p.clone().requires_grad_(True) for p in (W1, GA, BE, W2)]
+    ref = _toy_loss(X, pr[0], pr[1], pr[2], pr[3], lambda s_: 1)
+    ref.backward()
+    flat_ref = torch.cat([p.grad.reshape(-1) for p in pr])
+    ok = torch.allclose(flat, flat_ref, rtol=1e-10, atol=1e-12) and torch.allclose(lsum, ref.detach().reshape(1))
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_syncbn_sum_allreduce_equals_global_batch_cpu_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_cpu, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = sorted(q.get() for _ in range(2))
+    assert res == [(0, True), (1, True)]
+
+
+def _worker_gpu(rank, world, port, q):
+    _init(rank, world, port)
+    from oracle import vaegan_oracle as O
+    from fmri_hip.params import ArchConfig
+    from fmri_hip.steps import Stage1Step
+    torch.cuda.set_device(0)
+    B = 4
+    cfg = O.ArchCfg.px64()
+    data = O.synth_batch(2 * B, cfg, seed=1234, steps=1)
+    sl = slice(rank * B, (rank + 1) * B)
+    st = Stage1Step(ArchConfig.px64(), "cuda:0", distributed=True, sync_bn=True)
+    st.load_recipe(0, True)
+    st.forward(data["x"][sl].cuda(), data["noise"][0, 0][sl].cuda(), data["noise"][0, 1][sl].cuda())
+    st.gate(2 * B)
+    st.backward()
+    grads = {k: v.cpu() for k, v in st.named_grads().items()}
+    st.apply()
+    torch.cuda.synchronize()
+    q.put((rank, st.logs(), {k: float(v.norm()) for k, v in grads.items()},
+           {k: float(v.float().norm()) for k, v in st.state_dict().items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_rank_stage1_step_equals_single_process_global_batch():
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_gpu, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get() for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    # single process, global batch 8
+    from oracle import vaegan_oracle as O
+    from fmri_hip.params import ArchConfig
+    from fmri_hip.steps import Stage1Step
+    B = 8
+    cfg = O.ArchCfg.px64()
+    data = O.synth_batch(B, cfg, seed=1234, steps=1)
+    st = Stage1Step(ArchConfig.px64(), "cuda:0")
+    st.load_recipe(0, True)
+    st.forward(data["x"].cuda(), data["noise"][0, 0].cuda(), data["noise"][0, 1].cuda())
+    st.gate(B)
+    st.backward()
+    g1 = {k: float(v.norm()) for k, v in st.named_grads().items()}
+    st.apply()
+    logs1 = st.logs()
+    sd1 = {k: float(v.float().norm()) for k, v in st.state_dict().items()}
+    for rank, logs, gn, sdn in res:
+        for k in ("loss_encoder", "loss_decoder", "loss_discriminator", "kl", "mse", "nle"):
+            assert abs(logs[k] - logs1[k]) < 2e-4 * abs(logs1[k]), (rank, k, logs[k], logs1[k])
+        assert logs["train_dis"] == logs1["train_dis"] and logs["train_dec"] == logs1["train_dec"]
+        for k, v in g1.items():
+            assert abs(gn[k] - v) < 0.05 * v + 1e-6, (rank, k, gn[k], v)
+        for k, v in sd1.items():
+            assert abs(sdn[k] - v) < 2e-3 * v + 1e-6, (rank, k, sdn[k], v)
+    # both ranks hold identical parameters after the step
+    for k in res[0][3]:
+        assert abs(res[0][3][k] - res[1][3][k]) <= 1e-6 * abs(res[0][3][k]) + 1e-9, k

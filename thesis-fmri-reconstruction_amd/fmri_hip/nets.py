@@ -277,28 +277,34 @@ class DiscriminatorNet:
     def all_bns(self):
         return self.bns + [self.fc_bn]
 
-    def forward(self, x16: torch.Tensor, train_stats: bool = True):
+    def forward(self, x16: torch.Tensor, train_stats: bool = True, conv_updates: int = 2, fc_updates: int = 1,
+                head: bool = True):
         """x16 [3B,H,W,8] = cat(orig, predicted, sampled).  One pass produces both reference outputs:
         the raw conv-3 features ('REC', models/vae_gan.py:166-173) and the class logits ('GAN', :176-183).
-        Conv BN layers receive the reference's two running-stat updates per step."""
+        Conv BN layers receive the reference's two running-stat updates per step in the fused
+        step; the per-mode API calls pass conv_updates=1 and head=False for 'REC'."""
         a0 = self.c0.forward(x16, ACT_RELU)
         acts, raws, svs = [a0], [], []
         h = a0
         for conv, bn in zip(self.convs, self.bns):
             raw = conv.forward(h)
-            h, sv = bn.forward(raw, relu=True, updates=2 if train_stats else 0)
+            h, sv = bn.forward(raw, relu=True, updates=conv_updates if train_stats else 0)
             raws.append(raw)
             svs.append(sv)
             acts.append(h)
+        ctx = dict(x=x16, acts=acts, raws=raws, svs=svs)
+        if not head:
+            return raws[2], None, ctx
         flat = h.reshape(h.shape[0], -1)
         raw_fc, _ = self.fc0.forward(flat)
-        hfc, svfc = self.fc_bn.forward(raw_fc, relu=True, updates=1 if train_stats else 0)
+        hfc, svfc = self.fc_bn.forward(raw_fc, relu=True, updates=fc_updates if train_stats else 0)
         _, logit32 = self.fc3.forward(hfc, ACT_NONE, want16=False, want32=True)
-        ctx = dict(x=x16, acts=acts, raws=raws, svs=svs, flat=flat, raw_fc=raw_fc, hfc=hfc, svfc=svfc)
+        ctx.update(flat=flat, raw_fc=raw_fc, hfc=hfc, svfc=svfc)
         return raws[2], logit32, ctx
 
     def backward(self, ctx, dlogit16: Optional[torch.Tensor], scale_a: float, dfeat16: Optional[torch.Tensor],
-                 scale_b: float, train: bool, img_rows: Optional[slice], img_streams=(True, True)):
+                 scale_b: float, train: bool, img_rows: Optional[slice], img_streams=(True, True),
+                 train_b: bool = False):
         """Two cotangent streams through one saved forward:
              A: d(sum bce)/d logit  (dlogit16 [3B,8], scale_a) -- accumulates discriminator grads if ``train``
              B: d(sum mse)/d raw conv-3 features (dfeat16 [3B,h,w,c], scale_b) -- data gradient only
@@ -318,7 +324,7 @@ class DiscriminatorNet:
             draw3, _ = self.bns[2].backward(ctx["raws"][2], d3, ctx["svs"][2], True, scale_a if train else None)
             streams.append(dict(d=draw3, scale=scale_a, train=train, img=img_streams[0]))
         if dfeat16 is not None:
-            streams.append(dict(d=dfeat16.reshape(ctx["raws"][2].shape), scale=scale_b, train=False,
+            streams.append(dict(d=dfeat16.reshape(ctx["raws"][2].shape), scale=scale_b, train=train_b,
                                 img=img_streams[1]))
         S = len(streams)
         d = torch.cat([s["d"] for s in streams], 0) if S > 1 else streams[0]["d"]

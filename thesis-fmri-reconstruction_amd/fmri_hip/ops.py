@@ -366,6 +366,7 @@ class BatchNorm:
         self.rm, self.rv = group.bufs[prefix + "running_mean"], group.bufs[prefix + "running_var"]
         self.nbt = group.bufs[prefix + "num_batches_tracked"]
         self.reducer = None
+        self.eval_mode = False
         self._v = -1
         if perm:
             dev = self.gamma.device
@@ -397,6 +398,8 @@ class BatchNorm:
             lib.call("fmri_permute_chw", _P(self.rv_e), _P(self.rv), c0, hw, 0, 1.0, 0)
 
     def forward(self, raw: torch.Tensor, relu: bool = True, updates: int = 1, out: Optional[torch.Tensor] = None):
+        if self.eval_mode:
+            return self.forward_eval(raw, relu, out), None
         C = self.C
         x2 = raw.reshape(-1, C)
         M = x2.shape[0]
@@ -423,6 +426,19 @@ class BatchNorm:
             out = torch.empty_like(raw)
         lib.call("fmri_bn_apply", _P(x2), _P(out), M, C, _P(sv.scale), _P(sv.shift), 1 if relu else 0)
         return out, sv
+
+    def forward_eval(self, raw: torch.Tensor, relu: bool = True, out: Optional[torch.Tensor] = None):
+        """Eval-mode BN (running statistics, models/vae_gan.py:288-297 path): y = relu(gamma*(x-rm)/sqrt(rv+eps)+beta)."""
+        C = self.C
+        x2 = raw.reshape(-1, C)
+        gamma, beta, rm, rv = self._params()
+        self._running_in()
+        scale = gamma * torch.rsqrt(rv + 1e-5)
+        shift = beta - rm * scale
+        if out is None:
+            out = torch.empty_like(raw)
+        lib.call("fmri_bn_apply", _P(x2), _P(out), x2.shape[0], C, _P(scale), _P(shift), 1 if relu else 0)
+        return out
 
     def backward(self, raw: torch.Tensor, dy: torch.Tensor, sv: BNSaved, relu: bool = True,
                  param_scale: Optional[float] = None, out: Optional[torch.Tensor] = None):

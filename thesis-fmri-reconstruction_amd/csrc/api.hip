@@ -2,6 +2,7 @@
 // Host-side geometry derivation + argument validation; all device work is enqueued on the caller's stream.
 #include "../../include/fmri_hip.h"
 #include "kernels.h"
+#include <cstdlib>
 
 using namespace fmri;
 

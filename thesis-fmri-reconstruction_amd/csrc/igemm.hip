@@ -103,26 +103,42 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     auto compute = [&](int buf) {
         const char* As = smem + buf * STAGE;
         const char* Bs = As + A_BYTES;
+        // all fragment reads of the K-step are issued up front: the second half's LDS latency hides under
+        // the first half's MFMAs (the compiler then waits with a counted lgkmcnt instead of lgkmcnt(0))
+        h8 af[2][TM], bf[2][TN];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            h8 af[TM], bf[TN];
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
                 const int row = wm * (BM / WM) + tm * 16 + frow;
                 const int ph = (ks * 4 + fq) ^ ((row >> 1) & 7);
-                af[tm] = *(const h8*)(As + row * 128 + ph * 16);
+                af[ks][tm] = *(const h8*)(As + row * 128 + ph * 16);
             }
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
                 const int row = wn * (BN / WN) + tn * 16 + frow;
                 const int ph = (ks * 4 + fq) ^ ((row >> 1) & 7);
-                bf[tn] = *(const h8*)(Bs + row * 128 + ph * 16);
+                bf[ks][tn] = *(const h8*)(Bs + row * 128 + ph * 16);
             }
+            if (ks == 0) __builtin_amdgcn_sched_barrier(0);   // first-half reads are issued first
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm)
-                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[tn], af[tm], acc[tn][tm], 0, 0, 0);
+                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[ks][tn], af[ks][tm], acc[tn][tm], 0, 0, 0);
+            if (ks == 0) {
+                // interleave the second-half reads with the first TM+TN MFMAs of the first half, then the rest
+#pragma unroll
+                for (int i = 0; i < TM + TN; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - (TM + TN), 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     };
 

@@ -30,6 +30,67 @@ __global__ void pack_weight_kernel(const PackArgs p) {
     }
 }
 
+// Fast path 1 ("tap-inner"): source taps are contiguous (stb == 1).  One thread per (row, b): it reads its
+// taps from one contiguous run of the source and, for every tap, the threads of a wave write consecutive b.
+// Padding regions of dst are pre-zeroed by the caller and never touched.
+__global__ void pack_tapinner_kernel(const PackArgs p) {
+    const int64_t total = (int64_t)p.TA * p.A * p.B;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i % p.B);
+        const int row = (int)(i / p.B);
+        const int ta = row / p.A, a = row - ta * p.A;
+        const float* s = p.src + a * p.sa + ta * p.sta + b * p.sb;
+        half_t* d = p.dst + (int64_t)row * p.kpad + b;
+        for (int ty = 0; ty < p.TH; ++ty)
+            for (int tx = 0; tx < p.TW; ++tx) {
+                const int t = (p.py + p.step * ty) * p.KW + (p.px + p.step * tx);
+                d[(ty * p.TW + tx) * p.Bp] = (half_t)s[t];
+            }
+    }
+}
+
+// Fast path 2: LDS-tiled transpose between a source-contiguous index X (stride 1 in src, stride dX in dst)
+// and b (stride sb in src, stride 1 in dst); an outer index o (O values) is iterated by blockIdx.z.
+struct PackT { const float* src; half_t* dst; int X, B, O; int64_t sb, so_src, dX, so_dst; };
+__global__ __launch_bounds__(256) void pack_transpose_kernel(const PackT p) {
+    __shared__ float tile[32][33];
+    const int x0 = blockIdx.x * 32, b0 = blockIdx.y * 32, o = blockIdx.z;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+    const float* s = p.src + o * p.so_src;
+    half_t* d = p.dst + o * p.so_dst;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int b = b0 + ty + 8 * k, x = x0 + tx;
+        tile[ty + 8 * k][tx] = (b < p.B && x < p.X) ? s[b * p.sb + x] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int x = x0 + ty + 8 * k, b = b0 + tx;
+        if (x < p.X && b < p.B) d[x * p.dX + b] = (half_t)tile[tx][ty + 8 * k];
+    }
+}
+
+// unpack fast path (stb == 1): one thread per (row, b) writes its taps to one contiguous run of dst.
+__global__ void unpack_tapinner_kernel(const UnpackArgs p) {
+    const int64_t total = (int64_t)p.TA * p.A * p.B;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i % p.B);
+        const int row = (int)(i / p.B);
+        const int ta = row / p.A, a = row - ta * p.A;
+        const float* s = p.src + (int64_t)row * p.ld + b;
+        float* d = p.dst + a * p.sa + ta * p.sta + b * p.sb;
+        for (int ty = 0; ty < p.TH; ++ty)
+            for (int tx = 0; tx < p.TW; ++tx) {
+                const int t = (p.py + p.step * ty) * p.KW + (p.px + p.step * tx);
+                const float v = s[(ty * p.TW + tx) * p.Bp] * p.scale;
+                if (p.accumulate) d[t] += v; else d[t] = v;
+            }
+    }
+}
+
 __global__ void unpack_grad_kernel(const UnpackArgs p) {
     const int ntb = p.TH * p.TW;
     const int64_t total = (int64_t)p.TA * p.A * ntb * p.B;
@@ -150,13 +211,34 @@ static inline int nblocks(int64_t total, int threads = 256, int cap = 4096) {
     return (int)b;
 }
 
+// The destination's padding (rows >= TA*A, columns >= taps*Bp, channels >= B) must be pre-zeroed by the
+// caller once; the fast paths only write the valid region.
 int pack_weight_launch(const PackArgs& p, hipStream_t st) {
-    hipLaunchKernelGGL(pack_weight_kernel, dim3(nblocks((int64_t)p.rows_pad * p.kpad)), dim3(256), 0, st, p);
+    const int ntaps = p.TH * p.TW;
+    if (ntaps > 1 && p.stb == 1) {
+        hipLaunchKernelGGL(pack_tapinner_kernel, dim3(nblocks((int64_t)p.TA * p.A * p.B, 256, 8192)), dim3(256), 0, st,
+                           p);
+    } else if (p.TA == 1 && p.sa == 1 && (ntaps == 1 || (p.step == 1 && p.py == 0 && p.px == 0 && p.TW == p.KW))) {
+        // X = a (rows), outer = tap: dst[a][tb*Bp + b] = src[a + b*sb + tb*stb]
+        PackT t{p.src, p.dst, p.A, p.B, ntaps, p.sb, p.stb, (int64_t)p.kpad, (int64_t)p.Bp};
+        hipLaunchKernelGGL(pack_transpose_kernel, dim3((p.A + 31) / 32, (p.B + 31) / 32, ntaps), dim3(256), 0, st, t);
+    } else if (ntaps == 1 && p.sta == 1 && p.TA > 1 && p.A <= 65535) {
+        // X = ta, outer = a: dst[ta*A + a][b] = src[a*sa + ta + b*sb]
+        PackT t{p.src, p.dst, p.TA, p.B, p.A, p.sb, p.sa, (int64_t)p.A * p.kpad, (int64_t)p.kpad};
+        hipLaunchKernelGGL(pack_transpose_kernel, dim3((p.TA + 31) / 32, (p.B + 31) / 32, p.A), dim3(256), 0, st, t);
+    } else {
+        hipLaunchKernelGGL(pack_weight_kernel, dim3(nblocks((int64_t)p.rows_pad * p.kpad)), dim3(256), 0, st, p);
+    }
     return hipGetLastError() == hipSuccess ? OK : E_LAUNCH;
 }
 int unpack_grad_launch(const UnpackArgs& p, hipStream_t st) {
     const int64_t total = (int64_t)p.TA * p.A * p.TH * p.TW * p.B;
-    hipLaunchKernelGGL(unpack_grad_kernel, dim3(nblocks(total)), dim3(256), 0, st, p);
+    if (p.TH * p.TW > 1 && p.stb == 1) {
+        hipLaunchKernelGGL(unpack_tapinner_kernel, dim3(nblocks((int64_t)p.TA * p.A * p.B, 256, 8192)), dim3(256), 0, st,
+                           p);
+    } else {
+        hipLaunchKernelGGL(unpack_grad_kernel, dim3(nblocks(total)), dim3(256), 0, st, p);
+    }
     return hipGetLastError() == hipSuccess ? OK : E_LAUNCH;
 }
 int nchw_to_nhwc_launch(const float* s, half_t* d, int N, int C, int HW, int Cp, hipStream_t st) {

@@ -99,9 +99,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     auto compute = [&](int buf) {
         const char* Ps = smem + buf * STAGE;
         const char* Qs = Ps + TILE;
+        // second-half transposing reads are interleaved with the first half's MFMAs (see igemm.hip)
+        h8 af[2][TA], bf[2][TB];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            h8 af[TA], bf[TB];
 #pragma unroll
             for (int ta = 0; ta < TA; ++ta) {
                 const int blk = (wa * WAVE_A + ta * 16) >> 4;
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
                 union { s4v s[2]; h8 h; } u;
                 u.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(ad));
                 u.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(ad + 4 * 256));
-                af[ta] = u.h;
+                af[ks][ta] = u.h;
             }
 #pragma unroll
             for (int tb = 0; tb < TB; ++tb) {
@@ -120,13 +121,26 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
                 union { s4v s[2]; h8 h; } u;
                 u.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(ad));
                 u.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(ad + 4 * 256));
-                bf[tb] = u.h;
+                bf[ks][tb] = u.h;
             }
+            if (ks == 0) __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
             for (int ta = 0; ta < TA; ++ta)
 #pragma unroll
                 for (int tb = 0; tb < TB; ++tb)
-                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ta], bf[tb], acc[ta][tb], 0, 0, 0);
+                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ks][ta], bf[ks][tb], acc[ta][tb], 0, 0, 0);
+            if (ks == 0) {
+#pragma unroll
+                for (int i = 0; i < TA + TB; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // 2 DS (transposing) reads
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, TA * TB - (TA + TB), 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     };
 

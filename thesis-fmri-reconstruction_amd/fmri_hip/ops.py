@@ -85,7 +85,8 @@ class PackedWeight:
         self.master, self.group = master, group
         self.specs, self.rows_pad, self.kpads, self.offsets = specs, rows_pad, kpads, offsets
         total = offsets[-1] + rows_pad * kpads[-1]
-        self.buf = torch.empty(total, dtype=torch.float16, device=master.device)
+        # zero once: the pack kernels' fast paths only rewrite the valid region, padding stays zero
+        self.buf = torch.zeros(total, dtype=torch.float16, device=master.device)
         self.version = -1
 
     def get(self) -> torch.Tensor:

@@ -66,8 +66,10 @@ int fmri_igemm(const void* in, const void* w, void* out, const float* bias, cons
 /* dW[a][tap*Bc+b] (+)= sum_m P[m][a] * Q[gather(m,tap)][b]; see csrc/wgrad.hip.  Replaces the weight
  * gradients autograd computes for the same modules (train/train_vgan_stage1.py:412,422,430). */
 int fmri_wgrad(const void* P, const void* Q, float* out, const void* zero16, int N, int Yc, int Xc, int A, int Hq,
-               int Wq, int Bc, int k, int stride, int pad, int apad, int ba_tile, int ldo, int splits, int atomic,
-               void* stream);
+               int Wq, int Bc, int k, int stride, int pad, int flip, int apad, int ba_tile, int ldo, int splits,
+               int atomic, void* stream);
+/* flip = 0: Q pixel = m*stride + tap - pad.  flip = 1 (stride 1 only): Q pixel = m + pad - tap, i.e. the roles of
+ * the two activations are exchanged so that the GATHERED operand is the one with fewer channels. */
 
 /* ---- layout casts ------------------------------------------------------------------------------- */
 int fmri_nchw_to_nhwc(const float* src, void* dst, int N, int C, int HW, int Cp, void* stream);

@@ -147,9 +147,10 @@ int fmri_igemm(const void* in, const void* w, void* out, const float* bias, cons
 }
 
 int fmri_wgrad(const void* P, const void* Q, float* out, const void* zero16, int N, int Yc, int Xc, int A, int Hq,
-               int Wq, int Bc, int k, int stride, int pad, int apad, int ba_tile, int ldo, int splits, int atomic,
-               void* stream) {
+               int Wq, int Bc, int k, int stride, int pad, int flip, int apad, int ba_tile, int ldo, int splits,
+               int atomic, void* stream) {
     if (!P || !Q || !out || !zero16) return FMRI_E_BADARG;
+    if (flip && stride != 1) return FMRI_E_UNSUPPORTED;
     if (N < 1 || A < 8 || (A & 7) || Bc < 8 || (Bc & 7) || splits < 1) return FMRI_E_BADARG;
     if (ba_tile != 32 && ba_tile != 64 && ba_tile != 128) return FMRI_E_UNSUPPORTED;
     if (apad % ba_tile || apad < A) return FMRI_E_BADARG;
@@ -161,7 +162,8 @@ int fmri_wgrad(const void* P, const void* Q, float* out, const void* zero16, int
     WgradArgs a;
     a.P = (const half_t*)P; a.Q = (const half_t*)Q; a.out = out; a.zero = (const half_t*)zero16;
     a.N = N; a.Yc = Yc; a.Xc = Xc; a.A = A; a.Hq = Hq; a.Wq = Wq; a.Bc = Bc;
-    a.s = stride; a.T = T; a.TW = k; a.dy0 = -pad; a.dx0 = -pad; a.dstep = 1;
+    a.s = stride; a.T = T; a.TW = k;
+    a.dy0 = flip ? pad : -pad; a.dx0 = a.dy0; a.dstep = flip ? -1 : 1;
     a.M = (int)M; a.ldo = ldo;
     const int steps = (int)((M + 63) / 64);
     if (splits > steps) splits = steps;

@@ -50,6 +50,55 @@ __global__ void pack_tapinner_kernel(const PackArgs p) {
     }
 }
 
+// Fast path 1b: LDS-tiled version of the tap-inner paths.  A block handles one row and 32 consecutive b:
+// the fp32 side is touched as runs of `run` contiguous taps per (row, b) (one 32*run-float run when
+// sb == run), the packed side as 32-element (64/128-byte) segments per tap.  run <= 64.
+__global__ __launch_bounds__(256) void pack_tile_kernel(const PackArgs p, int run) {
+    __shared__ float t[32 * 65];
+    const int nbt = (p.B + 31) / 32;
+    const int row = blockIdx.x / nbt, b0 = (blockIdx.x - row * nbt) * 32;
+    const int ta = row / p.A, a = row - ta * p.A;
+    const int stride = run | 1;
+    const float* s = p.src + a * p.sa + ta * p.sta;
+    for (int e = threadIdx.x; e < 32 * run; e += 256) {
+        const int bl = e / run, j = e - bl * run;
+        if (b0 + bl < p.B) t[bl * stride + j] = s[(b0 + bl) * p.sb + j];
+    }
+    __syncthreads();
+    half_t* d = p.dst + (int64_t)row * p.kpad + b0;
+    const int ntaps = p.TH * p.TW;
+    for (int e = threadIdx.x; e < ntaps * 32; e += 256) {
+        const int tb = e >> 5, bl = e & 31;
+        const int ty = tb / p.TW, tx = tb - ty * p.TW;
+        const int j = (p.py + p.step * ty) * p.KW + (p.px + p.step * tx);
+        if (b0 + bl < p.B) d[tb * p.Bp + bl] = (half_t)t[bl * stride + j];
+    }
+}
+
+// unpack counterpart (full tap set only: py = px = 0, step = 1, TH*TW == run)
+__global__ __launch_bounds__(256) void unpack_tile_kernel(const UnpackArgs p, int run) {
+    __shared__ float t[32 * 65];
+    const int nbt = (p.B + 31) / 32;
+    const int row = blockIdx.x / nbt, b0 = (blockIdx.x - row * nbt) * 32;
+    const int ta = row / p.A, a = row - ta * p.A;
+    const int stride = run | 1;
+    const float* s = p.src + (int64_t)row * p.ld + b0;
+    for (int e = threadIdx.x; e < run * 32; e += 256) {
+        const int tb = e >> 5, bl = e & 31;
+        if (b0 + bl < p.B) t[bl * stride + tb] = s[tb * p.Bp + bl];
+    }
+    __syncthreads();
+    float* d = p.dst + a * p.sa + ta * p.sta;
+    for (int e = threadIdx.x; e < 32 * run; e += 256) {
+        const int bl = e / run, j = e - bl * run;
+        if (b0 + bl < p.B) {
+            const float v = t[bl * stride + j] * p.scale;
+            float* q = d + (b0 + bl) * p.sb + j;
+            if (p.accumulate) *q += v; else *q = v;
+        }
+    }
+}
+
 // Fast path 2: LDS-tiled transpose between a source-contiguous index X (stride 1 in src, stride dX in dst)
 // and b (stride sb in src, stride 1 in dst); an outer index o (O values) is iterated by blockIdx.z.
 struct PackT { const float* src; half_t* dst; int X, B, O; int64_t sb, so_src, dX, so_dst; };
@@ -215,7 +264,11 @@ static inline int nblocks(int64_t total, int threads = 256, int cap = 4096) {
 // caller once; the fast paths only write the valid region.
 int pack_weight_launch(const PackArgs& p, hipStream_t st) {
     const int ntaps = p.TH * p.TW;
-    if (ntaps > 1 && p.stb == 1) {
+    const int run = (p.py + p.step * (p.TH - 1)) * p.KW + (p.px + p.step * (p.TW - 1)) + 1;   // source taps touched
+    const int64_t tiles = (int64_t)p.TA * p.A * ((p.B + 31) / 32);
+    if (ntaps > 1 && p.stb == 1 && run <= 64 && tiles < (1ll << 31)) {
+        hipLaunchKernelGGL(pack_tile_kernel, dim3((unsigned)tiles), dim3(256), 0, st, p, run);
+    } else if (ntaps > 1 && p.stb == 1) {
         hipLaunchKernelGGL(pack_tapinner_kernel, dim3(nblocks((int64_t)p.TA * p.A * p.B, 256, 8192)), dim3(256), 0, st,
                            p);
     } else if (p.TA == 1 && p.sa == 1 && (ntaps == 1 || (p.step == 1 && p.py == 0 && p.px == 0 && p.TW == p.KW))) {
@@ -233,7 +286,12 @@ int pack_weight_launch(const PackArgs& p, hipStream_t st) {
 }
 int unpack_grad_launch(const UnpackArgs& p, hipStream_t st) {
     const int64_t total = (int64_t)p.TA * p.A * p.TH * p.TW * p.B;
-    if (p.TH * p.TW > 1 && p.stb == 1) {
+    const int run = p.TH * p.TW;
+    const int64_t tiles = (int64_t)p.TA * p.A * ((p.B + 31) / 32);
+    if (run > 1 && run <= 64 && p.stb == 1 && p.py == 0 && p.px == 0 && p.step == 1 && p.TW == p.KW &&
+        tiles < (1ll << 31)) {
+        hipLaunchKernelGGL(unpack_tile_kernel, dim3((unsigned)tiles), dim3(256), 0, st, p, run);
+    } else if (p.TH * p.TW > 1 && p.stb == 1) {
         hipLaunchKernelGGL(unpack_tapinner_kernel, dim3(nblocks((int64_t)p.TA * p.A * p.B, 256, 8192)), dim3(256), 0, st,
                            p);
     } else {

@@ -22,7 +22,7 @@ _SIGS = {
     "fmri_pack_weight": [_p, _p, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "fmri_unpack_grad": [_p, _p, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p],
     "fmri_igemm": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _l, _i, _p],
-    "fmri_wgrad": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "fmri_wgrad": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "fmri_nchw_to_nhwc": [_p, _p, _i, _i, _i, _i, _p],
     "fmri_nhwc_to_nchw": [_p, _p, _i, _i, _i, _i, _f, _p],
     "fmri_rows_f32_to_f16": [_p, _p, _i, _i, _i, _f, _p],

@@ -145,7 +145,7 @@ def run_igemm(x, pw: PackedWeight, out, bias, N, Hi, Wi, Ci, Ho, Wo, CoStore, Co
         PROFILE.append((e0, e1, flops))
 
 
-def run_wgrad(P, Q, N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad):
+def run_wgrad(P, Q, N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad, flip=0):
     """Returns the packed fp32 gradient [apad][ldo]."""
     ba = tile_for(A)
     apad = ceil_to(A, ba)
@@ -161,7 +161,7 @@ def run_wgrad(P, Q, N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad):
     else:
         out = torch.empty(apad, ldo, dtype=torch.float32, device=P.device)
     lib.call("fmri_wgrad", _P(P), _P(Q), _P(out), _P(zero_page(P.device)), N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad,
-             apad, ba, ldo, splits, 1 if splits > 1 else 0)
+             flip, apad, ba, ldo, splits, 1 if splits > 1 else 0)
     return out, ldo
 
 
@@ -250,6 +250,15 @@ class ConvLayer:
         """weight.grad += (1/scale) * dW(x, dy)."""
         N, Hi, Wi, _ = x.shape
         _, Ho, Wo, _ = dy.shape
+        if self.kind == "conv" and self.stride == 1 and self.cinp > self.coutp:
+            # exchange the roles (dW[co][ci][k] = sum_m' X[m'][ci] * dY[m' + pad - k][co]) so that the gathered
+            # operand is the narrow one: rows ci, columns (tap, co)
+            packed, ldo = run_wgrad(x, dy, N, Hi, Wi, self.cinp, Ho, Wo, self.coutp, self.k, 1, self.pad, flip=1)
+            kk = self.k * self.k
+            spec = PackSpec(sa=kk, sta=0, A=self.cin, TA=1, sb=self.cin * kk, stb=1, B=self.cout, KW=self.k,
+                            TH=self.k, TW=self.k)
+            unpack_grad(packed, self.wg, spec, ldo, 1.0 / scale)
+            return
         if self.kind == "conv":
             packed, ldo = run_wgrad(dy, x, N, Ho, Wo, self.coutp, Hi, Wi, self.cinp, self.k, self.stride, self.pad)
         else:

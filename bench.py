@@ -136,7 +136,7 @@ def main():
 
     if rank == 0:
         value = world * B * a.steps / dt
-        # dominant kernel = igemm_kernel<128,2,2,false> (all conv/deconv fwd+dgrad with >=128 output channels)
+        # dominant kernel = igemm_kernel<128,2,2,false,true> (conv/deconv/dense fwd+dgrad, >=128 out channels, Ci%64==0)
         ms = sum(e0.elapsed_time(e1) for e0, e1, _ in prof)
         fl = sum(f for _, _, f in prof)
         nl = max(len(prof), 1)
@@ -151,7 +151,7 @@ def main():
                        "parallelism": f"dp{world}" + ("" if world == 1 else ("-localbn" if a.local_bn else "-syncbn"))},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                         "kernel": "fmri::igemm_kernel<128,2,2,false>",
+                         "kernel": "fmri::igemm_kernel<128,2,2,false,true>",
                          "launches_per_step": nl // max(a.steps, 1),
                          "avg_launch_ms": round(ms / nl, 4),
                          "avg_launch_gflop": round(fl / nl / 1e9, 2)},

@@ -391,3 +391,19 @@ def test_optimizers_match_torch():
         lib.call("fmri_adam", P(pd), P(g.to(DEV)), P(m), P(v), n, 1e-4, 0.5, 0.999, 1e-8, 1 - 0.5 ** t,
                  float(np.sqrt(1 - 0.999 ** t)), 1.0, None, 0.0, None)
     assert torch.allclose(pd.cpu(), pt.detach(), rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("route", ["all", "off"])
+def test_igemm_routing_variants(route):
+    """The patch-resident kernel is routed by default only to the stride-1 convolutions; FMRI_PATCH=all sends every
+    eligible geometry (transposed-conv parity classes too) through it and FMRI_PATCH=off none.  The routing is read
+    once per process, so the conv / deconv parity cases are re-run in a child process for both settings."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, FMRI_PATCH=route)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k",
+                        "conv_forward or deconv_forward or epilogues", "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -2,6 +2,7 @@
 // Host-side geometry derivation + argument validation; all device work is enqueued on the caller's stream.
 #include "../../include/fmri_hip.h"
 #include "kernels.h"
+#include <string.h>
 #include <cstdlib>
 
 using namespace fmri;
@@ -100,6 +101,7 @@ int fmri_igemm(const void* in, const void* w, void* out, const float* bias, cons
     a.N = N; a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.Ho = Ho; a.Wo = Wo; a.CoStore = CoStore; a.Co = Co;
     a.act = act; a.splits = splits; a.slab_stride = slab_stride;
     a.fdCi = make_fastdiv((uint32_t)Ci);
+    a.fdCpt = make_fastdiv((uint32_t)(Ci >= 64 ? Ci / 64 : 1));
     int maxM = 0;
     auto set_class = [&](IgemmClass& c, int Yc, int Xc, int oy0, int ox0, int TH, int TW, int dy0, int dx0, int dstep,
                          int kpad, int64_t w_off) -> bool {
@@ -143,6 +145,59 @@ int fmri_igemm(const void* in, const void* w, void* out, const float* bias, cons
         if (per * (splits - 1) >= a.cls[i].ksteps && splits > 1) return FMRI_E_BADARG;
     }
     if (maxM == 0) return FMRI_OK;
+    // unit-stride sampling with a spatial extent -> patch-resident kernel (csrc/igemm_patch.hip)
+    // Measured at the B=256 Stage-I shapes (tools/microbench_igemm.py): the patch kernel wins on the stride-1
+    // (single class, 25 tap) convolutions and loses on the short-K parity classes of the transposed convolutions,
+    // so only the former are routed to it by default.  FMRI_PATCH=all routes every eligible geometry (tests),
+    // FMRI_PATCH=off none.
+    static const char* patch_env = getenv("FMRI_PATCH");
+    static const bool no_patch = patch_env && !strcmp(patch_env, "off");
+    static const bool all_patch = patch_env && !strcmp(patch_env, "all");
+    const bool unit = all_patch ? (mode == FMRI_TCONV2 || mode == FMRI_CONV_FLIP || (mode == FMRI_CONV && stride == 1))
+                                : ((mode == FMRI_CONV_FLIP || mode == FMRI_CONV) && stride == 1);
+    if (!no_patch && unit && !out_f32 && splits == 1 && k >= 2 && k <= 5 && Hi * Wi > 1 &&
+        (Ci == 8 || Ci == 32 || (Ci & 63) == 0) && (int64_t)N * Hi * Wi * Ci < 0x7fffffffLL) {
+        PatchArgs p;
+        p.in = a.in; p.w = a.w; p.out = (half_t*)out; p.bias = bias; p.zero = a.zero;
+        p.N = N; p.Hi = Hi; p.Wi = Wi; p.Ci = Ci; p.Ho = Ho; p.Wo = Wo; p.CoStore = CoStore; p.Co = Co;
+        p.os = a.os; p.act = act; p.ncls = a.ncls;
+        const int CK = Ci >= 64 ? 64 : Ci;
+        p.cpp_log2 = CK == 64 ? 3 : (CK == 32 ? 2 : 0);
+        p.nchunks = Ci / CK;
+        p.pbufs = p.nchunks > 1 ? 2 : 1;
+        int max_tiles = 0, max_ent = 0;
+        bool ok = true;
+        for (int i = 0; i < a.ncls; ++i) {
+            const IgemmClass& s = a.cls[i];
+            PatchClass& d = p.cls[i];
+            d.Yc = s.Yc; d.Xc = s.Xc; d.oy0 = s.oy0; d.ox0 = s.ox0; d.T = s.T; d.TW = s.TW;
+            d.dy0 = s.dy0; d.dx0 = s.dx0; d.dstep = s.dstep; d.Kpad = s.Kpad; d.w_off = s.w_off;
+            const int TH = s.T / s.TW;
+            const int ey = (TH - 1) * s.dstep, ex = (s.TW - 1) * s.dstep;
+            d.dymin = s.dy0 + (ey < 0 ? ey : 0);
+            d.dxmin = s.dx0 + (ex < 0 ? ex : 0);
+            d.pw_log2 = s.Xc > 8 ? 4 : 3;
+            d.PH = s.Yc > 8 ? 16 : 8;
+            d.IPB = 256 / (d.PH << d.pw_log2);
+            d.IH = d.PH + (TH - 1);
+            d.IW = (1 << d.pw_log2) + (s.TW - 1);
+            d.tiles_x = (s.Xc + (1 << d.pw_log2) - 1) >> d.pw_log2;
+            d.tiles_y = (s.Yc + d.PH - 1) / d.PH;
+            d.ntiles = s.M > 0 ? ((N + d.IPB - 1) / d.IPB) * d.tiles_y * d.tiles_x : 0;
+            const int chunks = (d.IPB * d.IH * d.IW) << p.cpp_log2;
+            const int nent = (chunks + 511) / 512;
+            if (nent > 7 || s.T > 31) ok = false;
+            if (chunks > max_ent) max_ent = chunks;
+            if (d.ntiles > max_tiles) max_tiles = d.ntiles;
+        }
+        for (int i = a.ncls; i < 4; ++i) p.cls[i] = p.cls[0];
+        p.patch_bytes = pad_to(max_ent * 16, 1024);
+        p.wstages = 0; p.pad0 = 0;
+        if (ok && max_tiles > 0) {
+            const int r = igemm_patch_launch(p, max_tiles, bn_tile, copad, S(stream));
+            if (r != E_UNSUPPORTED) return r;
+        }
+    }
     return igemm_launch(a, maxM, bn_tile, copad, out_f32 != 0, S(stream));
 }
 

@@ -85,7 +85,34 @@ struct IgemmArgs {
     int32_t ncls, splits;
     int64_t slab_stride;     // elements between split-K slabs (fp32 output only)
     FastDiv fdCi;
+    FastDiv fdCpt;           // divide by Ci/64 (K-steps per tap) when Ci % 64 == 0
     IgemmClass cls[4];
+};
+
+// patch-resident implicit GEMM (igemm_patch.hip): unit-stride sampling only
+struct PatchClass {
+    int32_t Yc, Xc, oy0, ox0;
+    int32_t T, TW, dy0, dx0, dstep;
+    int32_t pw_log2, PH, IPB;           // tile: PW = 1 << pw_log2, PW * PH * IPB == 256 output pixels
+    int32_t tiles_x, tiles_y, ntiles;   // tiles per image (x, y); ntiles = ceil(N/IPB) * tiles_y * tiles_x
+    int32_t IH, IW, dymin, dxmin;       // input patch rows / cols and origin offset
+    int32_t Kpad;
+    int64_t w_off;
+};
+
+struct PatchArgs {
+    const half_t* in;
+    const half_t* w;
+    half_t* out;
+    const float* bias;
+    const half_t* zero;
+    int32_t N, Hi, Wi, Ci;
+    int32_t Ho, Wo, CoStore, Co;
+    int32_t os, act, ncls;
+    int32_t cpp_log2, nchunks;   // log2(channels per chunk / 8) in {0, 2, 3}; Ci / 64 (1 if Ci <= 64)
+    int32_t patch_bytes, pbufs;  // bytes of one LDS patch buffer (multiple of 1024); 1 or 2 buffers
+    int32_t wstages, pad0;       // weight ring depth (3 or 4), set by igemm_patch_launch
+    PatchClass cls[4];
 };
 
 // weight-gradient implicit GEMM (wgrad.hip):

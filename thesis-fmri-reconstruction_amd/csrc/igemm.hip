@@ -22,7 +22,7 @@
 
 namespace fmri {
 
-template <int BN, int WM, int WN, bool OUT_F32>
+template <int BN, int WM, int WN, bool OUT_F32, bool UNI>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     constexpr int BM = 128;
     constexpr int A_BYTES = BM * 128;
@@ -67,23 +67,52 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
 
     const half_t* wrow = a.w + c.w_off + (int64_t)(co0 + trow) * c.Kpad + clog * 8;
 
-    auto stage_load = [&](int buf, int kstep) {
-        const int k = kstep * 64 + clog * 8;
-        const int tap = (int)fd_div((uint32_t)k, a.fdCi);
-        const int ci = k - tap * a.Ci;
-        const int ty = (int)fd_div((uint32_t)tap, c.fdTW);
-        const int tx = tap - ty * c.TW;
-        const int dy = c.dy0 + ty * c.dstep;
-        const int dx = c.dx0 + tx * c.dstep;
-        const bool tv = tap < c.T;
-        char* dstA = smem + buf * STAGE + wave * (8 * 128);
+    // UNI (Ci % 64 == 0): a K-step lies inside one tap, so the tap decode is wave-uniform (scalar) and a
+    // row's source address is rowoff[i] + one scalar offset: no per-lane multiplies inside the K loop.
+    int rowoff[4];
+    if (UNI) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int iy = iy0[i] + dy;
-            const int ix = ix0[i] + dx;
-            const bool ok = tv && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
-            const half_t* src = ok ? a.in + ((int64_t)(pixbase[i] + iy * a.Wi + ix) * a.Ci + ci) : a.zero;
-            glds16(src, dstA + i * (32 * 128));
+        for (int i = 0; i < 4; ++i)
+            rowoff[i] = iy0[i] >= 0 ? (pixbase[i] + iy0[i] * a.Wi + ix0[i]) * a.Ci + clog * 8 : 0;
+    }
+    const int cpt = a.Ci >> 6;     // K-steps per tap (UNI)
+
+    auto stage_load = [&](int buf, int kstep) {
+        char* dstA = smem + buf * STAGE + wave * (8 * 128);
+        if (UNI) {
+            const int tap = (int)fd_div((uint32_t)kstep, a.fdCpt);
+            const int cstep = kstep - tap * cpt;
+            const int ty = (int)fd_div((uint32_t)tap, c.fdTW);
+            const int tx = tap - ty * c.TW;
+            const int dy = c.dy0 + ty * c.dstep;
+            const int dx = c.dx0 + tx * c.dstep;
+            const bool tv = tap < c.T;
+            const int tapoff = (dy * a.Wi + dx) * a.Ci + cstep * 64;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int iy = iy0[i] + dy;
+                const int ix = ix0[i] + dx;
+                const bool ok = tv && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
+                const half_t* src = ok ? a.in + (rowoff[i] + tapoff) : a.zero;
+                glds16(src, dstA + i * (32 * 128));
+            }
+        } else {
+            const int k = kstep * 64 + clog * 8;
+            const int tap = (int)fd_div((uint32_t)k, a.fdCi);
+            const int ci = k - tap * a.Ci;
+            const int ty = (int)fd_div((uint32_t)tap, c.fdTW);
+            const int tx = tap - ty * c.TW;
+            const int dy = c.dy0 + ty * c.dstep;
+            const int dx = c.dx0 + tx * c.dstep;
+            const bool tv = tap < c.T;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int iy = iy0[i] + dy;
+                const int ix = ix0[i] + dx;
+                const bool ok = tv && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
+                const half_t* src = ok ? a.in + ((int64_t)(pixbase[i] + iy * a.Wi + ix) * a.Ci + ci) : a.zero;
+                glds16(src, dstA + i * (32 * 128));
+            }
         }
         char* dstB = smem + buf * STAGE + A_BYTES + wave * (8 * 128);
         const half_t* wsrc = wrow + (int64_t)kstep * 64;
@@ -195,11 +224,14 @@ template <int BN, int WM, int WN>
 static int launch_bn(const IgemmArgs& a, int maxM, int copad, bool out_f32, hipStream_t st) {
     dim3 grid((maxM + 127) / 128, copad / BN, a.ncls * a.splits);
     const int lds = 2 * (128 * 128 + BN * 128);
-    // fp32-slab output is used for split-K / fp32 consumers
+    // fp32-slab output is used for split-K / fp32 consumers; UNI = K-steps never straddle taps
+    const bool uni = (a.Ci & 63) == 0;
     if (out_f32) {
-        hipLaunchKernelGGL((igemm_kernel<BN, WM, WN, true>), grid, dim3(256), lds, st, a);
+        if (uni) hipLaunchKernelGGL((igemm_kernel<BN, WM, WN, true, true>), grid, dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((igemm_kernel<BN, WM, WN, true, false>), grid, dim3(256), lds, st, a);
     } else {
-        hipLaunchKernelGGL((igemm_kernel<BN, WM, WN, false>), grid, dim3(256), lds, st, a);
+        if (uni) hipLaunchKernelGGL((igemm_kernel<BN, WM, WN, false, true>), grid, dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((igemm_kernel<BN, WM, WN, false, false>), grid, dim3(256), lds, st, a);
     }
     return hipGetLastError() == hipSuccess ? OK : E_LAUNCH;
 }

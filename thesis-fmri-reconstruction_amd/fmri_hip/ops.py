@@ -127,14 +127,16 @@ def _choose_splits(blocks: int, ksteps: int) -> int:
 
 
 # bench.py sets PROFILE to a list to time every launch of the dominant kernel instantiation
-# (igemm_kernel<128,2,2,false>) with HIP events on the launch stream: entries (start, end, algorithmic flops)
+# (igemm_kernel<128,2,2,false,true>: 128 output channels per block, Ci % 64 == 0) with HIP events on the launch
+# stream: entries (start, end, algorithmic flops)
 PROFILE = None
 
 
 def run_igemm(x, pw: PackedWeight, out, bias, N, Hi, Wi, Ci, Ho, Wo, CoStore, Co, k, stride, pad, mode, act, out_f32,
               splits, slab_stride, tile, flops=0.0):
     w = pw.get()
-    prof = PROFILE is not None and tile == 128 and not out_f32
+    prof = (PROFILE is not None and tile == 128 and not out_f32 and Ci % 64 == 0
+            and not (mode != MODE_TCONV2 and stride == 1 and Hi * Wi > 1 and 2 <= k <= 5))   # patch-kernel routing
     if prof:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -541,6 +541,145 @@ def wae_stage1_step(P: State, opts: Dict[str, OptState], x: Tensor, z_fake_noise
     return out
 
 
+def _gsum(a: List[Tensor], b: List[Tensor]) -> List[Tensor]:
+    """Element-wise sum of two gradient lists where None = "no gradient" (e.g. l_var under a mean-only latent)."""
+    return [y if x is None else (x if y is None else x + y) for x, y in zip(a, b)]
+
+
+def _wae_dis_phase(P: State, opt: OptState, z_real: Tensor, z_fake: Tensor, dis_k: List[str], lam: float,
+                   pre: str = "discriminator."):
+    """Latent-discriminator phase shared by every WAE script (e.g. train/train_wae_stage2.py:297-307): two
+    separate backward passes accumulate into .grad, then one optimizer step."""
+    _leafify(P, dis_k)
+    d_real = wae_discriminator_fwd(P, pre, z_real)
+    d_fake = wae_discriminator_fwd(P, pre, z_fake)
+    l_fake = -lam * torch.sum(torch.log(d_fake + 1e-3))
+    l_real = -lam * torch.sum(torch.log(1 - d_real + 1e-3))
+    g_dis = [a + b for a, b in zip(_grads(l_fake, P, dis_k, True), _grads(l_real, P, dis_k, False))]
+    opt_step(P, dis_k, g_dis, opt)
+    for k in dis_k:
+        P[k] = P[k].detach()
+    return l_fake, l_real, g_dis
+
+
+def wae_stage2_step(P: State, opts: Dict[str, OptState], fmri: Tensor, image: Tensor, cfg: ArchCfg, n_voxels: int,
+                    keep_grads: bool = False):
+    """WAE Stage-II step (train/train_wae_stage2.py:276-328): cognitive encoder + latent discriminator trained,
+    decoder frozen (but in train mode: BN batch statistics, running stats updated by both decoder calls), the
+    Stage-I image encoder `teacher_net.encoder.` gives the "real" latents (train mode as well, called twice)."""
+    enc_k = param_keys(cognitive_encoder_spec(cfg, n_voxels))
+    dis_k = param_keys(wae_discriminator_spec(cfg))
+    with torch.no_grad():
+        z_t, _ = encoder_fwd(P, "teacher_net.encoder.", image, cfg)       # :284
+        decoder_fwd(P, "decoder.", z_t, cfg)                               # :285 x_gt: unused, BN side effects only
+        z_fake, _ = cognitive_encoder_fwd(P, "encoder.", fmri)             # :292
+        z_real, _ = encoder_fwd(P, "teacher_net.encoder.", image, cfg)     # :293
+    l_fake, l_real, g_dis = _wae_dis_phase(P, opts["discriminator"], z_real, z_fake, dis_k, 10.0)
+    _leafify(P, enc_k)
+    z, _ = cognitive_encoder_fwd(P, "encoder.", fmri)                      # :314
+    x_recon = decoder_fwd(P, "decoder.", z, cfg)
+    d = wae_discriminator_fwd(P, "discriminator.", z)
+    l_rec = F.mse_loss(x_recon, image)                                     # :320
+    l_pen = -10 * torch.mean(torch.log(d + 1e-3))                          # :321
+    g = _gsum(_grads(l_rec, P, enc_k, True), _grads(l_pen, P, enc_k, False))
+    opt_step(P, enc_k, g, opts["encoder"])
+    for k in enc_k:
+        P[k] = P[k].detach()
+    logs = dict(loss_reconstruction=l_rec.item(), loss_penalty=l_pen.item(),
+                loss_discriminator_fake=l_fake.item(), loss_discriminator_real=l_real.item())
+    out = dict(logs=logs, fw=dict(x_recon=x_recon.detach(), z_real=z.detach()))
+    if keep_grads:
+        out["grads"] = {**dict(zip(dis_k, g_dis)), **dict(zip(enc_k, g))}
+    return out
+
+
+def wae_stage3_step(P: State, opts: Dict[str, OptState], fmri: Tensor, image: Tensor, cfg: ArchCfg, n_voxels: int,
+                    keep_grads: bool = False):
+    """WAE Stage-III step (train/train_wae_stage3.py:297-347): cognitive encoder frozen (train-mode BN, two calls),
+    latent discriminator and decoder trained; the penalty is computed but never back-propagated (:344)."""
+    dec_k = param_keys(decoder_spec(cfg))
+    dis_k = param_keys(wae_discriminator_spec(cfg))
+    with torch.no_grad():
+        z_fake, _ = cognitive_encoder_fwd(P, "encoder.", fmri)             # :311
+        z_real, _ = encoder_fwd(P, "teacher_net.encoder.", image, cfg)     # :312
+    l_fake, l_real, g_dis = _wae_dis_phase(P, opts["discriminator"], z_real, z_fake, dis_k, 10.0)
+    _leafify(P, dec_k)
+    with torch.no_grad():
+        z, _ = cognitive_encoder_fwd(P, "encoder.", fmri)                  # :333
+        d = wae_discriminator_fwd(P, "discriminator.", z)
+    x_recon = decoder_fwd(P, "decoder.", z, cfg)
+    l_rec = F.mse_loss(x_recon, image)                                     # :339
+    l_pen = -10 * torch.mean(torch.log(d + 1e-3))                          # :340 (logged only)
+    g_dec = _grads(l_rec, P, dec_k, False)
+    opt_step(P, dec_k, g_dec, opts["decoder"])
+    for k in dec_k:
+        P[k] = P[k].detach()
+    logs = dict(loss_reconstruction=l_rec.item(), loss_penalty=l_pen.item(),
+                loss_discriminator_fake=l_fake.item(), loss_discriminator_real=l_real.item())
+    out = dict(logs=logs, fw=dict(x_recon=x_recon.detach(), z_real=z.detach()))
+    if keep_grads:
+        out["grads"] = {**dict(zip(dis_k, g_dis)), **dict(zip(dec_k, g_dec))}
+    return out
+
+
+def dual_stage1_step(P: State, opts: Dict[str, OptState], x: Tensor, noise: Tensor, cfg: ArchCfg,
+                     hp: GanHyper = GanHyper(), lam: float = 1.0, keep_grads: bool = False):
+    """Dual WAE + VAE/GAN Stage-I step, mode 'vae-gan' (train/wae_vgan_stage1.py:284-441).
+
+    = the Stage-I VAE/GAN forward and losses (:290-364), then a WAE latent-discriminator phase on the encoder
+    means (`wae_discriminator.`, RMSprop, :384-397), then the penalty -lam*sum log(d_real+1e-3) back-propagated
+    into the encoder from a third encoder pass (:405-413; the decoder call :406 only moves BN statistics and the
+    `optimizer_decoder.step()` of :417 sees no new gradient), and finally the three gated VAE/GAN updates with the
+    penalty gradient still sitting in the encoder's .grad (:419-441).  noise = [eps, z_p, z_fake] (3, B, z).
+
+    torch-1.4 detail (the pinned version): `zero_grad()` zeroes existing .grad tensors instead of dropping them,
+    so from the second iteration on the RMSprop step of :417 runs with an all-zero decoder gradient -- parameters
+    stay put but `square_avg` decays by alpha once more.  Restated here as that extra decay."""
+    enc_k = param_keys(encoder_spec(cfg))
+    dec_k = param_keys(decoder_spec(cfg))
+    dis_k = param_keys(discriminator_spec(cfg))
+    wd_k = param_keys(wae_discriminator_spec(cfg, pre="wae_discriminator."))
+    _leafify(P, enc_k + dec_k + dis_k)
+    B = x.shape[0]
+    fw = vaegan_forward(P, x, noise[0], noise[1], cfg)
+    loss_enc, loss_dis, loss_dec, logs = _compose_losses(fw, x, B, hp)
+    train_dis, train_dec = equilibrium_gate(logs["bce_orig"] / B, logs["bce_pred"] / B, hp)
+    with torch.no_grad():
+        z_real, _ = encoder_fwd(P, "encoder.", x, cfg)                     # :384
+    z_fake = noise[2] * 0.5                                                # :385
+    l_fake, l_real, g_wd = _wae_dis_phase(P, opts["wae_discriminator"], z_real, z_fake, wd_k, lam,
+                                          pre="wae_discriminator.")
+    z_real2, _ = encoder_fwd(P, "encoder.", x, cfg)                        # :405
+    with torch.no_grad():
+        decoder_fwd(P, "decoder.", z_real2, cfg)                           # :406 x_recon: unused, BN side effects
+    d_real = wae_discriminator_fwd(P, "wae_discriminator.", z_real2)
+    l_pen = -lam * torch.sum(torch.log(d_real + 1e-3))                     # :411
+    g_pen = _grads(l_pen, P, enc_k, False)
+    dopt = opts["decoder"]
+    if dopt.step > 0:                                                      # :417 with zeroed grads (torch 1.4)
+        with torch.no_grad():
+            for k in dec_k:
+                if k in dopt.bufs:
+                    dopt.bufs[k].mul_(dopt.alpha)
+    g_enc = _gsum(_grads(loss_enc, P, enc_k, True), g_pen)                 # :421 accumulates onto the penalty
+    g_dec = _grads(loss_dec, P, dec_k, True)
+    g_dis = _grads(loss_dis, P, dis_k, False)
+    opt_step(P, enc_k, g_enc, opts["encoder"])
+    if train_dec:
+        opt_step(P, dec_k, g_dec, opts["decoder"])
+    if train_dis:
+        opt_step(P, dis_k, g_dis, opts["discriminator"])
+    for k in enc_k + dec_k + dis_k:
+        P[k] = P[k].detach()
+    logs.update(train_dis=train_dis, train_dec=train_dec, loss_penalty=l_pen.item(),
+                loss_discriminator_fake=l_fake.item(), loss_discriminator_real=l_real.item())
+    out = dict(logs=logs, fw={k: v.detach() for k, v in fw.items()})
+    if keep_grads:
+        out["grads"] = {**dict(zip(enc_k, g_enc)), **dict(zip(dec_k, g_dec)), **dict(zip(dis_k, g_dis)),
+                        **dict(zip(wd_k, g_wd))}
+    return out
+
+
 # ----------------------------------------------------------------------------------------------
 # summaries used by golden fixtures
 # ----------------------------------------------------------------------------------------------

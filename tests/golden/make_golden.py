@@ -375,6 +375,200 @@ def case_wae1(name, cfg, B, seed, steps=2):
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
 
 
+def build_wae_cognitive(vg, cfg, V, seed):
+    """Model wiring of train/train_wae_stage2.py:195-202 (Stage III wires the same objects, :208-221) on recipe
+    weights: `teacher` = Stage-I WaeGan (image encoder + decoder), `model` = WaeGanCognitive sharing its decoder."""
+    Z = cfg.latent_dim
+    teacher = vg.WaeGan(device="cpu", z_size=Z)
+    teacher.load_state_dict(O.fill_state(O.encoder_spec(cfg) + O.decoder_spec(cfg) + O.wae_discriminator_spec(cfg),
+                                         seed, True))
+    cog = vg.CognitiveEncoder(input_size=V, z_size=Z)
+    cog.load_state_dict({k[len("encoder."):]: v for k, v in
+                         O.fill_state(O.cognitive_encoder_spec(cfg, V), seed + 100, True).items()})
+    model = vg.WaeGanCognitive(device="cpu", encoder=cog, decoder=teacher.decoder, z_size=Z)
+    model.discriminator.load_state_dict({k[len("discriminator."):]: v for k, v in
+                                         O.fill_state(O.wae_discriminator_spec(cfg), seed + 200, True).items()})
+    return teacher, model
+
+
+def case_wae23(name, cfg, B, V, seed, stage, steps=2):
+    """train/train_wae_stage2.py:276-328 (stage 2) / train/train_wae_stage3.py:297-347 (stage 3)."""
+    vg = load_reference(cfg)
+    teacher, model = build_wae_cognitive(vg, cfg, V, seed)
+    import torch.nn as nn
+    opt_e = torch.optim.Adam(model.encoder.parameters(), lr=0.001, betas=(0.5, 0.999))
+    opt_d = torch.optim.Adam(model.decoder.parameters(), lr=0.001, betas=(0.5, 0.999))
+    opt_s = torch.optim.Adam(model.discriminator.parameters(), lr=0.0005, betas=(0.5, 0.999))
+    data = O.synth_batch(B, cfg, n_voxels=V, seed=1234, steps=steps)
+    x_image, x_fmri = data["x"], data["fmri"]
+
+    def freeze(m, flag):
+        for p in m.parameters():
+            p.requires_grad = not flag
+
+    if stage == 2:
+        freeze(teacher.decoder, True)
+    else:
+        freeze(teacher.encoder, True)
+        freeze(model.encoder, True)
+    out = {"meta/case": np.array(f"wae{stage}"), "meta/B": B, "meta/V": V, "meta/seed": seed, "meta/steps": steps,
+           "meta/image_size": cfg.image_size}
+    for s in range(steps):
+        model.train()
+        g = {}
+        if stage == 2:
+            freeze(model.decoder, True)
+            model.encoder.zero_grad()
+            model.discriminator.zero_grad()
+            z, _ = teacher.encoder(x_image)
+            teacher.decoder(z)                       # x_gt: unused by the script, moves BN statistics
+            freeze(model.encoder, True)
+        else:
+            freeze(model.encoder, True)
+            model.decoder.zero_grad()
+            model.discriminator.zero_grad()
+            freeze(model.decoder, True)
+        freeze(model.discriminator, False)
+        z_fake, var = model.encoder(x_fmri)
+        z_real, var = teacher.encoder(x_image)
+        d_real = model.discriminator(z_real)
+        d_fake = model.discriminator(z_fake)
+        l_fake = -10 * torch.sum(torch.log(d_fake + 1e-3))
+        l_real = -10 * torch.sum(torch.log(1 - d_real + 1e-3))
+        l_fake.backward(retain_graph=True)
+        l_real.backward(retain_graph=True)
+        g.update(grads_of([("discriminator." + k, p) for k, p in model.discriminator.named_parameters()]))
+        opt_s.step()
+        if stage == 2:
+            freeze(model.encoder, False)
+        else:
+            freeze(model.decoder, False)
+        freeze(model.discriminator, True)
+        z_real, var = model.encoder(x_fmri)
+        x_recon = model.decoder(z_real)
+        d_real = model.discriminator(z_real)
+        l_rec = nn.MSELoss()(x_recon, x_image)
+        l_pen = -10 * torch.mean(torch.log(d_real + 1e-3))
+        l_rec.backward(retain_graph=True)
+        if stage == 2:
+            l_pen.backward()
+            g.update(grads_of([("encoder." + k, p) for k, p in model.encoder.named_parameters()]))
+            opt_e.step()
+        else:
+            g.update(grads_of([("decoder." + k, p) for k, p in model.decoder.named_parameters()]))
+            opt_d.step()
+        logs = dict(loss_reconstruction=l_rec.item(), loss_penalty=l_pen.item(),
+                    loss_discriminator_fake=l_fake.item(), loss_discriminator_real=l_real.item())
+        record_step(out, f"step{s}", logs, dict(x_recon=x_recon, z_real=z_real), g)
+        sd = dict(model.state_dict())
+        sd.update({"teacher_net.encoder." + k: v for k, v in teacher.encoder.state_dict().items()})
+        keys, summ = summarize_state(sd)
+        out[f"step{s}/state_keys"] = np.array(keys)
+        out[f"step{s}/state_sum"] = summ
+        print(name, "step", s, {k: round(v, 5) for k, v in logs.items()})
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+
+
+def case_dual1(name, cfg, B, seed, perturb, steps=3, lam=1.0):
+    """train/wae_vgan_stage1.py:284-441, mode 'vae-gan': Stage-I VAE/GAN step + WAE latent-discriminator phase +
+    latent penalty into the encoder.  Optimizer steps are applied after all gradients are taken (SURVEY 0.5);
+    `zero_grad()` follows the pinned torch 1.4 (zeroes instead of dropping .grad), which makes the
+    `optimizer_decoder.step()` of :417 an extra decay of the decoder's RMSprop state from the 2nd iteration on."""
+    vg = load_reference(cfg)
+    hp = O.GanHyper()
+    Z = cfg.latent_dim
+    model = vg.VaeGan(device="cpu", z_size=Z)
+    model.load_state_dict(O.fill_state(O.vaegan_spec(cfg), seed, perturb))
+    model_wae = vg.WaeGan(device="cpu", z_size=Z)
+    model_wae.discriminator.load_state_dict(
+        {k[len("wae_discriminator."):]: v for k, v in
+         O.fill_state(O.wae_discriminator_spec(cfg, pre="wae_discriminator."), seed + 200, perturb).items()})
+    model.train()
+    data = O.synth_batch(B, cfg, seed=1234, steps=steps)
+    x = data["x"]
+    opt_e = rms(model.encoder.parameters(), hp.lr)
+    opt_d = rms(model.decoder.parameters(), hp.lr)
+    opt_s = rms(model.discriminator.parameters(), hp.lr)
+    opt_w = rms(model_wae.discriminator.parameters(), hp.lr)
+
+    def freeze(m, flag):
+        for p in m.parameters():
+            p.requires_grad = not flag
+
+    out = {"meta/case": np.array("dual1"), "meta/B": B, "meta/seed": seed, "meta/perturb": perturb,
+           "meta/steps": steps, "meta/image_size": cfg.image_size, "meta/lam": lam}
+    for s in range(steps):
+        nz = data["noise"][s]
+        model.train()
+        mus, lv = model.encoder(x)
+        x_tilde = model.decoder(nz[0] * torch.exp(0.5 * lv) + mus)
+        x_p = model.decoder(nz[1])
+        disc_layer = model.discriminator(x, x_tilde, x_p, "REC")
+        disc_class = model.discriminator(x, x_tilde, x_p, "GAN")
+        nle, kld, mse, bo, bp, bs = vg.VaeGan.loss(x, x_tilde, disc_layer[:B], disc_layer[B:-B], disc_layer[-B:],
+                                                   disc_class[:B], disc_class[B:-B], disc_class[-B:], mus, lv)
+        loss_enc = torch.sum(kld) + torch.sum(mse)
+        loss_dis = torch.sum(bo) + torch.sum(bp) + torch.sum(bs)
+        loss_dec = torch.sum(hp.lambda_mse * mse) - (1.0 - hp.lambda_mse) * loss_dis
+        train_dis, train_dec = gate(torch.mean(bo).item(), torch.mean(bp).item(), hp)
+        model.zero_grad()
+        # ---- WAE discriminator phase (:378-397)
+        freeze(model.decoder, True)
+        freeze(model.encoder, True)
+        freeze(model_wae.discriminator, False)
+        z_real, var = model.encoder(x)
+        z_fake = nz[2] * 0.5
+        d_real = model_wae.discriminator(z_real)
+        d_fake = model_wae.discriminator(z_fake)
+        l_fake = -lam * torch.sum(torch.log(d_fake + 1e-3))
+        l_real = -lam * torch.sum(torch.log(1 - d_real + 1e-3))
+        model_wae.discriminator.zero_grad()
+        l_fake.backward(retain_graph=True)
+        l_real.backward(retain_graph=True)
+        g = grads_of([("wae_discriminator." + k, p) for k, p in model_wae.discriminator.named_parameters()])
+        opt_w.step()
+        # ---- generator phase (:401-417)
+        freeze(model.encoder, False)
+        freeze(model.decoder, False)
+        freeze(model_wae.discriminator, True)
+        z_real, var = model.encoder(x)
+        x_recon = model.decoder(z_real)
+        d_real = model_wae.discriminator(z_real)
+        l_pen = -lam * torch.sum(torch.log(d_real + 1e-3))
+        g_pen = torch.autograd.grad(l_pen, list(model.encoder.parameters()), allow_unused=True)
+        # ---- VAE/GAN updates (:419-441), gradients at the pre-update weights
+        g3 = literal_three_backward(model, loss_enc, loss_dec, loss_dis, ("encoder", "decoder", "discriminator"))
+        for (k, p), gp in zip(model.encoder.named_parameters(), g_pen):
+            if gp is not None:
+                g3["encoder." + k] = g3["encoder." + k] + gp  # :421 accumulates onto the penalty gradient
+        g.update(g3)
+        if s > 0:   # :417 under torch 1.4: decoder .grad are zero tensors there -> RMSprop decays square_avg, params
+            #         unchanged (run here, after the backward passes, because the step bumps tensor versions)
+            for p in model.decoder.parameters():
+                p.grad = torch.zeros_like(p)
+            opt_d.step()
+        apply_grads(model.encoder, "encoder.", g, opt_e)
+        if train_dec:
+            apply_grads(model.decoder, "decoder.", g, opt_d)
+        if train_dis:
+            apply_grads(model.discriminator, "discriminator.", g, opt_s)
+        model.zero_grad()
+        logs = dict(loss_encoder=loss_enc.item(), loss_discriminator=loss_dis.item(), loss_decoder=loss_dec.item(),
+                    nle=torch.sum(nle).item(), kl=torch.sum(kld).item(), mse=torch.sum(mse).item(),
+                    bce_orig=torch.sum(bo).item(), bce_pred=torch.sum(bp).item(), bce_samp=torch.sum(bs).item(),
+                    train_dis=float(train_dis), train_dec=float(train_dec), loss_penalty=l_pen.item(),
+                    loss_discriminator_fake=l_fake.item(), loss_discriminator_real=l_real.item())
+        fw = dict(x_tilde=x_tilde, x_p=x_p, disc_class=disc_class, disc_layer=disc_layer, mus=mus, log_variances=lv)
+        record_step(out, f"step{s}", logs, fw, g)
+        sd = dict(model.state_dict())
+        sd.update({"wae_discriminator." + k: v for k, v in model_wae.discriminator.state_dict().items()})
+        keys, summ = summarize_state(sd)
+        out[f"step{s}/state_keys"] = np.array(keys)
+        out[f"step{s}/state_sum"] = summ
+        print(name, "step", s, {k: round(v, 5) for k, v in logs.items()})
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     which = sys.argv[1:] or ["all"]
@@ -394,3 +588,9 @@ if __name__ == "__main__":
         case_cognitive("stage3_b4", O.ArchCfg.px64(), B=4, V=4096, seed=2, perturb=True, stage=3)
     if want("wae1_b4"):
         case_wae1("wae1_b4", O.ArchCfg.px64(), B=4, seed=5)
+    if want("wae2_b4"):
+        case_wae23("wae2_b4", O.ArchCfg.px64(), B=4, V=4096, seed=6, stage=2)
+    if want("wae3_b4"):
+        case_wae23("wae3_b4", O.ArchCfg.px64(), B=4, V=4096, seed=7, stage=3)
+    if want("dual1_b4"):
+        case_dual1("dual1_b4", O.ArchCfg.px64(), B=4, seed=8, perturb=True)

@@ -132,3 +132,46 @@ def test_stage1_b32_first_step_losses(golden_dir):
         fw = O.vaegan_forward(P, data["x"], data["noise"][0, 0], data["noise"][0, 1], cfg)
         _, _, _, logs = O._compose_losses(fw, data["x"], 32, O.GanHyper())
     _check_logs(g, "step0", logs)
+
+
+def wae_cognitive_state(cfg, V, seed):
+    """Recipe state of the WAE Stage-II/III wiring (tests/golden/make_golden.py::build_wae_cognitive)."""
+    teacher = O.fill_state(O.encoder_spec(cfg) + O.decoder_spec(cfg) + O.wae_discriminator_spec(cfg), seed, True)
+    P = dict(O.fill_state(O.cognitive_encoder_spec(cfg, V), seed + 100, True))
+    P.update({k: v for k, v in teacher.items() if k.startswith("decoder.")})
+    P.update(O.fill_state(O.wae_discriminator_spec(cfg), seed + 200, True))
+    P.update({"teacher_net." + k: v for k, v in teacher.items() if k.startswith("encoder.")})
+    return P
+
+
+@pytest.mark.parametrize("stage", [2, 3])
+def test_wae_stage23_matches_reference(golden_dir, stage):
+    cfg = O.ArchCfg.px64()
+    g = _load(golden_dir, f"wae{stage}_b4")
+    B, V, seed, steps = int(g["meta/B"]), int(g["meta/V"]), int(g["meta/seed"]), int(g["meta/steps"])
+    P = wae_cognitive_state(cfg, V, seed)
+    data = O.synth_batch(B, cfg, n_voxels=V, seed=1234, steps=steps)
+    opts = {"encoder": O.OptState(kind="adam", lr=1e-3), "decoder": O.OptState(kind="adam", lr=1e-3),
+            "discriminator": O.OptState(kind="adam", lr=5e-4)}
+    step = O.wae_stage2_step if stage == 2 else O.wae_stage3_step
+    for s in range(steps):
+        out = step(P, opts, data["fmri"], data["x"], cfg, V, keep_grads=True)
+        _check_step(g, f"step{s}", out, P)
+
+
+def dual_state(cfg, seed, perturb):
+    P = O.fill_state(O.vaegan_spec(cfg), seed, perturb)
+    P.update(O.fill_state(O.wae_discriminator_spec(cfg, pre="wae_discriminator."), seed + 200, perturb))
+    return P
+
+
+def test_dual_stage1_matches_reference(golden_dir):
+    cfg = O.ArchCfg.px64()
+    g = _load(golden_dir, "dual1_b4")
+    B, seed, perturb, steps = int(g["meta/B"]), int(g["meta/seed"]), bool(g["meta/perturb"]), int(g["meta/steps"])
+    P = dual_state(cfg, seed, perturb)
+    data = O.synth_batch(B, cfg, seed=1234, steps=steps)
+    opts = _rms_opts("encoder", "decoder", "discriminator", "wae_discriminator")
+    for s in range(steps):
+        out = O.dual_stage1_step(P, opts, data["x"], data["noise"][s], cfg, lam=float(g["meta/lam"]), keep_grads=True)
+        _check_step(g, f"step{s}", out, P)

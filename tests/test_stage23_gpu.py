@@ -87,3 +87,31 @@ def test_cognitive_step_matches_oracle_and_golden(golden_dir, stage):
             assert float(sd[k]) == summ[i][1], k
         elif "running_mean" in k or "running_var" in k:
             assert _rel(sd[k].double().norm().item(), summ[i][0]) < 2e-2, k
+
+
+def test_stage3_px128_bold5000_shape_matches_oracle():
+    """BASELINE configs[5] shape (Stage III, 128x128 images, V = 3620 voxels) at a batch the CPU oracle finishes in
+    seconds: first-step losses within 1e-3 of the oracle, same gate decision."""
+    from oracle import vaegan_oracle as O
+    from fmri_hip.params import ArchConfig
+    from fmri_hip.steps import CognitiveStep
+    B, V, seed = 4, 3620, 5
+    cfg_o = O.ArchCfg.px128()
+    data = O.synth_batch(B, cfg_o, n_voxels=V, seed=4321, steps=1)
+    st = CognitiveStep(ArchConfig.px128(), V, DEV, 3)
+    st.load_recipe(seed, True)
+    P, _ = _oracle_state(O, cfg_o, V, seed, True, 3)
+    opts = {n: O.OptState(kind="rmsprop", lr=1e-4) for n in ("encoder", "decoder", "discriminator")}
+    nz = data["noise"][0]
+    st.forward(data["fmri"].to(DEV), data["x"].to(DEV), nz[0].to(DEV), nz[1].to(DEV), nz[2].to(DEV))
+    st.gate(B)
+    st.backward()
+    outs = {k: v.cpu() for k, v in st.outputs().items()}
+    st.apply()
+    logs = st.logs()
+    ref = O.stage3_step(P, opts, data["fmri"], data["x"], nz, cfg_o, V, keep_grads=False)
+    assert logs["train_dis"] == ref["logs"]["train_dis"] and logs["train_dec"] == ref["logs"]["train_dec"]
+    for k in LOSS_KEYS:
+        assert _rel(logs[k], ref["logs"][k]) < 1e-3, (k, logs[k], ref["logs"][k])
+    for k in ("x_tilde", "disc_class", "disc_layer", "mus"):
+        assert _terr(outs[k], ref["fw"][k]) < 1e-2, k

@@ -216,3 +216,49 @@ class FlatGroup:
 
     def zero_grad(self):
         self.grad.zero_()
+
+
+# ------------------------------------------------------------------------------------------------
+# algorithmic FLOP counter: forward MACs x 2 per image, every layer instance counted once
+# ------------------------------------------------------------------------------------------------
+def _conv_out(n: int, k: int, s: int, p: int) -> int:
+    return (n + 2 * p - k) // s + 1
+
+
+def forward_flops(cfg: ArchConfig, n_voxels: int = 4096) -> Dict[str, float]:
+    """Per-image forward FLOPs of the sub-networks: E (Encoder), D (Decoder, one call), S (Discriminator,
+    REC+GAN counted as one pass over one image), C (CognitiveEncoder), W (WaeDiscriminator)."""
+    k, s, p = cfg.kernel_size, cfg.stride, cfg.padding
+    kk = k * k
+    h, cin, E = cfg.image_size, 3, 0.0
+    for c in cfg.encoder_channels[:3]:
+        h = _conv_out(h, k, s, p)
+        E += 2.0 * h * h * c * cin * kk
+        cin = c
+    E += 2.0 * cfg.fc_input ** 2 * cin * cfg.fc_output + 2 * 2.0 * cfg.fc_output * cfg.latent_dim
+    size = cfg.encoder_channels[2]
+    D = 2.0 * cfg.latent_dim * cfg.fc_input ** 2 * size
+    h = cfg.fc_input
+    for (ci, co), op in zip([(size, size), (size, cfg.decoder_channels[1]),
+                             (cfg.decoder_channels[1], cfg.decoder_channels[2])], cfg.output_pad_dec):
+        D += 2.0 * h * h * ci * co * kk                      # transposed conv: MACs = input pixels x Cin x Cout x taps
+        h = (h - 1) * s - 2 * p + k + (1 if op else 0)
+    D += 2.0 * h * h * cfg.decoder_channels[3] * cfg.decoder_channels[2] * 25
+    d = cfg.discrim_channels
+    h = _conv_out(cfg.image_size, 5, cfg.stride_gan, 2)
+    S = 2.0 * h * h * d[0] * 3 * 25
+    cin = d[0]
+    for i in (1, 2, 3):
+        h = _conv_out(h, k, s, p)
+        S += 2.0 * h * h * d[i] * cin * kk
+        cin = d[i]
+    S += 2.0 * cfg.fc_input_gan ** 2 * cin * cfg.fc_output_gan + 2.0 * cfg.fc_output_gan
+    C = 2.0 * n_voxels * 1024 + 2 * 2.0 * 1024 * cfg.latent_dim
+    W = 2.0 * (cfg.latent_dim * 512 + 3 * 512 * 512 + 512)
+    return dict(E=E, D=D, S=S, C=C, W=W)
+
+
+def stage1_step_flops(cfg: ArchConfig) -> float:
+    """Stage-I step = 3 x (E + 2 D + 3 S) per image (forward + wgrad + dgrad, each layer once)."""
+    f = forward_flops(cfg)
+    return 3.0 * (f["E"] + 2.0 * f["D"] + 3.0 * f["S"])

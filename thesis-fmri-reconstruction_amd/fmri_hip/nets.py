@@ -100,11 +100,12 @@ class EncoderNet:
     def all_bns(self):
         return self.bns + [self.fc_bn]
 
-    def forward(self, x16: torch.Tensor, train_stats: bool = True):
-        """x16 [B,H,W,8] fp16 -> (head32 [B,2z], ctx)."""
+    def forward(self, x16: torch.Tensor, train_stats: bool = True, updates: Optional[int] = None):
+        """x16 [B,H,W,8] fp16 -> (head32 [B,2z], ctx).  ``updates`` = number of running-stat updates this call
+        stands for (the WAE scripts run the same encoder pass two or three times per step)."""
         acts, raws, svs = [x16], [], []
         h = x16
-        upd = 1 if train_stats else 0
+        upd = (1 if train_stats else 0) if updates is None else updates
         for conv, bn in zip(self.convs, self.bns):
             raw = conv.forward(h)
             h, sv = bn.forward(raw, relu=True, updates=upd)
@@ -144,9 +145,10 @@ class CognitiveEncoderNet:
     def all_bns(self):
         return [self.fc1_bn]
 
-    def forward(self, fmri16: torch.Tensor, train_stats: bool = True):
+    def forward(self, fmri16: torch.Tensor, train_stats: bool = True, updates: Optional[int] = None):
         raw, _ = self.fc1.forward(fmri16)
-        h, sv = self.fc1_bn.forward(raw, relu=True, updates=1 if train_stats else 0)
+        upd = (1 if train_stats else 0) if updates is None else updates
+        h, sv = self.fc1_bn.forward(raw, relu=True, updates=upd)
         return self.heads.forward(h), dict(x=fmri16, raw=raw, h=h, sv=sv)
 
     def backward(self, ctx, dhead16, scale):

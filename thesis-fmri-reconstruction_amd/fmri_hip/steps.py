@@ -3,7 +3,7 @@
     Stage1Step   train/train_vgan_stage1.py:316-432   (mode 'vae-gan')
     Stage2Step   train/train_vgan_stage2.py:321-407
     Stage3Step   train/train_vgan_stage3.py:324-411
-    WaeStage1Step train/train_wae_stage1.py:259-311
+    (WAE Stage I/II/III and the Dual WAE+VAE/GAN step live in wae_steps.py)
 
 Contract: one forward -> the three gradient sets, each of its own loss w.r.t. its own
 sub-network, all evaluated at the pre-update weights -> gated optimizer steps.  The discriminator is run
@@ -188,6 +188,8 @@ class Stage1Step(_GanStepBase):
         self.opt_enc = _Optim(self.enc.group, "rmsprop", hp.lr, hp.alpha, hp.eps)
         self.opt_dec = _Optim(self.dec.group, "rmsprop", hp.lr, hp.alpha, hp.eps)
         self.opt_dis = _Optim(self.dis.group, "rmsprop", hp.lr, hp.alpha, hp.eps)
+        self.enc_updates = 1                 # encoder passes per batch in the script (BN running-stat updates)
+        self.extra_mu_decoder_pass = False   # DualStage1Step (wae_steps.py)
 
     # ---- parameters -----------------------------------------------------------------------------
     def load_recipe(self, seed: int, perturb: bool = False):
@@ -215,14 +217,19 @@ class Stage1Step(_GanStepBase):
         Z, zp = cfg.latent_dim, pad8(cfg.latent_dim)
         dev = x.device
         self.scal.zero_()
-        disc_in = torch.empty(3 * B, H, W, 8, dtype=torch.float16, device=dev)
+        # decoder groups: z (x_tilde), z_p (x_p) and -- Dual step only -- mu (wae_vgan_stage1.py:406, BN statistics)
+        G = 3 if self.extra_mu_decoder_pass else 2
+        dec_out = torch.empty((1 + G) * B, H, W, 8, dtype=torch.float16, device=dev)
+        disc_in = dec_out[:3 * B]
         images_to_nhwc(x, out=disc_in[:B])
-        head32, ectx = self.enc.forward(disc_in[:B])
-        z16 = torch.empty(2 * B, zp, dtype=torch.float16, device=dev)
+        head32, ectx = self.enc.forward(disc_in[:B], updates=self.enc_updates)
+        z16 = torch.empty(G * B, zp, dtype=torch.float16, device=dev)
         eps = eps.contiguous().float()
         lib.call("fmri_latent_fwd", _P(head32), _P(eps), B, Z, zp, _P(z16), None, _P(self._slot(S_KL)), 1)
         lib.call("fmri_rows_f32_to_f16", _P(z_p.contiguous().float()), _P(z16[B:]), B, Z, zp, 1.0)
-        _, dctx = self.dec.forward(z16, 2, out=disc_in[B:])
+        if G == 3:
+            lib.call("fmri_latent_fwd", _P(head32), None, B, Z, zp, _P(z16[2 * B:]), None, None, 0)
+        _, dctx = self.dec.forward(z16, G, out=dec_out[B:])
         feat, logit32, sctx = self.dis.forward(disc_in)
         prob, F = self._gan_losses(feat, logit32, B, disc_in[:B], disc_in[B:2 * B], H, W)
         self.fw = dict(B=B, H=H, W=W, F=F, disc_in=disc_in, head32=head32, eps=eps, ectx=ectx, dctx=dctx, sctx=sctx,
@@ -232,7 +239,8 @@ class Stage1Step(_GanStepBase):
     def gate(self, B_global: int):
         self._gate(B_global, self.fw["F"], True)
 
-    def backward(self):
+    def backward(self, extra_dmu: Optional[torch.Tensor] = None):
+        """``extra_dmu`` [B, z] fp32: an additional true-scale cotangent on the encoder means (Dual step)."""
         fw, sc, hp, cfg = self.fw, self.sc, self.hp, self.cfg
         B, H, W = fw["B"], fw["H"], fw["W"]
         Z = cfg.latent_dim
@@ -253,6 +261,8 @@ class Stage1Step(_GanStepBase):
         dhead32 = torch.empty(B, 2 * Z, dtype=torch.float32, device=dev)
         lib.call("fmri_latent_bwd", _P(fw["head32"]), _P(fw["eps"]), _P(dz), Z, 1.0, 1.0, _P(self._slot(S_NB)), B, Z,
                  1.0, None, _P(dhead32), 1)                              # = nB * dhead_true
+        if extra_dmu is not None:
+            dhead32[:, :Z].addcmul_(extra_dmu, self._slot(S_NB))            # carried at the same device factor nB
         dhead16 = self._renorm(dhead32, sc.enc, self._slot(S_NB), B * self.dd.world)   # S_NE = nB * nE
         self.enc.backward(fw["ectx"], dhead16, sc.enc)                  # grads = S_NE * true
         for n in (self.dis, self.dec, self.enc):

@@ -177,7 +177,10 @@ def test_two_rank_stage1_step_equals_single_process_global_batch():
             assert abs(logs[k] - logs1[k]) < 2e-4 * abs(logs1[k]), (rank, k, logs[k], logs1[k])
         assert logs["train_dis"] == logs1["train_dis"] and logs["train_dec"] == logs1["train_dec"]
         for k, v in g1.items():
-            assert abs(gn[k] - v) < 0.05 * v + 1e-6, (rank, k, gn[k], v)
+            # the 3-element bias gradient of the decoder's last conv is a heavily cancelling sum over 2B*64*64 fp16
+            # cotangents: its norm moves by several % with the summation split (per-rank batch) alone
+            tol = 0.15 if k == "decoder.conv.3.0.bias" else 0.05
+            assert abs(gn[k] - v) < tol * v + 1e-6, (rank, k, gn[k], v)
         for k, v in sd1.items():
             assert abs(sdn[k] - v) < 2e-3 * v + 1e-6, (rank, k, sdn[k], v)
     # both ranks hold identical parameters after the step

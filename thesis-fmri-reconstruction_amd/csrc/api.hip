@@ -145,6 +145,55 @@ int fmri_igemm(const void* in, const void* w, void* out, const float* bias, cons
         if (per * (splits - 1) >= a.cls[i].ksteps && splits > 1) return FMRI_E_BADARG;
     }
     if (maxM == 0) return FMRI_OK;
+    // unit-stride sampling, Ci % 64 == 0 -> window-resident kernel (csrc/igemm_win.hip); FMRI_WIN=off disables
+    static const char* win_env = getenv("FMRI_WIN");
+    static const bool no_win = win_env && !strcmp(win_env, "off");
+    const bool unit_any = mode == FMRI_TCONV2 || mode == FMRI_CONV_FLIP || (mode == FMRI_CONV && stride == 1);
+    if (!no_win && unit_any && bn_tile >= 64 && !out_f32 && splits == 1 && k >= 2 && k <= 5 && Hi * Wi > 1 && (Ci & 63) == 0 &&
+        (int64_t)N * Hi * Wi * Ci < 0x7fffffffLL) {
+        WinArgs p;
+        p.in = a.in; p.w = a.w; p.out = (half_t*)out; p.bias = bias; p.zero = a.zero;
+        p.N = N; p.Hi = Hi; p.Wi = Wi; p.Ci = Ci; p.Ho = Ho; p.Wo = Wo; p.CoStore = CoStore; p.Co = Co;
+        p.os = a.os; p.act = act; p.ncls = a.ncls;
+        p.nchunks = Ci / 64;
+        p.pbufs = 1;
+        int max_tiles = 0, max_slices = 0;
+        bool ok = true;
+        for (int i = 0; i < a.ncls; ++i) {
+            const IgemmClass& s = a.cls[i];
+            WinClass& d = p.cls[i];
+            d.Yc = s.Yc; d.Xc = s.Xc; d.oy0 = s.oy0; d.ox0 = s.ox0; d.T = s.T; d.TW = s.TW;
+            d.dy0 = s.dy0; d.dx0 = s.dx0; d.dstep = s.dstep; d.Kpad = s.Kpad; d.w_off = s.w_off; d.pad0 = 0;
+            const int TH = s.T / s.TW;
+            const int ey = (TH - 1) * s.dstep, ex = (s.TW - 1) * s.dstep;
+            d.dymin = s.dy0 + (ey < 0 ? ey : 0);
+            d.dxmin = s.dx0 + (ex < 0 ? ex : 0);
+            d.pw_log2 = s.Xc > 8 ? 4 : 3;
+            d.ph_log2 = (d.pw_log2 == 3 && s.Yc > 8) ? 4 : 3;
+            d.PH = 1 << d.ph_log2;
+            d.IPB = 128 >> (d.pw_log2 + d.ph_log2);
+            d.IH = d.PH + (TH - 1);
+            d.IW = (1 << d.pw_log2) + (s.TW - 1);
+            d.tiles_x = (s.Xc + (1 << d.pw_log2) - 1) >> d.pw_log2;
+            d.tiles_y = (s.Yc + d.PH - 1) >> d.ph_log2;
+            d.ntiles = s.M > 0 ? ((N + d.IPB - 1) / d.IPB) * d.tiles_y * d.tiles_x : 0;
+            d.nslice = (d.IPB * d.IH * d.IW * 8 + 255) / 256;
+            d.spt = (d.nslice + s.T - 1) / s.T;
+            d.fdTPI = make_fastdiv((uint32_t)(d.tiles_y * d.tiles_x));
+            d.fdTX = make_fastdiv((uint32_t)d.tiles_x);
+            d.fdIHW = make_fastdiv((uint32_t)(d.IH * d.IW));
+            d.fdIW = make_fastdiv((uint32_t)d.IW);
+            if (d.nslice > 8 || d.spt > 2) ok = false;
+            if (d.nslice > max_slices) max_slices = d.nslice;
+            if (d.ntiles > max_tiles) max_tiles = d.ntiles;
+        }
+        for (int i = a.ncls; i < 4; ++i) p.cls[i] = p.cls[0];
+        p.win_bytes = max_slices * 4096;
+        if (ok && max_tiles > 0) {
+            const int r = igemm_win_launch(p, max_tiles, bn_tile, copad, S(stream));
+            if (r != E_UNSUPPORTED) return r;
+        }
+    }
     // unit-stride sampling with a spatial extent -> patch-resident kernel (csrc/igemm_patch.hip)
     // Measured at the B=256 Stage-I shapes (tools/microbench_igemm.py): the patch kernel wins on the stride-1
     // (single class, 25 tap) convolutions and loses on the short-K parity classes of the transposed convolutions,

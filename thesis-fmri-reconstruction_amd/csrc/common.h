@@ -115,6 +115,34 @@ struct PatchArgs {
     PatchClass cls[4];
 };
 
+// window-resident implicit GEMM (igemm_win.hip): unit-stride sampling, Ci % 64 == 0, 128 output pixels per block
+struct WinClass {
+    int32_t Yc, Xc, oy0, ox0;
+    int32_t T, TW, dy0, dx0, dstep;
+    int32_t pw_log2, ph_log2, PH, IPB;  // window: PW = 1 << pw_log2, PH = 1 << ph_log2, PW * PH * IPB == 128
+    int32_t tiles_x, tiles_y, ntiles;   // windows per image (x, y); ntiles = ceil(N/IPB) * tiles_y * tiles_x
+    int32_t IH, IW, dymin, dxmin;       // input window rows / cols and origin offset
+    int32_t Kpad;
+    int32_t nslice, spt;                // 4 KB DMA slices per window; slices issued per tap (<= 2)
+    int32_t pad0;
+    int64_t w_off;
+    FastDiv fdTPI, fdTX, fdIHW, fdIW;
+};
+
+struct WinArgs {
+    const half_t* in;
+    const half_t* w;
+    half_t* out;
+    const float* bias;
+    const half_t* zero;
+    int32_t N, Hi, Wi, Ci;
+    int32_t Ho, Wo, CoStore, Co;
+    int32_t os, act, ncls;
+    int32_t nchunks;             // Ci / 64
+    int32_t win_bytes, pbufs;    // bytes of one LDS window buffer (multiple of 4096); 1 or 2 buffers (set at launch)
+    WinClass cls[4];
+};
+
 // weight-gradient implicit GEMM (wgrad.hip):
 //   dW[a][tap*Bc + b] (+)= sum_m P[m][a] * Q[n, y*s+dy(tap), x*s+dx(tap), b],  m = (n, y, x)
 struct WgradArgs {
@@ -135,6 +163,14 @@ struct WgradArgs {
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+// Same DMA issued from inline asm.  The compiler does not see an LDS write, so it does not put `s_waitcnt vmcnt(0)`
+// in front of every later ds_read that might alias it (which silently turns a counted-vmcnt pipeline into a drained
+// one); the caller owns the vmcnt / barrier protocol for the DMA'd bytes.  M0 is reserved (set before each use).
+__device__ __forceinline__ void glds16_raw(const void* gsrc, void* lds_dst) {
+    const uint32_t l = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_dst);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(l) : "memory");
 }
 
 __device__ __forceinline__ float act_apply(float v, int act) {

@@ -51,10 +51,11 @@ int fmri_kpad(int taps, int ci);
  * (models/vae_gan.py:18,46,79,107,119,146,156) incl. the (C,H,W) flatten order at :89,:127,:181. */
 int fmri_pack_weight(const float* src, void* dst, int64_t sa, int64_t sta, int64_t sb, int64_t stb, int A, int TA,
                      int B, int KW, int py, int px, int step, int TH, int TW, int rows_pad, int kpad, void* stream);
-/* inverse map for fp32 weight gradients: dst[...] (+)= scale * src[(ta*A+a)*ld + tb*Bp + b] */
+/* inverse map for fp32 weight gradients: dst[...] (+)= scale * sum_z src[z*slab_stride + (ta*A+a)*ld + tb*Bp + b],
+ * z < nslabs (the per-split partial results of fmri_wgrad, mode 2) */
 int fmri_unpack_grad(const float* src, float* dst, int64_t sa, int64_t sta, int64_t sb, int64_t stb, int A, int TA,
                      int B, int KW, int py, int px, int step, int TH, int TW, int ld, float scale, int accumulate,
-                     void* stream);
+                     int nslabs, int64_t slab_stride, void* stream);
 
 /* ---- contractions (MFMA) ------------------------------------------------------------------------
  * out = act(bias + contraction(in, w)); see csrc/igemm.hip.  Replaces F.conv2d / F.conv_transpose2d /
@@ -68,8 +69,13 @@ int fmri_igemm(const void* in, const void* w, void* out, const float* bias, cons
 int fmri_wgrad(const void* P, const void* Q, float* out, const void* zero16, int N, int Yc, int Xc, int A, int Hq,
                int Wq, int Bc, int k, int stride, int pad, int flip, int apad, int ba_tile, int ldo, int splits,
                int atomic, void* stream);
-/* flip = 0: Q pixel = m*stride + tap - pad.  flip = 1 (stride 1 only): Q pixel = m + pad - tap, i.e. the roles of
+/* atomic = 0: one split, plain stores.  1: atomic adds into a pre-zeroed out.  2: split z stores its partial result
+ * to out + z*apad*ldo (stride-2, 128-row, 32-channel-block geometries only -- csrc/wgrad_win.hip -- else
+ * FMRI_E_UNSUPPORTED).  For that kernel `splits` is the block budget per (128-row, 32-channel) group over the 4
+ * parity planes; the number of slabs it writes is fmri_wgrad_slabs().
+ * flip = 0: Q pixel = m*stride + tap - pad.  flip = 1 (stride 1 only): Q pixel = m + pad - tap, i.e. the roles of
  * the two activations are exchanged so that the GATHERED operand is the one with fewer channels. */
+int fmri_wgrad_slabs(int N, int Yc, int Xc, int k, int pad, int splits);
 
 /* ---- layout casts ------------------------------------------------------------------------------- */
 int fmri_nchw_to_nhwc(const float* src, void* dst, int N, int C, int HW, int Cp, void* stream);

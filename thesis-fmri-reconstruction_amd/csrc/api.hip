@@ -75,13 +75,13 @@ int fmri_pack_weight(const float* src, void* dst, int64_t sa, int64_t sta, int64
 
 int fmri_unpack_grad(const float* src, float* dst, int64_t sa, int64_t sta, int64_t sb, int64_t stb, int A, int TA,
                      int B, int KW, int py, int px, int step, int TH, int TW, int ld, float scale, int accumulate,
-                     void* stream) {
-    if (!src || !dst || A < 1 || TA < 1 || B < 1) return FMRI_E_BADARG;
+                     int nslabs, int64_t slab_stride, void* stream) {
+    if (!src || !dst || A < 1 || TA < 1 || B < 1 || nslabs < 1) return FMRI_E_BADARG;
     UnpackArgs p;
     p.src = src; p.dst = dst; p.sa = sa; p.sta = sta; p.sb = sb; p.stb = stb;
     p.A = A; p.TA = TA; p.B = B; p.Bp = pad_to(B, 8);
     p.KW = KW; p.py = py; p.px = px; p.step = step; p.TH = TH; p.TW = TW;
-    p.ld = ld; p.scale = scale; p.accumulate = accumulate;
+    p.ld = ld; p.scale = scale; p.accumulate = accumulate; p.nslabs = nslabs; p.slab_stride = slab_stride;
     if (ld < TH * TW * p.Bp) return FMRI_E_BADARG;
     return unpack_grad_launch(p, S(stream));
 }
@@ -250,6 +250,17 @@ int fmri_igemm(const void* in, const void* w, void* out, const float* bias, cons
     return igemm_launch(a, maxM, bn_tile, copad, out_f32 != 0, S(stream));
 }
 
+// number of per-split slabs fmri_wgrad(..., atomic = 2) writes for a budget of `splits` blocks per tile group
+int fmri_wgrad_slabs(int N, int Yc, int Xc, int k, int pad, int splits) {
+    (void)k; (void)pad;
+    const int ntiles = N * ((Yc + 7) / 8) * ((Xc + 7) / 8);
+    int sp = (splits < 4 ? 4 : splits) / 4;
+    if (sp > ntiles) sp = ntiles;
+    if (sp < 1) return 1;
+    const int tps = (ntiles + sp - 1) / sp;
+    return (ntiles + tps - 1) / tps;
+}
+
 int fmri_wgrad(const void* P, const void* Q, float* out, const void* zero16, int N, int Yc, int Xc, int A, int Hq,
                int Wq, int Bc, int k, int stride, int pad, int flip, int apad, int ba_tile, int ldo, int splits,
                int atomic, void* stream) {
@@ -261,8 +272,51 @@ int fmri_wgrad(const void* P, const void* Q, float* out, const void* zero16, int
     const int T = k * k;
     if (ldo % 128 || ldo < T * Bc) return FMRI_E_BADARG;
     if (splits > 1 && !atomic) return FMRI_E_BADARG;
+    if (atomic < 0 || atomic > 2) return FMRI_E_BADARG;
     const int64_t M = (int64_t)N * Yc * Xc;
     if (M < 1 || M > 0x7fffff00LL) return FMRI_E_BADARG;
+    // stride-2 sampling, >= 128 rows, 32-channel column blocks, pre-zeroed fp32 output (atomic accumulation):
+    // window-resident kernel (csrc/wgrad_win.hip).  FMRI_WGRAD_WIN=off disables.
+    static const char* ww_env = getenv("FMRI_WGRAD_WIN");
+    static const bool no_ww = ww_env && !strcmp(ww_env, "off");
+    if (!no_ww && stride == 2 && !flip && atomic && ba_tile == 128 && (Bc & 31) == 0 && Yc * Xc > 1 &&
+        (int64_t)N * Hq * Wq * Bc < 0x7fffffffLL && M * A < 0x7fffffffLL) {
+        WgradWinArgs w;
+        w.P = (const half_t*)P; w.Q = (const half_t*)Q; w.out = out; w.zero = (const half_t*)zero16;
+        w.N = N; w.Yc = Yc; w.Xc = Xc; w.A = A; w.Hq = Hq; w.Wq = Wq; w.Bc = Bc; w.pad = pad; w.TW = k; w.ldo = ldo;
+        w.slab_stride = atomic == 2 ? (int64_t)apad * ldo : 0;
+        w.a_tiles = apad / 128;
+        bool ok = true;
+        for (int par = 0; par < 2; ++par) {
+            int cnt = 0, emin = 0;
+            for (int t = 0; t < k; ++t)
+                if (((t - pad) & 1) == par) { if (!cnt) emin = t - pad; ++cnt; }
+            w.nsy[par] = w.nsx[par] = cnt;
+            w.tmin[par] = (emin - par) / 2;      // exact: emin and par have the same parity
+            if (cnt < 2 || cnt > 3) ok = false;
+        }
+        if (ok) {
+            w.tiles_y = (Yc + 7) / 8; w.tiles_x = (Xc + 7) / 8;
+            w.ntiles = N * w.tiles_y * w.tiles_x;
+            // `splits` = blocks per (row block, column block) over the 4 planes.  All planes get the same K pieces although
+            // their MFMA counts differ (9 : 6 : 6 : 4 shifts for k = 5): the blocks of one piece then walk the same
+            // pixel tiles in lockstep and share them through their XCD's L2, which measured faster than equal-MFMA
+            // pieces with diverging tile sequences.
+            int sp = (splits < 4 ? 4 : splits) / 4;
+            if (sp > w.ntiles) sp = w.ntiles;
+            const int tps = (w.ntiles + sp - 1) / sp;
+            int smax = (w.ntiles + tps - 1) / tps;
+            for (int pl = 0; pl < 4; ++pl) w.plane_tps[pl] = tps;
+            w.splits = smax;
+            // slab mode: the caller sized the output with fmri_wgrad_slabs()
+            if (atomic == 2 && smax > fmri_wgrad_slabs(N, Yc, Xc, k, pad, splits)) return FMRI_E_BADARG;
+            if (atomic == 2) smax = fmri_wgrad_slabs(N, Yc, Xc, k, pad, splits);   // every allocated slab is written
+            w.fdTPI = make_fastdiv((uint32_t)(w.tiles_y * w.tiles_x));
+            w.fdTX = make_fastdiv((uint32_t)w.tiles_x);
+            return wgrad_win_launch(w, apad, S(stream));
+        }
+    }
+    if (atomic == 2) return FMRI_E_UNSUPPORTED;      // per-split slabs exist only in the window-resident kernel
     WgradArgs a;
     a.P = (const half_t*)P; a.Q = (const half_t*)Q; a.out = out; a.zero = (const half_t*)zero16;
     a.N = N; a.Yc = Yc; a.Xc = Xc; a.A = A; a.Hq = Hq; a.Wq = Wq; a.Bc = Bc;

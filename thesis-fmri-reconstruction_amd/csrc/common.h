@@ -159,6 +159,26 @@ struct WgradArgs {
     FastDiv fdX, fdYX, fdTW, fdBc8;
 };
 
+// window-resident weight gradient for stride-2 sampling (wgrad_win.hip): the gathered operand Q is split into its
+// 4 parity planes; per plane the taps are unit shifts of one LDS-resident window
+struct WgradWinArgs {
+    const half_t* P;       // [M][A]
+    const half_t* Q;       // [N][Hq][Wq][Bc]
+    float* out;            // [Apad][ldo] fp32, column = tap*Bc + b
+    const half_t* zero;
+    int32_t N, Yc, Xc, A;
+    int32_t Hq, Wq, Bc;
+    int32_t pad, TW;                 // conv padding, taps per tap row (k)
+    int32_t tiles_y, tiles_x;        // 8x8 output-pixel tiles per image
+    int32_t ntiles, splits;          // grid.z = splits = max over planes
+    int32_t plane_tps[4];            // tiles per split of plane (py*2 + px)
+    int32_t ldo, a_tiles;            // a_tiles = 128-row blocks
+    int64_t slab_stride;             // elements between the per-split output slabs
+    int32_t nsy[2], nsx[2];          // shifts per parity (2 or 3)
+    int32_t tmin[2];                 // first plane shift per parity (same for rows and columns)
+    FastDiv fdTPI, fdTX;
+};
+
 // 16-byte global -> LDS DMA.  LDS destination = wave-uniform base + lane*16.
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -171,6 +191,20 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
 __device__ __forceinline__ void glds16_raw(const void* gsrc, void* lds_dst) {
     const uint32_t l = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_dst);
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(l) : "memory");
+}
+
+// XCD-aware block -> tile map for a (tiles_x, tiles_y) grid whose blocks with the same x share an operand tile.
+// Consecutive workgroup ids are dealt round-robin to the 8 XCDs (each has its own L2), so neighbouring ids never share
+// an L2.  Logical ids are laid out so that a run of nb/8 of them lives on one XCD, with y fastest: the blocks that
+// re-read the same A tile (and the spatially adjacent tiles that share its halo) then hit in that XCD's L2.
+// Speed only -- any bijection is correct; falls back to the identity when nb is not a multiple of 8.
+__device__ __forceinline__ void xcd_tile(int& tx, int& ty) {
+    const int gx = gridDim.x, gy = gridDim.y;
+    const int nb = gx * gy;
+    int l = blockIdx.x + gx * blockIdx.y;
+    if ((nb & 7) == 0) l = (l & 7) * (nb >> 3) + (l >> 3);
+    ty = l % gy;
+    tx = l / gy;
 }
 
 __device__ __forceinline__ float act_apply(float v, int act) {

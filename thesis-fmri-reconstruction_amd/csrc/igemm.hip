@@ -40,9 +40,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     const int icls = blockIdx.z % a.ncls;
     const int split = blockIdx.z / a.ncls;
     const IgemmClass& c = a.cls[icls];
-    const int m0 = blockIdx.x * BM;
+    int bx, by;
+    xcd_tile(bx, by);
+    const int m0 = bx * BM;
     if (m0 >= c.M) return;
-    const int co0 = blockIdx.y * BN;
+    const int co0 = by * BN;
 
     const int trow = tid >> 3;
     const int cphys = tid & 7;

@@ -33,16 +33,18 @@ __global__ __launch_bounds__(256, 2) void igemm_win_kernel(const WinArgs a) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const WinClass& c = a.cls[blockIdx.z];
-    if ((int)blockIdx.x >= c.ntiles) return;
-    const int co0 = blockIdx.y * BN;
+    int bx, by;
+    xcd_tile(bx, by);
+    if (bx >= c.ntiles) return;
+    const int co0 = by * BN;
 
     char* const win0 = smem;
     char* const wbuf0 = smem + a.pbufs * a.win_bytes;
 
     // ---- tile -> (image group, window row, window col)
     const int tpi = c.tiles_y * c.tiles_x;
-    const int grp = (int)fd_div(blockIdx.x, c.fdTPI);
-    const int trem = (int)blockIdx.x - grp * tpi;
+    const int grp = (int)fd_div((uint32_t)bx, c.fdTPI);
+    const int trem = bx - grp * tpi;
     const int tyi = (int)fd_div((uint32_t)trem, c.fdTX);
     const int txi = trem - tyi * c.tiles_x;
     const int PW = 1 << c.pw_log2;

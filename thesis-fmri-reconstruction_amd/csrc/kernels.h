@@ -22,12 +22,15 @@ struct UnpackArgs {
     int32_t ld;
     float scale;
     int32_t accumulate;
+    int32_t nslabs;        // src holds nslabs partial matrices, slab_stride elements apart; they are summed
+    int64_t slab_stride;
 };
 
 int igemm_launch(const IgemmArgs& a, int maxM, int bn_tile, int copad, bool out_f32, hipStream_t st);
 int igemm_patch_launch(PatchArgs& a, int max_tiles, int bn_tile, int copad, hipStream_t st);
 int igemm_win_launch(WinArgs& a, int max_tiles, int bn_tile, int copad, hipStream_t st);
 int wgrad_launch(const WgradArgs& a, int apad, int ba_tile, hipStream_t st);
+int wgrad_win_launch(const WgradWinArgs& a, int apad, hipStream_t st);
 
 int pack_weight_launch(const PackArgs& p, hipStream_t st);
 int unpack_grad_launch(const UnpackArgs& p, hipStream_t st);

@@ -85,7 +85,11 @@ __global__ __launch_bounds__(256) void unpack_tile_kernel(const UnpackArgs p, in
     const float* s = p.src + (int64_t)row * p.ld + b0;
     for (int e = threadIdx.x; e < run * 32; e += 256) {
         const int tb = e >> 5, bl = e & 31;
-        if (b0 + bl < p.B) t[bl * stride + tb] = s[tb * p.Bp + bl];
+        if (b0 + bl < p.B) {
+            float v = s[tb * p.Bp + bl];
+            for (int z = 1; z < p.nslabs; ++z) v += s[z * p.slab_stride + tb * p.Bp + bl];
+            t[bl * stride + tb] = v;
+        }
     }
     __syncthreads();
     float* d = p.dst + a * p.sa + ta * p.sta;
@@ -134,7 +138,9 @@ __global__ void unpack_tapinner_kernel(const UnpackArgs p) {
         for (int ty = 0; ty < p.TH; ++ty)
             for (int tx = 0; tx < p.TW; ++tx) {
                 const int t = (p.py + p.step * ty) * p.KW + (p.px + p.step * tx);
-                const float v = s[(ty * p.TW + tx) * p.Bp] * p.scale;
+                float v = s[(ty * p.TW + tx) * p.Bp];
+                for (int z = 1; z < p.nslabs; ++z) v += s[z * p.slab_stride + (ty * p.TW + tx) * p.Bp];
+                v *= p.scale;
                 if (p.accumulate) d[t] += v; else d[t] = v;
             }
     }
@@ -153,7 +159,10 @@ __global__ void unpack_grad_kernel(const UnpackArgs p) {
         const int ta = (int)r;
         const int ty = tb / p.TW, tx = tb - ty * p.TW;
         const int t = (p.py + p.step * ty) * p.KW + (p.px + p.step * tx);
-        const float v = p.src[(int64_t)(ta * p.A + a) * p.ld + tb * p.Bp + b] * p.scale;
+        const float* sp = p.src + (int64_t)(ta * p.A + a) * p.ld + tb * p.Bp + b;
+        float v = *sp;
+        for (int z = 1; z < p.nslabs; ++z) v += sp[z * p.slab_stride];
+        v *= p.scale;
         float* d = p.dst + a * p.sa + ta * p.sta + b * p.sb + t * p.stb;
         if (p.accumulate) *d += v; else *d = v;
     }

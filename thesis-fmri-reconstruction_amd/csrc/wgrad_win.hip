@@ -1,0 +1,232 @@
+// Window-resident weight gradient for stride-2 sampling (gfx950).
+//
+//   dW[a][tap*Bc + b] += sum_{m=(n,y,x)} P[m][a] * Q[n, 2y + ty - pad, 2x + tx - pad, b]          (tap = ty*k + tx)
+//
+// (Conv2d stride 2: P = dY, Q = X; ConvTranspose2d stride 2: P = X, Q = dY -- wgrad.hip's contract.)  wgrad.hip
+// streams a 64 x 128 P tile AND a gathered 64 x 128 Q tile from L2 per K-step, one Q tile per (tap, 8-channel) column
+// block, although neighbouring taps read almost the same pixels.  Here Q is viewed as its four parity planes
+// Qp[r][c] = Q[2r+py][2c+px]: for the taps of one parity, tap (ty, tx) of output pixel (y, x) is plane pixel
+// (y + t_y, x + t_x) with t in {-1, 0, 1} -- a UNIT shift.  A block owns 128 rows a, 32 channels b and ALL (2..3)^2
+// shifts of one plane; per K-step (an 8x8 tile of output pixels) it DMAs the P tile (16 KB) and the (8+2)^2-pixel
+// window of the plane (6.4 KB) once and runs 8 * shifts MFMAs per wave from them: 22 KB per 4.7 MFLOP instead of
+// 32 KB per 2.1 MFLOP.  The MFMA K index is the pixel, so both operands are read with transposing LDS reads
+// (ds_read_b64_tr_b16); the window fragments of a shift are the same reads at a compile-time byte offset.
+#include "kernels.h"
+
+namespace fmri {
+
+// P tile: 64 m-rows x 256 B, swizzled exactly like wgrad.hip.  Window: WH x WW pixels x 64 B, linear.
+template <int NSY, int NSX>
+__device__ __forceinline__ void wgrad_win_body(const WgradWinArgs& a, char* smem, int py, int px, int a_tile,
+                                               int b_tile, int split) {
+    constexpr int WH = 8 + NSY - 1, WW = 8 + NSX - 1;
+    constexpr int P_BYTES = 64 * 256;
+    constexpr int W_BYTES = ((WH * WW * 64 + 1023) / 1024) * 1024;
+    constexpr int STAGE = P_BYTES + W_BYTES;
+    constexpr int NS = NSY * NSX;
+    constexpr int TA = 4;             // 2 x 2 waves: wave tile = 64 rows a x 16 channels b
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int a0 = a_tile * 128;
+    const int b0 = b_tile * 32;
+    const int tminy = a.tmin[py], tminx = a.tmin[px];
+
+    // ---- P source: thread loads the 16-B chunk `clog` of rows trow + 16 i (i < 4), wgrad.hip's swizzle
+    const int trow = tid >> 4;
+    const int cphys = tid & 15;
+    const int fsw = (((trow & 3) | (((trow >> 3) & 1) << 2)) << 1);
+    const int clog = cphys ^ fsw;
+    const bool p_on = a0 + clog * 8 < a.A;
+    const half_t* pbase = a.P + a0 + clog * 8;
+
+    // ---- window source: units u = tid, tid + 256 -> window pixel u >> 2, channels 8 * (u & 3)
+    int wj[2], wi[2];
+    bool won[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int u = tid + 256 * e;
+        const int pix = u >> 2;
+        won[e] = pix < WH * WW;
+        wj[e] = pix / WW;
+        wi[e] = pix - wj[e] * WW;
+    }
+    const half_t* qbase = a.Q + b0 + (tid & 3) * 8;
+
+    // the K range (8x8 pixel tiles) is cut into equal pieces, the same for every plane (see api.hip)
+    const int tps = a.plane_tps[py * 2 + px];
+    const int t0 = split * tps;
+    int t1 = t0 + tps;
+    if (t1 > a.ntiles) t1 = a.ntiles;
+    const int nsteps = t1 > t0 ? t1 - t0 : 0;
+    if (nsteps == 0 && a.slab_stride == 0) return;
+    const int tpi = a.tiles_y * a.tiles_x;
+
+    auto stage_load = [&](int buf, int t) {
+        // tile -> (image, tile row, tile col): wave-uniform
+        const int n = (int)fd_div((uint32_t)t, a.fdTPI);
+        const int trem = t - n * tpi;
+        const int tyi = (int)fd_div((uint32_t)trem, a.fdTX);
+        const int txi = trem - tyi * a.tiles_x;
+        const int y0 = tyi * 8, x0 = txi * 8;
+        char* dstP = smem + buf * STAGE + wave * (4 * 256);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = trow + 16 * i;
+            const int y = y0 + (r >> 3), x = x0 + (r & 7);
+            const bool ok = p_on && y < a.Yc && x < a.Xc;
+            const half_t* ps = ok ? pbase + (int64_t)((n * a.Yc + y) * a.Xc + x) * a.A : a.zero;
+            glds16_raw(ps, dstP + i * (16 * 256));
+        }
+        char* dstW = smem + buf * STAGE + P_BYTES + wave * 1024;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if (e * 4096 + wave * 1024 < W_BYTES) {      // wave-uniform
+                const int iy = 2 * (y0 + tminy + wj[e]) + py;
+                const int ix = 2 * (x0 + tminx + wi[e]) + px;
+                const bool ok = won[e] && (unsigned)iy < (unsigned)a.Hq && (unsigned)ix < (unsigned)a.Wq;
+                const half_t* qs = ok ? qbase + (int64_t)((n * a.Hq + iy) * a.Wq + ix) * a.Bc : a.zero;
+                glds16_raw(qs, dstW + e * 4096);
+            }
+        }
+    };
+
+    f4 acc[NS][TA];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int i = 0; i < TA; ++i) acc[s][i] = (f4){0.f, 0.f, 0.f, 0.f};
+
+    const int wa = wave >> 1, wb = wave & 1;
+    // transposing-read lane roles (wgrad.hip): group g = lane>>4 covers K rows 8g..8g+7 of a 32-row half; lane 4q+p of
+    // the group addresses row q (and q+4), columns 4p..4p+3 of a 16-column block
+    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const int fr = ((q | ((g & 1) << 2)) << 1);
+    const int rowoff = (8 * g + q) * 256 + (p & 1) * 8;
+    // window: K row r = 32 ks + 8 g + q (+4) is tile pixel (4 ks + g, q (+4)); shift (sy, sx) adds (sy*WW + sx) pixels
+    const int woff = (g * WW + q) * 64 + wb * 32 + p * 8;
+
+    auto compute = [&](int buf) {
+        const char* Ps = smem + buf * STAGE;
+        const char* Ws = Ps + P_BYTES + woff;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            h8 af[TA];
+#pragma unroll
+            for (int ta = 0; ta < TA; ++ta) {
+                const int blk = wa * 4 + ta;
+                const int ch = (2 * blk + (p >> 1)) ^ fr;
+                const char* ad = Ps + ks * (32 * 256) + rowoff + ch * 16;
+                union { s4v s[2]; h8 h; } u;
+                u.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(ad));
+                u.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(ad + 4 * 256));
+                af[ta] = u.h;
+            }
+#pragma unroll
+            for (int sy = 0; sy < NSY; ++sy)
+#pragma unroll
+                for (int sx = 0; sx < NSX; ++sx) {
+                    const char* ad = Ws + ((ks * 4 + sy) * WW + sx) * 64;
+                    union { s4v s[2]; h8 h; } u;
+                    u.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(ad));
+                    u.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(ad + 4 * 64));
+#pragma unroll
+                    for (int ta = 0; ta < TA; ++ta)
+                        acc[sy * NSX + sx][ta] =
+                            __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ta], u.h, acc[sy * NSX + sx][ta], 0, 0, 0);
+                }
+        }
+    };
+
+    // 3-stage ring: the DMAs of step it+2 are issued at the top of step it, so a stage has two full steps to land.
+    // Every wave issues the same number of DMA instructions per stage (4 + 2, wave 3: 4 + 1 when the window ends
+    // inside its slice), so "all but the newest stage" is a constant s_waitcnt vmcnt(NW) per wave.
+    const bool short_wave = 4096 + wave * 1024 >= W_BYTES;
+    if (nsteps > 0) stage_load(0, t0);
+    if (nsteps > 1) stage_load(1, t0 + 1);
+    int cur = 0, nxt = 2;
+    for (int it = 0; it < nsteps; ++it) {
+        if (it + 1 < nsteps) {
+            if (short_wave) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        // raw barrier (a __syncthreads() would drain vmcnt): stage `cur` has landed for every wave, and every wave
+        // is done reading stage `nxt` (it was the current stage of step it-1)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (it + 2 < nsteps) stage_load(nxt, t0 + it + 2);
+        compute(cur);
+        if (++cur == 3) cur = 0;
+        if (++nxt == 3) nxt = 0;
+    }
+
+    // D[i = a][j = b]: lane owns channel b (lane&15), rows (lane>>4)*4 .. +3; column of shift (sy, sx) = tap*Bc + b.
+    // slab_stride != 0: every split writes its own fp32 slab with plain stores (each slab element is written exactly
+    // once: the four planes cover all taps) and fmri_unpack_grad sums the slabs -- no atomics, no pre-zeroed buffer.
+    // slab_stride == 0 (many splits over a small matrix): atomic adds into one pre-zeroed matrix.
+    const int bcol = b0 + wb * 16 + (lane & 15);
+    if (bcol >= a.Bc) return;
+    float* const slab = a.out + (int64_t)split * a.slab_stride;
+#pragma unroll
+    for (int sy = 0; sy < NSY; ++sy)
+#pragma unroll
+        for (int sx = 0; sx < NSX; ++sx) {
+            const int ty = 2 * (tminy + sy) + py + a.pad;
+            const int tx = 2 * (tminx + sx) + px + a.pad;
+            const int col = (ty * a.TW + tx) * a.Bc + bcol;
+#pragma unroll
+            for (int ta = 0; ta < TA; ++ta) {
+                const int arow = a0 + wa * 64 + ta * 16 + (lane >> 4) * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float* o = slab + (int64_t)(arow + r) * a.ldo + col;
+                    if (a.slab_stride) *o = acc[sy * NSX + sx][ta][r];
+                    else atomicAdd(o, acc[sy * NSX + sx][ta][r]);
+                }
+            }
+        }
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad_win_kernel(const WgradWinArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // XCD-aware block -> work map.  Consecutive workgroup ids are dealt round-robin to the 8 XCDs (each with its own
+    // L2); the blocks that read the same P tiles and Q windows at the same time -- all (column block, plane, row
+    // block) combinations of one K split -- get consecutive LOGICAL ids, and logical ids are laid out so that a run of
+    // gridDim.x/8 of them shares one XCD: every tile is then fetched from HBM once per XCD-resident group and the
+    // other 15..31 readers hit in that XCD's L2.  (Speed only: any mapping is correct.)
+    const int nb = gridDim.x;
+    int logical = blockIdx.x;
+    if ((nb & 7) == 0) logical = (logical & 7) * (nb >> 3) + (logical >> 3);
+    const int nbt = a.Bc >> 5;                 // 32-channel column blocks
+    const int per_split = nbt * 4 * a.a_tiles;
+    const int split = logical / per_split;
+    int rem = logical - split * per_split;
+    const int b_tile = rem % nbt;
+    rem /= nbt;
+    const int plane = rem & 3;
+    const int a_tile = rem >> 2;
+    const int py = plane >> 1, px = plane & 1;
+    const int nsy = a.nsy[py], nsx = a.nsx[px];
+    if (nsy == 3 && nsx == 3) wgrad_win_body<3, 3>(a, smem, py, px, a_tile, b_tile, split);
+    else if (nsy == 3 && nsx == 2) wgrad_win_body<3, 2>(a, smem, py, px, a_tile, b_tile, split);
+    else if (nsy == 2 && nsx == 3) wgrad_win_body<2, 3>(a, smem, py, px, a_tile, b_tile, split);
+    else wgrad_win_body<2, 2>(a, smem, py, px, a_tile, b_tile, split);
+}
+
+int wgrad_win_launch(const WgradWinArgs& a, int apad, hipStream_t st) {
+    dim3 grid((a.Bc / 32) * a.a_tiles * 4 * a.splits);
+    const int lds = 3 * (64 * 256 + 7 * 1024);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)wgrad_win_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(wgrad_win_kernel, grid, dim3(256), lds, st, a);
+    return hipGetLastError() == hipSuccess ? OK : E_LAUNCH;
+}
+
+}  // namespace fmri

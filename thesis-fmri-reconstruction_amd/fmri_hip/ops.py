@@ -11,6 +11,8 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import List, Optional, Tuple
 
+import os
+
 import torch
 
 from . import lib
@@ -135,8 +137,9 @@ PROFILE = None
 def run_igemm(x, pw: PackedWeight, out, bias, N, Hi, Wi, Ci, Ho, Wo, CoStore, Co, k, stride, pad, mode, act, out_f32,
               splits, slab_stride, tile, flops=0.0):
     w = pw.get()
-    prof = (PROFILE is not None and tile == 128 and not out_f32 and Ci % 64 == 0
-            and not (mode != MODE_TCONV2 and stride == 1 and Hi * Wi > 1 and 2 <= k <= 5))   # patch-kernel routing
+    # unit-stride geometries (transposed-conv classes, stride-1 convs) are routed to igemm_win / igemm_patch (api.hip)
+    unit = (mode == MODE_TCONV2 or stride == 1) and Hi * Wi > 1 and 2 <= k <= 5
+    prof = PROFILE is not None and tile == 128 and not out_f32 and Ci % 64 == 0 and not unit
     if prof:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -152,6 +155,22 @@ def run_wgrad(P, Q, N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad, flip=0):
     ba = tile_for(A)
     apad = ceil_to(A, ba)
     ldo = ceil_to(k * k * Bc, 128)
+    if (stride == 2 and not flip and ba == 128 and Bc % 32 == 0 and Yc * Xc > 1 and k == 5 and pad == 2
+            and os.environ.get("FMRI_WGRAD_WIN") != "off"):
+        # window-resident kernel (csrc/wgrad_win.hip): blocks = 32-channel column blocks x 128-row blocks x 4 parity
+        # planes x splits over the 8x8 pixel tiles; every split stores its own slab, unpack_grad sums them
+        groups = (Bc // 32) * (apad // 128)
+        target = int(os.environ.get("FMRI_WW_BLOCKS", "512"))          # 2 resident blocks per CU
+        splits = max(4, target // groups)                               # block budget per group over the 4 planes
+        nslabs = lib.load().fmri_wgrad_slabs(N, Yc, Xc, k, pad, splits)
+        slabs = nslabs <= int(os.environ.get("FMRI_WW_SLABS", "24"))   # few splits: per-split slabs, else atomics
+        if slabs:
+            out = torch.empty(nslabs, apad, ldo, dtype=torch.float32, device=P.device)
+        else:
+            out = torch.zeros(apad, ldo, dtype=torch.float32, device=P.device)
+        lib.call("fmri_wgrad", _P(P), _P(Q), _P(out), _P(zero_page(P.device)), N, Yc, Xc, A, Hq, Wq, Bc, k, stride,
+                 pad, flip, apad, ba, ldo, splits, 2 if slabs else 1)
+        return out, ldo
     tiles = (ldo // 128) * (apad // ba)
     steps = (N * Yc * Xc + 63) // 64
     splits = 1
@@ -168,8 +187,10 @@ def run_wgrad(P, Q, N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad, flip=0):
 
 
 def unpack_grad(packed, grad_view, sp: PackSpec, ld: int, scale: float):
+    """packed: [rows][ld] or [nslabs][rows][ld] (per-split partial results, summed here)."""
+    nslabs = packed.shape[0] if packed.dim() == 3 else 1
     lib.call("fmri_unpack_grad", _P(packed), _P(grad_view), sp.sa, sp.sta, sp.sb, sp.stb, sp.A, sp.TA, sp.B, sp.KW,
-             sp.py, sp.px, sp.step, sp.TH, sp.TW, ld, float(scale), 1)
+             sp.py, sp.px, sp.step, sp.TH, sp.TW, ld, float(scale), 1, nslabs, packed.shape[-2] * packed.shape[-1])
 
 
 # ------------------------------------------------------------------------------------------------

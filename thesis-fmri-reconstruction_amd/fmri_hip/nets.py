@@ -339,30 +339,40 @@ class DiscriminatorNet:
                 if s["train"]:
                     self.convs[li].wgrad(ctx["acts"][li], rows(d, si), s["scale"])
             _, hi, wi, _ = ctx["acts"][li].shape
-            dact = self.convs[li].dgrad(d, hi, wi)
             if li > 0:
+                dact = self.convs[li].dgrad(d, hi, wi)
                 dn = torch.empty_like(dact)
                 for si, s in enumerate(streams):
                     self.bns[li - 1].backward(ctx["raws"][li - 1], rows(dact, si), ctx["svs"][li - 1], True,
                                               s["scale"] if s["train"] else None, out=rows(dn, si))
                 d = dn
-            else:
-                d = dact
-        # conv0: bias + ReLU
+        # conv1 data gradient, conv0 (bias + ReLU).  Below the last BatchNorm the images are independent, so a stream
+        # that does not train the discriminator only needs the rows whose image gradient is wanted.
         a0 = ctx["acts"][0]
-        dpre = torch.empty_like(d)
+        _, hi, wi, _ = a0.shape
+        full = slice(0, n3)
+        need = [full if s["train"] else (img_rows if (img_rows is not None and s["img"]) else None) for s in streams]
+        if all(nd == full for nd in need):
+            dact = self.convs[0].dgrad(d, hi, wi)
+            dacts = [rows(dact, si) for si in range(S)]
+        else:
+            dacts = [None if nd is None else self.convs[0].dgrad(rows(d, si)[nd], hi, wi) for si, nd in enumerate(need)]
         outs = []
         for si, s in enumerate(streams):
+            if need[si] is None:
+                outs.append(None)
+                continue
             colsum = None
             if s["train"]:
                 colsum = torch.empty(2 * self.c0.coutp, dtype=torch.float32, device=d.device)
-            act_backward(a0, rows(d, si), ACT_RELU, colsum, out=rows(dpre, si))
+            dpre = act_backward(a0[need[si]], dacts[si], ACT_RELU, colsum)
             if s["train"]:
                 self.c0.bg.add_(colsum[:self.c0.cout], alpha=1.0 / s["scale"])
-                self.c0.wgrad(ctx["x"], rows(dpre, si), s["scale"])
+                self.c0.wgrad(ctx["x"], dpre, s["scale"])
             if img_rows is not None and s["img"]:
-                _, hi, wi, _ = ctx["x"].shape
-                outs.append(self.c0.dgrad(rows(dpre, si)[img_rows].contiguous(), hi, wi))
+                _, xh, xw, _ = ctx["x"].shape
+                sub = dpre[img_rows] if need[si] == full else dpre
+                outs.append(self.c0.dgrad(sub.contiguous(), xh, xw))
             else:
                 outs.append(None)
         res = [None, None]

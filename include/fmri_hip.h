@@ -94,12 +94,14 @@ int64_t fmri_bn_ws_floats(int M, int C);
 int fmri_bn_stats(const void* x, int M, int C, float* sums2C, float* ws, int64_t ws_floats, void* stream);
 int fmri_bn_finalize(const float* sums2C, int C, float count, const float* gamma, const float* beta, float eps,
                      float momentum, int updates, float* running_mean, float* running_var, float* mean, float* rstd,
-                     float* scale, float* shift, void* stream);
+                     float* scale, float* shift, int64_t* num_batches_tracked /* += updates, may be NULL */,
+                     void* stream);
 int fmri_bn_apply(const void* x, void* y, int M, int C, const float* scale, const float* shift, int relu,
                   void* stream);
 int fmri_bn_bwd_reduce(const void* x, const void* dy, int M, int C, const float* mean, const float* rstd,
                        const float* gamma, const float* beta, int relu, float* sums2C, float* ws,
-                       int64_t ws_floats, void* stream);
+                       int64_t ws_floats, float* dbeta /* += gscale * sums[0..C), may be NULL */,
+                       float* dgamma /* += gscale * sums[C..2C), may be NULL */, float gscale, void* stream);
 int fmri_bn_bwd_apply(const void* x, const void* dy, void* dx, int M, int C, float count, const float* mean,
                       const float* rstd, const float* gamma, const float* beta, int relu, const float* sums2C,
                       void* stream);

@@ -372,10 +372,10 @@ int fmri_bn_stats(const void* x, int M, int C, float* sums2C, float* ws, int64_t
 }
 int fmri_bn_finalize(const float* sums2C, int C, float count, const float* gamma, const float* beta, float eps,
                      float momentum, int updates, float* running_mean, float* running_var, float* mean, float* rstd,
-                     float* scale, float* shift, void* stream) {
+                     float* scale, float* shift, int64_t* num_batches_tracked, void* stream) {
     if (!sums2C || !gamma || !beta || !mean || !rstd || !scale || !shift) return FMRI_E_BADARG;
     return bn_finalize_launch(sums2C, C, count, gamma, beta, eps, momentum, updates, running_mean, running_var, mean,
-                              rstd, scale, shift, S(stream));
+                              rstd, scale, shift, (long long*)num_batches_tracked, S(stream));
 }
 int fmri_bn_apply(const void* x, void* y, int M, int C, const float* scale, const float* shift, int relu,
                   void* stream) {
@@ -384,10 +384,10 @@ int fmri_bn_apply(const void* x, void* y, int M, int C, const float* scale, cons
 }
 int fmri_bn_bwd_reduce(const void* x, const void* dy, int M, int C, const float* mean, const float* rstd,
                        const float* gamma, const float* beta, int relu, float* sums2C, float* ws,
-                       int64_t ws_floats, void* stream) {
+                       int64_t ws_floats, float* dbeta, float* dgamma, float gscale, void* stream) {
     if (!x || !dy || !sums2C || (C & 7)) return FMRI_E_BADARG;
     return bn_bwd_reduce_launch((const half_t*)x, (const half_t*)dy, M, C, mean, rstd, gamma, beta, relu, sums2C, ws,
-                                ws_floats, S(stream));
+                                ws_floats, dbeta, dgamma, gscale, S(stream));
 }
 int fmri_bn_bwd_apply(const void* x, const void* dy, void* dx, int M, int C, float count, const float* mean,
                       const float* rstd, const float* gamma, const float* beta, int relu, const float* sums2C,

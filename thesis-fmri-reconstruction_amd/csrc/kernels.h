@@ -47,10 +47,10 @@ int64_t bn_ws_floats(int M, int C);
 int bn_stats_launch(const half_t* x, int M, int C, float* sums, float* ws, int64_t ws_floats, hipStream_t st);
 int bn_bwd_reduce_launch(const half_t* x, const half_t* dy, int M, int C, const float* mean, const float* rstd,
                          const float* gamma, const float* beta, int relu, float* sums, float* ws, int64_t ws_floats,
-                         hipStream_t st);
+                         float* dbeta, float* dgamma, float gscale, hipStream_t st);
 int bn_finalize_launch(const float* sums, int C, float count, const float* gamma, const float* beta, float eps,
                        float momentum, int updates, float* rm, float* rv, float* mean, float* rstd, float* scale,
-                       float* shift, hipStream_t st);
+                       float* shift, long long* nbt, hipStream_t st);
 int bn_apply_launch(const half_t* x, half_t* y, int M, int C, const float* scale, const float* shift, int relu,
                     hipStream_t st);
 int bn_bwd_apply_launch(const half_t* x, const half_t* dy, half_t* dx, int M, int C, float count, const float* mean,

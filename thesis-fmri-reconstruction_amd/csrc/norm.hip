@@ -132,8 +132,11 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const half_t* __restrict
 
 // sums[i] = sum_p part[p][i], i < n (n = 2*C).  A block folds 32 columns with 8 row groups (4 loads in
 // flight per thread): the partial matrix is small but a single serial chain per column is latency bound.
+// Optionally accumulates the folded sums into parameter gradients (BN backward: g0 += gscale * sums[0..C) = d beta,
+// g1 += gscale * sums[C..2C) = d gamma) -- one writer per element, no atomics.
 __global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restrict__ part, int nparts, int n,
-                                                            float* __restrict__ sums) {
+                                                            float* __restrict__ sums, float* __restrict__ g0,
+                                                            float* __restrict__ g1, float gscale) {
     __shared__ float red[8][33];
     const int cx = threadIdx.x & 31, gy = threadIdx.x >> 5;
     const int i = blockIdx.x * 32 + cx;
@@ -155,6 +158,9 @@ __global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restr
 #pragma unroll
         for (int r = 0; r < 8; ++r) s += red[r][cx];
         sums[i] = s;
+        const int C = n >> 1;
+        if (g0 && i < C) g0[i] += gscale * s;
+        if (g1 && i >= C) g1[i - C] += gscale * s;
     }
 }
 
@@ -163,8 +169,10 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, int C, float 
                                    const float* __restrict__ beta, float eps, float momentum, int updates,
                                    float* __restrict__ running_mean, float* __restrict__ running_var,
                                    float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                   float* __restrict__ scale_out, float* __restrict__ shift_out) {
+                                   float* __restrict__ scale_out, float* __restrict__ shift_out,
+                                   long long* __restrict__ nbt) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && nbt && updates > 0) *nbt += updates;      // num_batches_tracked
     if (c >= C) return;
     const float mean = sums[c] / count;
     float var = sums[C + c] / count - mean * mean;
@@ -262,7 +270,8 @@ int64_t bn_ws_floats(int M, int C) {
 template <int MODE>
 static int reduce_launch(const half_t* x, const half_t* dy, half_t* dout, int M, int C, const float* mean,
                          const float* rstd, const float* gamma, const float* beta, int flag, float* sums, float* ws,
-                         int64_t ws_floats, hipStream_t st) {
+                         int64_t ws_floats, hipStream_t st, float* g0 = nullptr, float* g1 = nullptr,
+                         float gscale = 0.f) {
     int max_gy = 1 << 30;
     if (sums) {
         if (!ws || ws_floats < 2 * (int64_t)C) return E_WORKSPACE;
@@ -273,7 +282,8 @@ static int reduce_launch(const half_t* x, const half_t* dy, half_t* dout, int M,
                        mean, rstd, gamma, beta, flag, sums ? ws : (float*)nullptr);
     if (sums) {
         const int n = 2 * C;
-        hipLaunchKernelGGL(fold_partials_kernel, dim3((n + 31) / 32), dim3(256), 0, st, ws, g.gy, n, sums);
+        hipLaunchKernelGGL(fold_partials_kernel, dim3((n + 31) / 32), dim3(256), 0, st, ws, g.gy, n, sums, g0, g1,
+                           gscale);
     }
     return LAUNCH_OK();
 }
@@ -284,8 +294,9 @@ int bn_stats_launch(const half_t* x, int M, int C, float* sums, float* ws, int64
 }
 int bn_bwd_reduce_launch(const half_t* x, const half_t* dy, int M, int C, const float* mean, const float* rstd,
                          const float* gamma, const float* beta, int relu, float* sums, float* ws, int64_t ws_floats,
-                         hipStream_t st) {
-    return reduce_launch<1>(x, dy, nullptr, M, C, mean, rstd, gamma, beta, relu, sums, ws, ws_floats, st);
+                         float* dbeta, float* dgamma, float gscale, hipStream_t st) {
+    return reduce_launch<1>(x, dy, nullptr, M, C, mean, rstd, gamma, beta, relu, sums, ws, ws_floats, st, dbeta, dgamma,
+                            gscale);
 }
 // colsum may be null (then no reduction is performed); colsum gets [2][C] (second half unused)
 int act_bwd_launch(const half_t* y, const half_t* dy, half_t* dpre, int M, int C, int act, float* colsum, float* ws,
@@ -294,9 +305,9 @@ int act_bwd_launch(const half_t* y, const half_t* dy, half_t* dpre, int M, int C
 }
 int bn_finalize_launch(const float* sums, int C, float count, const float* gamma, const float* beta, float eps,
                        float momentum, int updates, float* rm, float* rv, float* mean, float* rstd, float* scale,
-                       float* shift, hipStream_t st) {
+                       float* shift, long long* nbt, hipStream_t st) {
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, C, count, gamma, beta, eps,
-                       momentum, updates, rm, rv, mean, rstd, scale, shift);
+                       momentum, updates, rm, rv, mean, rstd, scale, shift, nbt);
     return LAUNCH_OK();
 }
 static RowGeom stream_geometry(int M, int C) {

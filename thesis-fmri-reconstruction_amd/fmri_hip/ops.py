@@ -451,10 +451,9 @@ class BatchNorm:
             self._running_in()
         lib.call("fmri_bn_finalize", _P(sums), C, count, _P(gamma), _P(beta), 1e-5, 0.9, updates,
                  _P(rm) if updates > 0 else None, _P(rv) if updates > 0 else None, _P(sv.mean), _P(sv.rstd),
-                 _P(sv.scale), _P(sv.shift))
+                 _P(sv.scale), _P(sv.shift), _P(self.nbt) if updates > 0 else None)
         if updates > 0:
             self._running_out()
-            self.nbt += updates
         if out is None:
             out = torch.empty_like(raw)
         lib.call("fmri_bn_apply", _P(x2), _P(out), M, C, _P(sv.scale), _P(sv.shift), 1 if relu else 0)
@@ -484,9 +483,13 @@ class BatchNorm:
         gamma, beta, _, _ = self._params()
         sums = torch.empty(2, C, dtype=torch.float32, device=raw.device)
         ws = _reduce_ws(M, C, raw.device)
+        # gamma/beta gradients come from the LOCAL sums (the SUM all-reduce of the gradients adds the other ranks); the
+        # fold kernel of the reduction accumulates them, the permuted (C,H,W)-ordered BN1d needs the scatter kernel
+        direct = param_scale is not None and not self.perm
         lib.call("fmri_bn_bwd_reduce", _P(x2), _P(g2), M, C, _P(sv.mean), _P(sv.rstd), _P(gamma), _P(beta),
-                 1 if relu else 0, _P(sums), _P(ws), ws.numel())
-        if param_scale is not None:       # local sums: the gradient all-reduce (SUM) adds the other ranks
+                 1 if relu else 0, _P(sums), _P(ws), ws.numel(), _P(self.gbeta) if direct else None,
+                 _P(self.ggamma) if direct else None, (1.0 / param_scale) if direct else 0.0)
+        if param_scale is not None and self.perm:
             self.accumulate_param_grads(sums, param_scale)
         if self.reducer is not None:
             self.reducer(sums)

@@ -51,6 +51,14 @@ int fmri_kpad(int taps, int ci);
  * (models/vae_gan.py:18,46,79,107,119,146,156) incl. the (C,H,W) flatten order at :89,:127,:181. */
 int fmri_pack_weight(const float* src, void* dst, int64_t sa, int64_t sta, int64_t sb, int64_t stb, int A, int TA,
                      int B, int KW, int py, int px, int step, int TH, int TW, int rows_pad, int kpad, void* stream);
+/* Batched fmri_pack_weight: a device-resident table of rows (filled on the host with fmri_pack_entry_fill, which
+ * returns the number of blocks of the row, 0 = not eligible, use fmri_pack_weight) repacked by ONE launch --
+ * what a sub-network needs after its optimizer step. */
+int fmri_pack_entry_bytes(void);
+int fmri_pack_entry_fill(void* host_entry, const float* src, void* dst, int64_t sa, int64_t sta, int64_t sb,
+                         int64_t stb, int A, int TA, int B, int KW, int py, int px, int step, int TH, int TW,
+                         int rows_pad, int kpad, int tile_begin);
+int fmri_pack_weight_batch(const void* table_dev, int n, int total_tiles, void* stream);
 /* inverse map for fp32 weight gradients: dst[...] (+)= scale * sum_z src[z*slab_stride + (ta*A+a)*ld + tb*Bp + b],
  * z < nslabs (the per-split partial results of fmri_wgrad, mode 2) */
 int fmri_unpack_grad(const float* src, float* dst, int64_t sa, int64_t sta, int64_t sb, int64_t stb, int A, int TA,

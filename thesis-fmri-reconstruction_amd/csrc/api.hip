@@ -73,6 +73,33 @@ int fmri_pack_weight(const float* src, void* dst, int64_t sa, int64_t sta, int64
     return pack_weight_launch(p, S(stream));
 }
 
+int fmri_pack_entry_bytes(void) { return (int)sizeof(PackEntry); }
+
+// Fills one host-side table row; returns the number of blocks the row occupies (tile_begin of the next row =
+// tile_begin + that), 0 if this weight/orientation is not eligible for the batched kernel, < 0 on bad arguments.
+int fmri_pack_entry_fill(void* host_entry, const float* src, void* dst, int64_t sa, int64_t sta, int64_t sb,
+                         int64_t stb, int A, int TA, int B, int KW, int py, int px, int step, int TH, int TW,
+                         int rows_pad, int kpad, int tile_begin) {
+    if (!host_entry || !src || !dst || A < 1 || TA < 1 || B < 1 || TH < 1 || TW < 1) return FMRI_E_BADARG;
+    PackEntry e;
+    memset(&e, 0, sizeof(e));
+    PackArgs& p = e.p;
+    p.src = src; p.dst = (half_t*)dst; p.sa = sa; p.sta = sta; p.sb = sb; p.stb = stb;
+    p.A = A; p.TA = TA; p.B = B; p.Bp = pad_to(B, 8);
+    p.KW = KW; p.py = py; p.px = px; p.step = step; p.TH = TH; p.TW = TW;
+    p.rows_pad = rows_pad; p.kpad = kpad;
+    if (rows_pad < TA * A || kpad < TH * TW * p.Bp) return FMRI_E_BADARG;
+    const int tiles = pack_tile_count(p, &e.run);
+    e.tile_begin = tile_begin;
+    memcpy(host_entry, &e, sizeof(e));
+    return tiles;
+}
+
+int fmri_pack_weight_batch(const void* table_dev, int n, int total_tiles, void* stream) {
+    if (!table_dev || n < 0 || total_tiles < 0) return FMRI_E_BADARG;
+    return pack_batch_launch((const PackEntry*)table_dev, n, total_tiles, S(stream));
+}
+
 int fmri_unpack_grad(const float* src, float* dst, int64_t sa, int64_t sta, int64_t sb, int64_t stb, int A, int TA,
                      int B, int KW, int py, int px, int step, int TH, int TW, int ld, float scale, int accumulate,
                      int nslabs, int64_t slab_stride, void* stream) {

@@ -13,6 +13,12 @@ struct PackArgs {
     int32_t rows_pad, kpad;        // destination matrix [rows_pad][kpad]
 };
 
+struct PackEntry {      // one row of the device-resident table of fmri_pack_weight_batch
+    PackArgs p;
+    int32_t run;
+    int32_t tile_begin;
+};
+
 struct UnpackArgs {
     const float* src;      // packed [rows][ld]
     float* dst;            // reference layout
@@ -34,6 +40,8 @@ int wgrad_win_launch(const WgradWinArgs& a, int apad, hipStream_t st);
 
 int pack_weight_launch(const PackArgs& p, hipStream_t st);
 int unpack_grad_launch(const UnpackArgs& p, hipStream_t st);
+int pack_tile_count(const PackArgs& p, int* run_out);
+int pack_batch_launch(const PackEntry* tab, int n, int total_tiles, hipStream_t st);
 int nchw_to_nhwc_launch(const float* s, half_t* d, int N, int C, int HW, int Cp, hipStream_t st);
 int nhwc_to_nchw_launch(const half_t* s, float* d, int N, int C, int HW, int Cp, float scale, hipStream_t st);
 int rows_f32_to_f16_launch(const float* s, half_t* d, int M, int C, int Cp, float scale, hipStream_t st);

@@ -75,6 +75,42 @@ __global__ __launch_bounds__(256) void pack_tile_kernel(const PackArgs p, int ru
     }
 }
 
+// Batched form of pack_tile_kernel: one launch repacks every (weight, orientation, class) of a sub-network after its
+// optimizer step.  `tab` lives in device memory and never changes (masters and packed buffers are persistent);
+// entry e owns the blocks [tile_begin[e], tile_begin[e+1]).
+__global__ __launch_bounds__(256) void pack_tile_batch_kernel(const PackEntry* __restrict__ tab, int n) {
+    __shared__ float t[32 * 65];
+    __shared__ int sel;
+    if (threadIdx.x == 0) {
+        int e = 0;
+        while (e + 1 < n && (int)blockIdx.x >= tab[e + 1].tile_begin) ++e;
+        sel = e;
+    }
+    __syncthreads();
+    const PackEntry& en = tab[sel];
+    const PackArgs& p = en.p;
+    const int run = en.run;
+    const int tile = blockIdx.x - en.tile_begin;
+    const int nbt = (p.B + 31) / 32;
+    const int row = tile / nbt, b0 = (tile - row * nbt) * 32;
+    const int ta = row / p.A, a = row - ta * p.A;
+    const int stride = run | 1;
+    const float* s = p.src + a * p.sa + ta * p.sta;
+    for (int e = threadIdx.x; e < 32 * run; e += 256) {
+        const int bl = e / run, j = e - bl * run;
+        if (b0 + bl < p.B) t[bl * stride + j] = s[(b0 + bl) * p.sb + j];
+    }
+    __syncthreads();
+    half_t* d = p.dst + (int64_t)row * p.kpad + b0;
+    const int ntaps = p.TH * p.TW;
+    for (int e = threadIdx.x; e < ntaps * 32; e += 256) {
+        const int tb = e >> 5, bl = e & 31;
+        const int ty = tb / p.TW, tx = tb - ty * p.TW;
+        const int j = (p.py + p.step * ty) * p.KW + (p.px + p.step * tx);
+        if (b0 + bl < p.B) d[tb * p.Bp + bl] = (half_t)t[bl * stride + j];
+    }
+}
+
 // unpack counterpart (full tap set only: py = px = 0, step = 1, TH*TW == run)
 __global__ __launch_bounds__(256) void unpack_tile_kernel(const UnpackArgs p, int run) {
     __shared__ float t[32 * 65];
@@ -291,6 +327,19 @@ int pack_weight_launch(const PackArgs& p, hipStream_t st) {
     } else {
         hipLaunchKernelGGL(pack_weight_kernel, dim3(nblocks((int64_t)p.rows_pad * p.kpad)), dim3(256), 0, st, p);
     }
+    return hipGetLastError() == hipSuccess ? OK : E_LAUNCH;
+}
+// number of pack_tile blocks of `p` (and its `run`), or 0 when the weight needs one of the other pack paths
+int pack_tile_count(const PackArgs& p, int* run_out) {
+    const int ntaps = p.TH * p.TW;
+    const int run = (p.py + p.step * (p.TH - 1)) * p.KW + (p.px + p.step * (p.TW - 1)) + 1;
+    const int64_t tiles = (int64_t)p.TA * p.A * ((p.B + 31) / 32);
+    if (run_out) *run_out = run;
+    return (ntaps > 1 && p.stb == 1 && run <= 64 && tiles < (1 << 24)) ? (int)tiles : 0;
+}
+int pack_batch_launch(const PackEntry* tab, int n, int total_tiles, hipStream_t st) {
+    if (total_tiles < 1 || n < 1) return OK;
+    hipLaunchKernelGGL(pack_tile_batch_kernel, dim3((unsigned)total_tiles), dim3(256), 0, st, tab, n);
     return hipGetLastError() == hipSuccess ? OK : E_LAUNCH;
 }
 int unpack_grad_launch(const UnpackArgs& p, hipStream_t st) {

@@ -11,6 +11,7 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import List, Optional, Tuple
 
+import ctypes
 import os
 
 import torch
@@ -90,14 +91,52 @@ class PackedWeight:
         # zero once: the pack kernels' fast paths only rewrite the valid region, padding stays zero
         self.buf = torch.zeros(total, dtype=torch.float16, device=master.device)
         self.version = -1
+        if not hasattr(group, "packed"):
+            group.packed = []
+        group.packed.append(self)
+
+    def _items(self):
+        for sp, kp, off in zip(self.specs, self.kpads, self.offsets):
+            yield (_P(self.master), self.buf.data_ptr() + 2 * off, sp.sa, sp.sta, sp.sb, sp.stb, sp.A, sp.TA, sp.B, sp.KW,
+                   sp.py, sp.px, sp.step, sp.TH, sp.TW, self.rows_pad, kp)
 
     def get(self) -> torch.Tensor:
         if self.version != self.group.version:
-            for sp, kp, off in zip(self.specs, self.kpads, self.offsets):
-                lib.call("fmri_pack_weight", _P(self.master), self.buf.data_ptr() + 2 * off, sp.sa, sp.sta, sp.sb,
-                         sp.stb, sp.A, sp.TA, sp.B, sp.KW, sp.py, sp.px, sp.step, sp.TH, sp.TW, self.rows_pad, kp)
-            self.version = self.group.version
+            _repack_group(self.group)
         return self.buf
+
+
+def _repack_group(group):
+    """Refresh every fp16 GEMM copy of a sub-network's weights after its master buffer changed: one batched launch
+    (fmri_pack_weight_batch, device-resident table built once) + the few weights that need another pack path."""
+    packed = group.packed
+    tab = getattr(group, "_pack_table", None)
+    if tab is None or tab["count"] != len(packed):
+        L = lib.load()
+        nbytes = L.fmri_pack_entry_bytes()
+        rows, singles, tiles = [], [], 0
+        for pw in packed:
+            for item in pw._items():
+                host = ctypes.create_string_buffer(nbytes)
+                n = L.fmri_pack_entry_fill(host, *item, tiles)
+                if n < 0:
+                    lib.check(n, "fmri_pack_entry_fill")
+                if n > 0:
+                    rows.append(host.raw)
+                    tiles += n
+                else:
+                    singles.append(item)
+        dev_tab = None
+        if rows:
+            dev_tab = torch.frombuffer(bytearray(b"".join(rows)), dtype=torch.uint8).to(group.device)
+        tab = dict(count=len(packed), table=dev_tab, n=len(rows), tiles=tiles, singles=singles)
+        group._pack_table = tab
+    if tab["n"]:
+        lib.call("fmri_pack_weight_batch", _P(tab["table"]), tab["n"], tab["tiles"])
+    for item in tab["singles"]:
+        lib.call("fmri_pack_weight", *item)
+    for pw in packed:
+        pw.version = group.version
 
 
 def _single(master, group, sp: PackSpec, tile: int) -> PackedWeight:

@@ -172,6 +172,26 @@ int fmri_igemm(const void* in, const void* w, void* out, const float* bias, cons
         if (per * (splits - 1) >= a.cls[i].ksteps && splits > 1) return FMRI_E_BADARG;
     }
     if (maxM == 0) return FMRI_OK;
+    // 5x5 stride-1 convolutions between 3(8)- and 32-channel maps -> register-resident-weight kernel
+    // (csrc/igemm_narrow.hip); FMRI_NARROW=off disables
+    static const char* nar_env = getenv("FMRI_NARROW");
+    static const bool no_narrow = nar_env && !strcmp(nar_env, "off");
+    if (!no_narrow && (mode == FMRI_CONV || mode == FMRI_CONV_FLIP) && stride == 1 && k == 5 && pad == 2 &&
+        (Ci == 8 || Ci == 32) && Co <= 32 && !out_f32 && splits == 1 && Hi == Ho && Wi == Wo &&
+        (int64_t)N * Hi * Wi * 32 < 0x7fffffffLL) {
+        const int co_tiles = Co <= 16 ? 1 : 2;
+        if ((Ci == 32 && co_tiles == 1) || Ci == 8) {
+            NarrowArgs q;
+            q.in = a.in; q.w = a.w + a.cls[0].w_off; q.out = (half_t*)out; q.bias = bias;
+            q.N = N; q.H = Hi; q.W = Wi; q.CoStore = CoStore; q.Co = Co; q.Kpad = a.cls[0].Kpad; q.act = act;
+            q.tiles_y = (Hi + 15) / 16; q.tiles_x = (Wi + 15) / 16;
+            q.ntiles = N * q.tiles_y * q.tiles_x;
+            if (copad >= co_tiles * 16 && q.Kpad >= (Ci == 32 ? 800 : 224)) {
+                const int r = igemm_narrow_launch(q, Ci, co_tiles, mode == FMRI_CONV_FLIP, S(stream));
+                if (r != E_UNSUPPORTED) return r;
+            }
+        }
+    }
     // unit-stride sampling, Ci % 64 == 0 -> window-resident kernel (csrc/igemm_win.hip); FMRI_WIN=off disables
     static const char* win_env = getenv("FMRI_WIN");
     static const bool no_win = win_env && !strcmp(win_env, "off");

@@ -159,6 +159,17 @@ struct WgradArgs {
     FastDiv fdX, fdYX, fdTW, fdBc8;
 };
 
+// narrow-channel 5x5 stride-1 convolution (igemm_narrow.hip)
+struct NarrowArgs {
+    const half_t* in;      // [N][H][W][Ci]
+    const half_t* w;       // packed [rows_pad][Kpad], row = co, k = tap*Ci + ci
+    half_t* out;           // [N][H][W][CoStore]
+    const float* bias;
+    int32_t N, H, W;
+    int32_t CoStore, Co, Kpad, act;
+    int32_t tiles_y, tiles_x, ntiles;
+};
+
 // window-resident weight gradient for stride-2 sampling (wgrad_win.hip): the gathered operand Q is split into its
 // 4 parity planes; per plane the taps are unit shifts of one LDS-resident window
 struct WgradWinArgs {

@@ -1,0 +1,186 @@
+// Narrow-channel 5x5 stride-1 convolution on MFMA (gfx950): Ci in {8, 32}, Co <= 32.
+//
+//   out[n, y, x, co] = act(bias[co] + sum_{tap, ci} in[n, y + dy(tap), x + dx(tap), ci] * w[co][tap*Ci + ci])
+//
+// These are the image-side layers of the model -- discriminator.conv.0 (3 -> 32) and decoder.conv.3 (32 -> 3),
+// forward and data gradient (models/vae_gan.py:118-121, 145-147).  They carry ~2 % of the FLOPs but the generic
+// kernels spend as long on them as on a 256-channel layer: with 3..32 channels a K-step is a handful of MFMAs, so
+// per-step barriers, DMA waits and address arithmetic dominate.  This kernel removes all of them from the inner loop:
+//   * the whole weight matrix (<= 25 K-steps x 16..32 rows) lives in REGISTERS as MFMA operand fragments, loaded
+//     once per block; blocks are persistent and walk 16x16-pixel tiles;
+//   * the (16+4)^2-pixel input window of a tile is staged through registers into LDS with a padded pixel pitch
+//     (80 B for 32 channels) that makes every fragment read conflict-free WITHOUT an address swizzle, so a tap is a
+//     compile-time byte offset: the tap loop is ds_read_b128 (immediate offset) + MFMA, no VALU;
+//   * the next tile's window is fetched (global -> registers) while the current tile computes; one barrier per tile.
+#include "kernels.h"
+
+namespace fmri {
+
+template <int CI, int TN, bool FLIP>
+__global__ __launch_bounds__(256, 2) void igemm_narrow_kernel(const NarrowArgs a) {
+    constexpr int K = 5, PAD = 2, T = K * K;
+    constexpr int WW = 16 + K - 1;                       // window width / height in pixels
+    constexpr int NPIX = WW * WW;                        // 400
+    constexpr int PITCH = CI == 32 ? 80 : 16;            // bytes per window pixel in LDS
+    constexpr int UPP = CI / 8;                          // 16-B units per pixel
+    constexpr int WBYTES = NPIX * PITCH;
+    constexpr int NU = (NPIX * UPP + 255) / 256;         // staged 16-B units per thread
+    constexpr int KS = CI == 32 ? T : (T + 3) / 4;       // k32 steps
+    constexpr int TM = 4;                                // wave = 4 rows of 16 pixels
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 15, fq = lane >> 4;
+
+    // ---- weights: B fragments of every K-step in registers.  lane = (row co = frow + 16 tn, k = 8 fq .. +7)
+    h8 wf[KS][TN];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+            wf[ks][tn] = *(const h8*)(a.w + (int64_t)(tn * 16 + frow) * a.Kpad + ks * 32 + fq * 8);
+
+    // ---- staged window units of this thread: unit u -> pixel u / UPP, 16-B chunk u % UPP
+    int upix[NU], uoff[NU];
+#pragma unroll
+    for (int e = 0; e < NU; ++e) {
+        const int u = e * 256 + tid;
+        upix[e] = u / UPP;
+        uoff[e] = upix[e] * PITCH + (u % UPP) * 16;
+    }
+
+    // ---- fragment read base: wave row 4*wave + tm, pixel x = frow; tap (ty, tx) adds (ty*WW + tx) pixels.
+    // CI == 32: K-step = tap, lane reads channels 8 fq .. of its pixel.  CI == 8: K-step = 4 taps, lane fq reads tap
+    // 4 ks + fq (all 8 channels); taps >= 25 meet zero weights, so they may read any valid pixel.
+    const int pbase = (4 * wave) * WW + frow;
+    int lane_off[CI == 32 ? 1 : KS];
+    if (CI == 32) {
+        lane_off[0] = pbase * PITCH + fq * 16;
+    } else {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            int tap = 4 * ks + fq;
+            if (tap >= T) tap = 0;
+            const int ty = tap / K, tx = tap - ty * K;
+            const int d = FLIP ? (K - 1 - ty) * WW + (K - 1 - tx) : ty * WW + tx;
+            lane_off[ks] = (pbase + d) * PITCH;
+        }
+    }
+
+    const int tiles_x = a.tiles_x, tpi = a.tiles_y * a.tiles_x;
+    h8 stg[NU];
+    auto fetch = [&](int t) {
+        const int n = t / tpi;
+        const int r = t - n * tpi;
+        const int tyi = r / tiles_x, txi = r - tyi * tiles_x;
+        const int y0 = tyi * 16 - PAD, x0 = txi * 16 - PAD;
+#pragma unroll
+        for (int e = 0; e < NU; ++e) {
+            const int j = upix[e] / WW, i = upix[e] - j * WW;
+            const int iy = y0 + j, ix = x0 + i;
+            const bool ok = upix[e] < NPIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const half_t* src = a.in + ((int64_t)(n * a.H + iy) * a.W + ix) * CI + ((e * 256 + tid) % UPP) * 8;
+            stg[e] = ok ? *(const h8*)src : (h8)(half_t)0.f;
+        }
+    };
+    auto stash = [&](int buf) {
+        char* dst = smem + buf * WBYTES;
+#pragma unroll
+        for (int e = 0; e < NU; ++e)
+            if (upix[e] < NPIX) *(h8*)(dst + uoff[e]) = stg[e];
+    };
+
+    int t = blockIdx.x;
+    if (t >= a.ntiles) return;
+    fetch(t);
+    stash(0);
+    __syncthreads();
+    int cur = 0;
+    for (; t < a.ntiles; t += gridDim.x) {
+        const int tn_ = t + gridDim.x;
+        const bool more = tn_ < a.ntiles;
+        if (more) fetch(tn_);                      // global loads in flight during the MFMAs below
+
+        f4 acc[TN][TM];
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+        const char* Ws = smem + cur * WBYTES;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            h8 af[TM];
+            if (CI == 32) {
+                const int ty = ks / K, tx = ks - ty * K;
+                const int d = FLIP ? (K - 1 - ty) * WW + (K - 1 - tx) : ty * WW + tx;
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+                    af[tm] = *(const h8*)(Ws + lane_off[0] + (d + tm * WW) * PITCH);
+            } else {
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+                    af[tm] = *(const h8*)(Ws + lane_off[ks] + tm * WW * PITCH);
+            }
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][tn], af[tm], acc[tn][tm], 0, 0, 0);
+        }
+
+        // ---- epilogue: D[i = co][j = pixel x]; lane owns channels fq*4 .. +3 (+16 tn) of pixel (4*wave + tm, frow)
+        {
+            const int n = t / tpi;
+            const int r = t - n * tpi;
+            const int tyi = r / tiles_x, txi = r - tyi * tiles_x;
+            const int x = txi * 16 + frow;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const int y = tyi * 16 + 4 * wave + tm;
+                if (y >= a.H || x >= a.W) continue;
+                half_t* orow = a.out + ((int64_t)(n * a.H + y) * a.W + x) * a.CoStore;
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    const int co = tn * 16 + fq * 4;
+                    if (co >= a.CoStore) continue;
+                    h4 hv;
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        float f = acc[tn][tm][rg];
+                        if (co + rg < a.Co) {
+                            if (a.bias) f += a.bias[co + rg];
+                            f = act_apply(f, a.act);
+                        } else {
+                            f = 0.f;
+                        }
+                        hv[rg] = (half_t)f;
+                    }
+                    *(h4*)(orow + co) = hv;
+                }
+            }
+        }
+        if (more) stash(cur ^ 1);                  // nobody reads that buffer: its tile finished before the last barrier
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+template <int CI, int TN>
+static int launch_narrow(const NarrowArgs& a, bool flip, hipStream_t st) {
+    constexpr int WB = 20 * 20 * (CI == 32 ? 80 : 16);
+    int blocks = a.ntiles < 512 ? a.ntiles : 512;
+    if (flip) hipLaunchKernelGGL((igemm_narrow_kernel<CI, TN, true>), dim3(blocks), dim3(256), 2 * WB, st, a);
+    else hipLaunchKernelGGL((igemm_narrow_kernel<CI, TN, false>), dim3(blocks), dim3(256), 2 * WB, st, a);
+    return hipGetLastError() == hipSuccess ? OK : E_LAUNCH;
+}
+
+int igemm_narrow_launch(const NarrowArgs& a, int ci, int co_tiles, bool flip, hipStream_t st) {
+    if (ci == 32 && co_tiles == 1) return launch_narrow<32, 1>(a, flip, st);
+    if (ci == 8 && co_tiles == 1) return launch_narrow<8, 1>(a, flip, st);
+    if (ci == 8 && co_tiles == 2) return launch_narrow<8, 2>(a, flip, st);
+    return E_UNSUPPORTED;
+}
+
+}  // namespace fmri

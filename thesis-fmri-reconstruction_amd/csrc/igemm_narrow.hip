@@ -92,6 +92,15 @@ __global__ __launch_bounds__(256, 2) void igemm_narrow_kernel(const NarrowArgs a
             if (upix[e] < NPIX) *(h8*)(dst + uoff[e]) = stg[e];
     };
 
+    float bv[TN][4];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int co = tn * 16 + fq * 4 + rg;
+            bv[tn][rg] = (a.bias && co < a.Co) ? a.bias[co] : 0.f;
+        }
+
     int t = blockIdx.x;
     if (t >= a.ntiles) return;
     fetch(t);
@@ -145,18 +154,28 @@ __global__ __launch_bounds__(256, 2) void igemm_narrow_kernel(const NarrowArgs a
                 for (int tn = 0; tn < TN; ++tn) {
                     const int co = tn * 16 + fq * 4;
                     if (co >= a.CoStore) continue;
+                    f4 v = acc[tn][tm];
+                    if (a.bias) {
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg) v[rg] += bv[tn][rg];
+                    }
+                    // one activation branch per fragment (wave-uniform), not per element
+                    if (a.act == ACT_RELU) {
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg) v[rg] = fmaxf(v[rg], 0.f);
+                    } else if (a.act == ACT_TANH) {
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg) {
+                            const float e = __expf(-2.f * fabsf(v[rg]));          // tanh(|x|) = (1 - e) / (1 + e)
+                            v[rg] = copysignf((1.f - e) / (1.f + e), v[rg]);
+                        }
+                    } else if (a.act == ACT_SIGMOID) {
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg) v[rg] = 1.f / (1.f + __expf(-v[rg]));
+                    }
                     h4 hv;
 #pragma unroll
-                    for (int rg = 0; rg < 4; ++rg) {
-                        float f = acc[tn][tm][rg];
-                        if (co + rg < a.Co) {
-                            if (a.bias) f += a.bias[co + rg];
-                            f = act_apply(f, a.act);
-                        } else {
-                            f = 0.f;
-                        }
-                        hv[rg] = (half_t)f;
-                    }
+                    for (int rg = 0; rg < 4; ++rg) hv[rg] = (half_t)(co + rg < a.Co ? v[rg] : 0.f);
                     *(h4*)(orow + co) = hv;
                 }
             }

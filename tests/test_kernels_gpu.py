@@ -68,6 +68,7 @@ CONV_CASES = [
     (64, 128, 2, 25, 25, 2),     # odd size (100-px config: 25 -> 13)
     (128, 256, 2, 13, 13, 3),    # 13 -> 7
     (3, 32, 2, 20, 20, 2),       # stride_gan = 2
+    (32, 128, 2, 25, 25, 2),     # data gradient = 128 -> 32 transposed conv on odd sizes (igemm_tc32, masked tiles)
 ]
 
 
@@ -105,6 +106,7 @@ DECONV_CASES = [
     (128, 32, 16, 1, 2),
     (256, 256, 13, 0, 2),        # 100-px config first block: 13 -> 25
     (128, 64, 25, 1, 2),         # 25 -> 50
+    (128, 32, 13, 0, 3),         # igemm_tc32 with partial tiles and output_padding = 0
 ]
 
 

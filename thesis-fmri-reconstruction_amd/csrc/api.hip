@@ -192,6 +192,36 @@ int fmri_igemm(const void* in, const void* w, void* out, const float* bias, cons
             }
         }
     }
+    // stride-2 transposed convolution 128 -> <= 32 channels -> persistent register-resident-weight kernel
+    // (csrc/igemm_tc32.hip); FMRI_TC32=off disables
+    static const char* tc_env = getenv("FMRI_TC32");
+    static const bool no_tc32 = tc_env && !strcmp(tc_env, "off");
+    if (!no_tc32 && mode == FMRI_TCONV2 && Ci == 128 && CoStore <= 32 && !out_f32 && splits == 1 &&
+        (int64_t)N * Hi * Wi * 128 < 0x7fffffffLL) {
+        Tc32Args q;
+        q.in = a.in; q.w = a.w; q.out = (half_t*)out; q.bias = bias;
+        q.N = N; q.Hi = Hi; q.Wi = Wi; q.Ho = Ho; q.Wo = Wo; q.CoStore = CoStore; q.Co = Co; q.act = act;
+        bool ok = copad >= 32;
+        int tsum = 0;
+        for (int i = 0; i < 4; ++i) tsum += a.cls[i].T;
+        int begin = 0;
+        for (int i = 0; i < 4 && ok; ++i) {
+            const IgemmClass& s = a.cls[i];
+            Tc32Class& d = q.cls[i];
+            d.Yc = s.Yc; d.Xc = s.Xc; d.oy0 = s.oy0; d.ox0 = s.ox0;
+            d.TW = s.TW; d.TH = s.T / s.TW; d.dy0 = s.dy0; d.dx0 = s.dx0; d.Kpad = s.Kpad; d.w_off = s.w_off;
+            if (d.TH < 2 || d.TH > 3 || d.TW < 2 || d.TW > 3 || s.dstep != -1 || s.Kpad < s.T * 128) ok = false;
+            d.tiles_y = (s.Yc + 7) / 8; d.tiles_x = (s.Xc + 15) / 16;
+            d.ntiles = N * d.tiles_y * d.tiles_x;
+            int nb = (256 * s.T + tsum / 2) / tsum;          // one block per CU, shared out by tap count
+            if (nb < 1) nb = 1;
+            if (nb > d.ntiles) nb = d.ntiles;
+            if (d.ntiles < 1) ok = false;
+            d.block_begin = begin; d.nblocks = nb;
+            begin += nb;
+        }
+        if (ok) return igemm_tc32_launch(q, begin, S(stream));
+    }
     // unit-stride sampling, Ci % 64 == 0 -> window-resident kernel (csrc/igemm_win.hip); FMRI_WIN=off disables
     static const char* win_env = getenv("FMRI_WIN");
     static const bool no_win = win_env && !strcmp(win_env, "off");

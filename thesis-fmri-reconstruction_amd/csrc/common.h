@@ -170,6 +170,26 @@ struct NarrowArgs {
     int32_t tiles_y, tiles_x, ntiles;
 };
 
+// stride-2 transposed convolution 128 -> <= 32 channels (igemm_tc32.hip)
+struct Tc32Class {
+    int32_t Yc, Xc, oy0, ox0;          // class output grid and its offset in the output image
+    int32_t TH, TW, dy0, dx0;          // taps (2 or 3 per dimension), first-tap input offset (taps step by -1)
+    int32_t Kpad;
+    int32_t tiles_y, tiles_x, ntiles;  // 8 x 16 pixel tiles
+    int32_t block_begin, nblocks;      // persistent blocks of this class
+    int64_t w_off;
+};
+
+struct Tc32Args {
+    const half_t* in;      // [N][Hi][Wi][128]
+    const half_t* w;
+    half_t* out;           // [N][Ho][Wo][CoStore]
+    const float* bias;
+    int32_t N, Hi, Wi, Ho, Wo;
+    int32_t CoStore, Co, act;
+    Tc32Class cls[4];
+};
+
 // window-resident weight gradient for stride-2 sampling (wgrad_win.hip): the gathered operand Q is split into its
 // 4 parity planes; per plane the taps are unit shifts of one LDS-resident window
 struct WgradWinArgs {

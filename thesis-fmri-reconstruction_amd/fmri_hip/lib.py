@@ -92,7 +92,14 @@ def ptr(t):
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream():
+    """Raw handle of torch's current stream on the current device (the fast private accessor when torch has it:
+    ``torch.cuda.current_stream()`` costs ~8 us per call, which adds up over ~370 launches per step)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -189,20 +189,24 @@ def run_igemm(x, pw: PackedWeight, out, bias, N, Hi, Wi, Ci, Ho, Wo, CoStore, Co
         PROFILE.append((e0, e1, flops))
 
 
+# window-resident wgrad kernel: on/off, resident-block target (2 per CU), largest split count still written as slabs
+_WW_ON = os.environ.get("FMRI_WGRAD_WIN") != "off"
+_WW_BLOCKS = int(os.environ.get("FMRI_WW_BLOCKS", "512"))
+_WW_SLABS = int(os.environ.get("FMRI_WW_SLABS", "24"))
+
+
 def run_wgrad(P, Q, N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad, flip=0):
     """Returns the packed fp32 gradient [apad][ldo]."""
     ba = tile_for(A)
     apad = ceil_to(A, ba)
     ldo = ceil_to(k * k * Bc, 128)
-    if (stride == 2 and not flip and ba == 128 and Bc % 32 == 0 and Yc * Xc > 1 and k == 5 and pad == 2
-            and os.environ.get("FMRI_WGRAD_WIN") != "off"):
+    if stride == 2 and not flip and ba == 128 and Bc % 32 == 0 and Yc * Xc > 1 and k == 5 and pad == 2 and _WW_ON:
         # window-resident kernel (csrc/wgrad_win.hip): blocks = 32-channel column blocks x 128-row blocks x 4 parity
         # planes x splits over the 8x8 pixel tiles; every split stores its own slab, unpack_grad sums them
         groups = (Bc // 32) * (apad // 128)
-        target = int(os.environ.get("FMRI_WW_BLOCKS", "512"))          # 2 resident blocks per CU
-        splits = max(4, target // groups)                               # block budget per group over the 4 planes
+        splits = max(4, _WW_BLOCKS // groups)                           # block budget per group over the 4 planes
         nslabs = lib.load().fmri_wgrad_slabs(N, Yc, Xc, k, pad, splits)
-        slabs = nslabs <= int(os.environ.get("FMRI_WW_SLABS", "24"))   # few splits: per-split slabs, else atomics
+        slabs = nslabs <= _WW_SLABS                                     # few splits: per-split slabs, else atomics
         if slabs:
             out = torch.empty(nslabs, apad, ldo, dtype=torch.float32, device=P.device)
         else:

@@ -167,6 +167,28 @@ class _GanStepBase:
                  _P(self._slot(S_NE)))
         return out
 
+    def capture(self, *static_inputs, warmup: int = 2):
+        """Record one ``step(*static_inputs)`` into a HIP graph and return a zero-argument callable that replays it.
+
+        Every launch of a step is enqueue-only and nothing inside a step synchronises with the host (the equilibrium
+        gate, the stream normalisation and the optimizer gating all live on the device), so the ~370 launches of a
+        step can be replayed as one graph: the step time then no longer depends on how fast the host can issue them.
+        Inputs are read from ``static_inputs`` at every replay -- copy each new batch into those tensors.  RMSprop
+        steps only (Adam's bias correction is a host-side scalar per step)."""
+        if self.dd.on:
+            raise RuntimeError("graph capture is only wired for single-process runs")
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.step(*static_inputs)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self.step(*static_inputs)
+        self._graph = graph
+        return graph.replay
+
     def logs(self):
         v = self.scal.tolist()
         out = {k: v[i] for i, k in enumerate(LOG_KEYS)}

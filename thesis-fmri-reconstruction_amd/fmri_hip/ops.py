@@ -167,18 +167,33 @@ def _choose_splits(blocks: int, ksteps: int) -> int:
     return (ksteps + per - 1) // per
 
 
-# bench.py sets PROFILE to a list to time every launch of the dominant kernel instantiation
-# (igemm_kernel<128,2,2,false,true>: 128 output channels per block, Ci % 64 == 0) with HIP events on the launch
-# stream: entries (start, end, algorithmic flops)
+# bench.py sets PROFILE to a list: every fmri_igemm launch is then bracketed by HIP events on the launch stream and
+# recorded as (kernel label, start, end, algorithmic flops); bench.py reports the label with the largest total time.
 PROFILE = None
+
+
+def igemm_kernel_label(N, Hi, Wi, Ci, CoStore, Co, k, stride, pad, mode, out_f32, splits, tile) -> str:
+    """Name of the kernel instantiation csrc/api.hip::fmri_igemm routes this geometry to (mirrors its rules)."""
+    spatial = Hi * Wi > 1
+    if (mode in (MODE_CONV, MODE_CONV_FLIP) and stride == 1 and k == 5 and pad == 2 and Ci in (8, 32) and Co <= 32
+            and not out_f32 and splits == 1 and (Ci == 8 or Co <= 16)):
+        return f"fmri::igemm_narrow_kernel<{Ci},{1 if Co <= 16 else 2},{'true' if mode == MODE_CONV_FLIP else 'false'}>"
+    if mode == MODE_TCONV2 and Ci == 128 and CoStore <= 32 and not out_f32 and splits == 1:
+        return "fmri::igemm_tc32_kernel"
+    unit = (mode == MODE_TCONV2 or stride == 1) and spatial and 2 <= k <= 5 and not out_f32 and splits == 1
+    if unit and Ci % 64 == 0 and tile >= 64:
+        return f"fmri::igemm_win_kernel<{tile},2,2>"
+    if unit and mode != MODE_TCONV2 and Ci in (8, 32):
+        return f"fmri::igemm_patch_kernel<{tile}>"
+    wm, wn = (4, 1) if tile == 32 else (2, 2)
+    return (f"fmri::igemm_kernel<{tile},{wm},{wn},{'true' if out_f32 else 'false'},"
+            f"{'true' if Ci % 64 == 0 else 'false'}>")
 
 
 def run_igemm(x, pw: PackedWeight, out, bias, N, Hi, Wi, Ci, Ho, Wo, CoStore, Co, k, stride, pad, mode, act, out_f32,
               splits, slab_stride, tile, flops=0.0):
     w = pw.get()
-    # unit-stride geometries (transposed-conv classes, stride-1 convs) are routed to igemm_win / igemm_patch (api.hip)
-    unit = (mode == MODE_TCONV2 or stride == 1) and Hi * Wi > 1 and 2 <= k <= 5
-    prof = PROFILE is not None and tile == 128 and not out_f32 and Ci % 64 == 0 and not unit
+    prof = PROFILE is not None and flops > 0.0
     if prof:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -186,7 +201,8 @@ def run_igemm(x, pw: PackedWeight, out, bias, N, Hi, Wi, Ci, Ho, Wo, CoStore, Co
              CoStore, Co, k, stride, pad, mode, act, 1 if out_f32 else 0, splits, slab_stride, tile)
     if prof:
         e1.record()
-        PROFILE.append((e0, e1, flops))
+        PROFILE.append((igemm_kernel_label(N, Hi, Wi, Ci, CoStore, Co, k, stride, pad, mode, out_f32, splits, tile),
+                        e0, e1, flops))
 
 
 # window-resident wgrad kernel: on/off, resident-block target (2 per CU), largest split count still written as slabs

@@ -83,6 +83,11 @@ def main():
     ap.add_argument("--eager", action="store_true", help="issue every launch from Python instead of replaying a graph")
     a = ap.parse_args()
 
+    # stdout must carry exactly one JSON line: native libraries (the RCCL version banner at communicator creation)
+    # print to file descriptor 1, so fd 1 is pointed at stderr for the run and the result goes to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -91,7 +96,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
-    if world > 1:
+    force_dist = os.environ.get("FMRI_FORCE_DIST") == "1"      # 1-rank rehearsal of the RCCL path
+    if world > 1 or force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -102,7 +108,7 @@ def main():
 
     cfg = ArchConfig.px64()
     B = a.batch
-    st = Stage1Step(cfg, dev, distributed=world > 1, sync_bn=not a.local_bn)
+    st = Stage1Step(cfg, dev, distributed=world > 1 or force_dist, sync_bn=not a.local_bn)
     st.load_recipe(0, False)
     x = torch.from_numpy(np.random.RandomState(1234 + rank).uniform(-1, 1, (B, 3, 64, 64)).astype(np.float32)).to(dev)
     nz = torch.from_numpy(np.random.RandomState(1236 + rank).standard_normal((2, B, cfg.latent_dim))
@@ -125,7 +131,7 @@ def main():
     # recorded once into a HIP graph and the K timed steps are K replays -- the same launches, issued by the GPU front
     # end instead of ~370 Python/ctypes calls, so the number no longer depends on the host CPU of the box.
     # Multi-process runs (RCCL collectives between the launches) issue the step eagerly.
-    use_graph = world == 1 and not a.eager
+    use_graph = world == 1 and not a.eager and not force_dist
     run = st.capture(x, nz[0], nz[1]) if use_graph else (lambda: st.step(x, nz[0], nz[1]))
     if use_graph:
         run()
@@ -183,8 +189,8 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(32, 3)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -16,6 +16,7 @@ kernels divide out again.
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Dict, Optional
 
@@ -89,7 +90,9 @@ class _Dist:
     def __init__(self, enabled: bool, sync_bn: bool = True):
         import torch.distributed as dist
         self.dist = dist
-        self.on = enabled and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        # FMRI_FORCE_DIST=1: take the collective path even with one rank (single-GPU rehearsal of the RCCL calls)
+        force = os.environ.get("FMRI_FORCE_DIST") == "1"
+        self.on = enabled and dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force)
         self.world = dist.get_world_size() if self.on else 1
         self.sync_bn = sync_bn
 

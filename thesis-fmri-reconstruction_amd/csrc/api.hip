@@ -201,25 +201,22 @@ int fmri_igemm(const void* in, const void* w, void* out, const float* bias, cons
         Tc32Args q;
         q.in = a.in; q.w = a.w; q.out = (half_t*)out; q.bias = bias;
         q.N = N; q.Hi = Hi; q.Wi = Wi; q.Ho = Ho; q.Wo = Wo; q.CoStore = CoStore; q.Co = Co; q.act = act;
-        bool ok = copad >= 32;
-        int tsum = 0;
-        for (int i = 0; i < 4; ++i) tsum += a.cls[i].T;
-        int begin = 0;
+        // the kernel hard-wires the k5 p2 class geometry: parity-0 classes have 3 taps from input offset +1 downwards,
+        // parity-1 classes 2 taps from +1 downwards
+        bool ok = copad >= 32 && k == 5 && pad == 2;
         for (int i = 0; i < 4 && ok; ++i) {
             const IgemmClass& s = a.cls[i];
             Tc32Class& d = q.cls[i];
-            d.Yc = s.Yc; d.Xc = s.Xc; d.oy0 = s.oy0; d.ox0 = s.ox0;
-            d.TW = s.TW; d.TH = s.T / s.TW; d.dy0 = s.dy0; d.dx0 = s.dx0; d.Kpad = s.Kpad; d.w_off = s.w_off;
-            if (d.TH < 2 || d.TH > 3 || d.TW < 2 || d.TW > 3 || s.dstep != -1 || s.Kpad < s.T * 128) ok = false;
-            d.tiles_y = (s.Yc + 7) / 8; d.tiles_x = (s.Xc + 15) / 16;
-            d.ntiles = N * d.tiles_y * d.tiles_x;
-            int nb = (256 * s.T + tsum / 2) / tsum;          // one block per CU, shared out by tap count
-            if (nb < 1) nb = 1;
-            if (nb > d.ntiles) nb = d.ntiles;
-            if (d.ntiles < 1) ok = false;
-            d.block_begin = begin; d.nblocks = nb;
-            begin += nb;
+            const int th = s.T / s.TW;
+            if (th != ((i >> 1) ? 2 : 3) || s.TW != ((i & 1) ? 2 : 3) || s.dy0 != 1 || s.dx0 != 1 || s.dstep != -1 ||
+                s.oy0 != (i >> 1) || s.ox0 != (i & 1) || s.Kpad < s.T * 128)
+                ok = false;
+            d.Yc = s.Yc; d.Xc = s.Xc; d.Kpad = s.Kpad; d.pad0 = 0; d.w_off = s.w_off;
         }
+        q.tiles_y = (a.cls[0].Yc + 7) / 8; q.tiles_x = (a.cls[0].Xc + 15) / 16;     // class (0,0) has the largest grid
+        q.ntiles = N * q.tiles_y * q.tiles_x;
+        if (q.ntiles < 1) ok = false;
+        const int begin = q.ntiles < 256 ? q.ntiles : 256;                          // one persistent block per CU
         if (ok) return igemm_tc32_launch(q, begin, S(stream));
     }
     // unit-stride sampling, Ci % 64 == 0 -> window-resident kernel (csrc/igemm_win.hip); FMRI_WIN=off disables

@@ -170,13 +170,10 @@ struct NarrowArgs {
     int32_t tiles_y, tiles_x, ntiles;
 };
 
-// stride-2 transposed convolution 128 -> <= 32 channels (igemm_tc32.hip)
+// stride-2 transposed convolution (k5 p2) 128 -> <= 32 channels (igemm_tc32.hip)
 struct Tc32Class {
-    int32_t Yc, Xc, oy0, ox0;          // class output grid and its offset in the output image
-    int32_t TH, TW, dy0, dx0;          // taps (2 or 3 per dimension), first-tap input offset (taps step by -1)
-    int32_t Kpad;
-    int32_t tiles_y, tiles_x, ntiles;  // 8 x 16 pixel tiles
-    int32_t block_begin, nblocks;      // persistent blocks of this class
+    int32_t Yc, Xc;                    // class output grid (class (cy, cx) writes output pixel (2y + cy, 2x + cx))
+    int32_t Kpad, pad0;
     int64_t w_off;
 };
 
@@ -187,6 +184,7 @@ struct Tc32Args {
     const float* bias;
     int32_t N, Hi, Wi, Ho, Wo;
     int32_t CoStore, Co, act;
+    int32_t tiles_y, tiles_x, ntiles;  // 8 x 16 tiles of class-grid positions (all four classes per tile)
     Tc32Class cls[4];
 };
 

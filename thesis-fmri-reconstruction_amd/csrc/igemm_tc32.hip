@@ -1,37 +1,39 @@
-// Stride-2 transposed convolution from 128 to <= 32 channels on MFMA (gfx950): decoder.conv.2 forward and the data
-// gradient of discriminator.conv.1 (models/vae_gan.py:112-116, 149-153; ConvTranspose2d k5 s2 p2 as 4 output-parity
-// classes with 3x3 / 3x2 / 2x3 / 2x2 unit-shift taps).
+// Stride-2 transposed convolution (k5 p2) from 128 to <= 32 channels on MFMA (gfx950): decoder.conv.2 forward and the
+// data gradient of discriminator.conv.1 (models/vae_gan.py:112-116, 149-153).
 //
 // With only 32 output channels the generic kernels move 8x more operand bytes per FLOP than on a 256-channel layer
-// and run at 15 % of the MFMA peak, so this layer class cost as much as the widest one.  Here
-//   * blocks are persistent and class-bound (blocks per class in proportion to its taps), 512 threads = 4 pixel
-//     groups x 2 channel chunks: wave (g, h) contracts the 64 input channels of chunk h for the 32 pixels of group g
-//     and keeps the WHOLE weight slice it needs (T taps x 64 ch x 32 co) as MFMA fragments in registers;
-//   * the input window of an 8x16-pixel tile ((8+TH-1) x (16+TW-1) pixels x 128 ch) is staged through registers
-//     into LDS with a 144-byte pixel pitch: fragment reads are conflict-free without a swizzle and every tap is a
-//     compile-time byte offset -- the tap loop is ds_read_b128 + MFMA only;
-//   * the two chunk partial sums of a pixel group meet once per tile through LDS; the next tile's window is in
-//     flight (global -> registers) during the MFMAs; one barrier per tile.
+// and ran at 15 % of the MFMA peak, so this layer class cost as much as the widest one.  Here
+//   * a ConvTranspose2d(k5, s2, p2) is 4 output-parity classes with 3x3 / 3x2 / 2x3 / 2x2 unit-shift taps that all
+//     read the SAME (8+2) x (16+2)-pixel input window per 8x16 tile of class-grid positions.  A 512-thread block loads
+//     that window once (global -> registers -> LDS, 144-byte pixel pitch: conflict-free fragment reads without a
+//     swizzle, every tap a compile-time byte offset) and its 8 waves are (class, 64-channel chunk) specialists: wave
+//     (c, h) keeps the whole weight slice of class c and chunk h (T taps x 64 ch x 32 co) as MFMA fragments in
+//     REGISTERS and computes all 128 positions of the tile for it -- the tap loop is ds_read_b128 + MFMA only;
+//   * the wave order puts a 9-tap and a 4-tap wave, or two 6-tap waves, on every SIMD (13 / 12 tap-units each);
+//   * the two chunk partial sums of a class meet through LDS once per two tile rows; blocks are persistent and the next
+//     tile's window is in flight during the MFMAs.
 #include "kernels.h"
 
 namespace fmri {
 
-template <int TH, int TW>
-__device__ __forceinline__ void tc32_body(const Tc32Args& a, const Tc32Class& c, char* smem, int first, int stride) {
-    constexpr int T = TH * TW;
-    constexpr int WH = 8 + TH - 1, WW = 16 + TW - 1;
-    constexpr int NPIX = WH * WW;
-    constexpr int PITCH = 144;
-    constexpr int CHB = NPIX * PITCH;               // bytes of one 64-channel chunk of the window
-    constexpr int BUF = 2 * CHB;
-    constexpr int UNITS = 2 * NPIX * 8;             // 16-B units of a window
-    constexpr int NU = (UNITS + 511) / 512;
-    constexpr int XCH_OFF = 2 * BUF;                // exchange area: [parity][group][half] x 2 KB
+namespace {
+constexpr int WH = 10, WW = 18, NPIX = WH * WW;    // union window of the four classes
+constexpr int PITCH = 144;
+constexpr int CHB = NPIX * PITCH;                  // one 64-channel chunk of the window
+constexpr int BUF = 2 * CHB;
+constexpr int UNITS = 2 * NPIX * 8;                // 16-B units of a window
+constexpr int NU = (UNITS + 511) / 512;
+constexpr int XCH_OFF = 2 * BUF;                   // exchange: [row-pair parity][wave pair][direction] x 2 KB
+constexpr int TC32_LDS = XCH_OFF + 2 * 4 * 2 * 2048;
+}  // namespace
 
+// One (class, chunk) specialist.  CY, CX: output parity of the class; taps of a parity-0 dimension sample window
+// offsets 2, 1, 0 (3 taps), of a parity-1 dimension 2, 1 (2 taps) relative to the tile origin.
+template <int CY, int CX>
+__device__ __forceinline__ void tc32_role(const Tc32Args& a, char* smem, int h, int pair, int lane) {
+    constexpr int TH = CY ? 2 : 3, TW = CX ? 2 : 3, T = TH * TW;
+    const Tc32Class& c = a.cls[CY * 2 + CX];
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = wave >> 1, h = wave & 1;
     const int frow = lane & 15, fq = lane >> 4;
 
     // ---- this wave's weight slice as MFMA fragments: lane = (row co = frow + 16 tn, k = 8 fq .. +7 of a 32-wide step)
@@ -45,96 +47,100 @@ __device__ __forceinline__ void tc32_body(const Tc32Args& a, const Tc32Class& c,
                 wf[t][ks][tn] = *(const h8*)(a.w + c.w_off + (int64_t)(tn * 16 + frow) * c.Kpad + t * 128 + h * 64 +
                                              ks * 32 + fq * 8);
 
-    // ---- staged window units of this thread (fixed for all tiles)
-    int upix[NU], uoff[NU], ugl[NU];
-#pragma unroll
-    for (int e = 0; e < NU; ++e) {
-        const int u = e * 512 + tid;
-        const int chunk = u / (NPIX * 8);
-        const int r = u - chunk * (NPIX * 8);
-        upix[e] = u < UNITS ? (r >> 3) : -1;
-        uoff[e] = chunk * CHB + (r >> 3) * PITCH + (r & 7) * 16;
-        ugl[e] = chunk * 64 + (r & 7) * 8;
-    }
-    const int dymin = c.dy0 - (TH - 1), dxmin = c.dx0 - (TW - 1);
-    const int tpi = c.tiles_y * c.tiles_x;
-    h8 stg[NU];
-    auto fetch = [&](int t) {
+    // ---- window staging: unit u = e*512 + tid -> chunk u / (NPIX*8), pixel (u % (NPIX*8)) >> 3, 16-B slot & 7.
+    // Recomputed per tile (a handful of constant divisions) rather than kept in registers next to the weights.
+    const int tpi = a.tiles_y * a.tiles_x;
+    // One staging phase (all NU units in flight during the whole tile) measured 5 % faster than two half-sized
+    // phases although the 9-tap role then spills 7 VGPRs outside its tap loop.
+    constexpr int PHASES = 1;
+    constexpr int NH = (NU + PHASES - 1) / PHASES;
+    h8 stg[NH];
+    auto fetch = [&](int t, int ph) {
         const int n = t / tpi;
         const int r = t - n * tpi;
-        const int tyi = r / c.tiles_x, txi = r - tyi * c.tiles_x;
-        const int y0 = tyi * 8 + dymin, x0 = txi * 16 + dxmin;
+        const int tyi = r / a.tiles_x, txi = r - tyi * a.tiles_x;
+        const int y0 = tyi * 8 - 1, x0 = txi * 16 - 1;            // window origin = tile origin - 1
 #pragma unroll
-        for (int e = 0; e < NU; ++e) {
-            const int j = upix[e] / WW, i = upix[e] - j * WW;
+        for (int e = 0; e < NH; ++e) {
+            const int u = (ph * NH + e) * 512 + tid;
+            const int chunk = u / (NPIX * 8);
+            const int rr = u - chunk * (NPIX * 8);
+            const int pix = rr >> 3;
+            const int j = pix / WW, i = pix - j * WW;
             const int iy = y0 + j, ix = x0 + i;
-            const bool ok = upix[e] >= 0 && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
-            const half_t* src = a.in + ((int64_t)(n * a.Hi + iy) * a.Wi + ix) * 128 + ugl[e];
+            const bool ok = u < UNITS && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
+            const half_t* src = a.in + ((int64_t)(n * a.Hi + iy) * a.Wi + ix) * 128 + chunk * 64 + (rr & 7) * 8;
             stg[e] = ok ? *(const h8*)src : (h8)(half_t)0.f;
         }
     };
-    auto stash = [&](int buf) {
+    auto stash = [&](int buf, int ph) {
         char* dst = smem + buf * BUF;
 #pragma unroll
-        for (int e = 0; e < NU; ++e)
-            if (upix[e] >= 0) *(h8*)(dst + uoff[e]) = stg[e];
+        for (int e = 0; e < NH; ++e) {
+            const int u = (ph * NH + e) * 512 + tid;
+            const int chunk = u / (NPIX * 8);
+            const int rr = u - chunk * (NPIX * 8);
+            if (u < UNITS) *(h8*)(dst + chunk * CHB + (rr >> 3) * PITCH + (rr & 7) * 16) = stg[e];
+        }
     };
 
-    // fragment read base of this lane: chunk h, window row 2g (+tm), column frow; tap (ty, tx) of a transposed-conv
-    // class samples input (y + dy0 - ty, x + dx0 - tx) = window ((TH-1-ty) + row, (TW-1-tx) + column)
-    const int lane_off = h * CHB + ((2 * g) * WW + frow) * PITCH + fq * 16;
+    const int lane_off = h * CHB + frow * PITCH + fq * 16;
 
-    int t = first;
-    if (t >= c.ntiles) return;
-    fetch(t);
-    stash(0);
+    int t = blockIdx.x;
+#pragma unroll
+    for (int ph = 0; ph < PHASES; ++ph) {
+        fetch(t, ph);
+        stash(0, ph);
+    }
     __syncthreads();
     int cur = 0;
-    for (; t < c.ntiles; t += stride) {
-        const int tnext = t + stride;
-        const bool more = tnext < c.ntiles;
-        if (more) fetch(tnext);                     // global loads in flight during the MFMAs below
-
-        f4 acc[2][2];                               // [tn][tm]
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+    for (; t < a.ntiles; t += gridDim.x) {
+        const int tnext = t + gridDim.x;
+        const bool more = tnext < a.ntiles;
+        if (more) fetch(tnext, 0);                  // global loads in flight during the MFMAs below
+        const int n = t / tpi;
+        const int r = t - n * tpi;
+        const int tyi = r / a.tiles_x, txi = r - tyi * a.tiles_x;
         const char* Ws = smem + cur * BUF + lane_off;
 #pragma unroll
-        for (int tp = 0; tp < T; ++tp) {
-            const int ty = tp / TW, tx = tp - ty * TW;
-            const int d = (TH - 1 - ty) * WW + (TW - 1 - tx);
+        for (int q = 0; q < 4; ++q) {               // class-grid rows 2 q, 2 q + 1 of the tile
+            f4 acc[2][2];                           // [tn][tm]
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                h8 af[2];
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int tm = 0; tm < 2; ++tm) af[tm] = *(const h8*)(Ws + (d + tm * WW) * PITCH + ks * 64);
+                for (int j = 0; j < 2; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int tm = 0; tm < 2; ++tm)
+            for (int tp = 0; tp < T; ++tp) {
+                const int ty = tp / TW, tx = tp - ty * TW;
 #pragma unroll
-                    for (int tn = 0; tn < 2; ++tn)
-                        acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[tp][ks][tn], af[tm], acc[tn][tm], 0, 0, 0);
+                for (int ks = 0; ks < 2; ++ks) {
+                    h8 af[2];
+#pragma unroll
+                    for (int tm = 0; tm < 2; ++tm)
+                        af[tm] = *(const h8*)(Ws + ((2 * q + tm + 2 - ty) * WW + (2 - tx)) * PITCH + ks * 64);
+#pragma unroll
+                    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < 2; ++tn)
+                            acc[tn][tm] =
+                                __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[tp][ks][tn], af[tm], acc[tn][tm], 0, 0, 0);
+                }
             }
-        }
-
-        // ---- the two chunk partial sums of a group meet through LDS: wave h keeps row tm = h and hands over tm = 1-h
-        float* xch = (float*)(smem + XCH_OFF + ((cur * 4 + g) * 2) * 2048);
-        {
-            float* dst = xch + (1 - h) * 512 + lane * 8;          // slot read by the partner
+            // ---- the two chunk partial sums meet through LDS: wave h keeps row tm = h and hands over row 1 - h
+            float* xch = (float*)(smem + XCH_OFF + (((q & 1) * 4 + pair) * 2) * 2048);
+            {
+                float* dst = xch + (1 - h) * 512 + lane * 8;      // slot read by the partner
 #pragma unroll
-            for (int tn = 0; tn < 2; ++tn) *(f4*)(dst + tn * 4) = acc[tn][1 - h];
-        }
-        if (more) stash(cur ^ 1);
-        __syncthreads();
-        {
+                for (int tn = 0; tn < 2; ++tn) *(f4*)(dst + tn * 4) = acc[tn][1 - h];
+            }
+            if (PHASES == 2 && q == 1 && more) { stash(cur ^ 1, 0); fetch(tnext, 1); }
+            if (q == 3 && more) stash(cur ^ 1, PHASES - 1);
+            __syncthreads();
             const float* src = xch + h * 512 + lane * 8;
-            const int n = t / tpi;
-            const int r = t - n * tpi;
-            const int tyi = r / c.tiles_x, txi = r - tyi * c.tiles_x;
-            const int y = tyi * 8 + 2 * g + h, x = txi * 16 + frow;
+            const int x = txi * 16 + frow;
+            const int y = tyi * 8 + 2 * q + h;
             if (y < c.Yc && x < c.Xc) {
-                half_t* orow = a.out + ((int64_t)(n * a.Ho + (2 * y + c.oy0)) * a.Wo + (2 * x + c.ox0)) * a.CoStore;
+                half_t* orow = a.out + ((int64_t)(n * a.Ho + (2 * y + CY)) * a.Wo + (2 * x + CX)) * a.CoStore;
 #pragma unroll
                 for (int tn = 0; tn < 2; ++tn) {
                     const int co = tn * 16 + fq * 4;
@@ -156,30 +162,30 @@ __device__ __forceinline__ void tc32_body(const Tc32Args& a, const Tc32Class& c,
                 }
             }
         }
+        __syncthreads();                            // next tile's window is in place, everyone is done with this one
         cur ^= 1;
     }
 }
 
 __global__ __launch_bounds__(512) void igemm_tc32_kernel(const Tc32Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int ci = 0;
-    while (ci < 3 && (int)blockIdx.x >= a.cls[ci + 1].block_begin) ++ci;
-    const Tc32Class& c = a.cls[ci];
-    const int first = blockIdx.x - c.block_begin;
-    if (c.TH == 3 && c.TW == 3) tc32_body<3, 3>(a, c, smem, first, c.nblocks);
-    else if (c.TH == 3 && c.TW == 2) tc32_body<3, 2>(a, c, smem, first, c.nblocks);
-    else if (c.TH == 2 && c.TW == 3) tc32_body<2, 3>(a, c, smem, first, c.nblocks);
-    else tc32_body<2, 2>(a, c, smem, first, c.nblocks);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pair = wave >> 1, h = wave & 1;
+    // wave w runs on SIMD w % 4: pairs 0 / 2 (9 + 4 taps) share SIMDs 0, 1; pairs 1 / 3 (6 + 6 taps) share SIMDs 2, 3
+    if (pair == 0) tc32_role<0, 0>(a, smem, h, pair, lane);
+    else if (pair == 1) tc32_role<0, 1>(a, smem, h, pair, lane);
+    else if (pair == 2) tc32_role<1, 1>(a, smem, h, pair, lane);
+    else tc32_role<1, 0>(a, smem, h, pair, lane);
 }
 
 int igemm_tc32_launch(const Tc32Args& a, int nblocks, hipStream_t st) {
-    const int lds = 2 * 2 * (10 * 18 * 144) + 2 * 4 * 2 * 2048;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)igemm_tc32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)igemm_tc32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TC32_LDS);
         attr_done = true;
     }
-    hipLaunchKernelGGL(igemm_tc32_kernel, dim3(nblocks), dim3(512), lds, st, a);
+    hipLaunchKernelGGL(igemm_tc32_kernel, dim3(nblocks), dim3(512), TC32_LDS, st, a);
     return hipGetLastError() == hipSuccess ? OK : E_LAUNCH;
 }
 

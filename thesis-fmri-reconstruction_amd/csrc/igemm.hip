@@ -19,19 +19,25 @@
 //     channels of one pixel -> 8-byte NHWC stores.
 //   * fp32 accumulate; epilogue fuses bias + ReLU/tanh, or writes fp32 split-K slabs.
 #include "kernels.h"
+#include <cstdlib>
+#include <cstring>
 
 namespace fmri {
 
-template <int BN, int WM, int WN, bool OUT_F32, bool UNI>
-__global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
-    constexpr int BM = 128;
+// BM x BN x 64 tile, WM x WN waves (4 waves: BM = 128, two blocks per CU; 8 waves: BM = BN = 256, one block per CU --
+// half the operand bytes per FLOP and per-wave 128 x 64 sub-tiles for the >= 256-channel layers).
+template <int BM, int BN, int WM, int WN, bool OUT_F32, bool UNI>
+__global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmArgs a) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int RPP = NT / 8;                 // tile rows covered by one DMA pass of the block
     constexpr int A_BYTES = BM * 128;
     constexpr int B_BYTES = BN * 128;
     constexpr int STAGE = A_BYTES + B_BYTES;
     constexpr int TM = BM / WM / 16;
     constexpr int TN = BN / WN / 16;
-    constexpr int BROWS = BN / 32;
-    static_assert(WM * WN == 4, "4 waves");
+    constexpr int AROWS = BM / RPP;
+    constexpr int BROWS = BN / RPP;
+    static_assert(AROWS == 4, "4 gather rows per thread");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -55,7 +61,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     const int YX = c.Yc * c.Xc;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int m = m0 + trow + 32 * i;
+        const int m = m0 + trow + RPP * i;
         const bool v = m < c.M;
         const uint32_t mm = v ? (uint32_t)m : 0u;
         const uint32_t n = fd_div(mm, c.fdYX);
@@ -96,7 +102,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
                 const int ix = ix0[i] + dx;
                 const bool ok = tv && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
                 const half_t* src = ok ? a.in + (rowoff[i] + tapoff) : a.zero;
-                glds16(src, dstA + i * (32 * 128));
+                glds16(src, dstA + i * (RPP * 128));
             }
         } else {
             const int k = kstep * 64 + clog * 8;
@@ -113,13 +119,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
                 const int ix = ix0[i] + dx;
                 const bool ok = tv && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
                 const half_t* src = ok ? a.in + ((int64_t)(pixbase[i] + iy * a.Wi + ix) * a.Ci + ci) : a.zero;
-                glds16(src, dstA + i * (32 * 128));
+                glds16(src, dstA + i * (RPP * 128));
             }
         }
         char* dstB = smem + buf * STAGE + A_BYTES + wave * (8 * 128);
         const half_t* wsrc = wrow + (int64_t)kstep * 64;
 #pragma unroll
-        for (int i = 0; i < BROWS; ++i) glds16(wsrc + (int64_t)i * 32 * c.Kpad, dstB + i * (32 * 128));
+        for (int i = 0; i < BROWS; ++i) glds16(wsrc + (int64_t)i * RPP * c.Kpad, dstB + i * (RPP * 128));
     };
 
     f4 acc[TN][TM];
@@ -134,41 +140,68 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     auto compute = [&](int buf) {
         const char* As = smem + buf * STAGE;
         const char* Bs = As + A_BYTES;
-        // all fragment reads of the K-step are issued up front: the second half's LDS latency hides under
-        // the first half's MFMAs (the compiler then waits with a counted lgkmcnt instead of lgkmcnt(0))
-        h8 af[2][TM], bf[2][TN];
+        if constexpr (TM * TN <= 16) {
+            // all fragment reads of the K-step are issued up front: the second half's LDS latency hides under
+            // the first half's MFMAs (the compiler then waits with a counted lgkmcnt instead of lgkmcnt(0))
+            h8 af[2][TM], bf[2][TN];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+            for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm) {
-                const int row = wm * (BM / WM) + tm * 16 + frow;
-                const int ph = (ks * 4 + fq) ^ ((row >> 1) & 7);
-                af[ks][tm] = *(const h8*)(As + row * 128 + ph * 16);
-            }
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-                const int row = wn * (BN / WN) + tn * 16 + frow;
-                const int ph = (ks * 4 + fq) ^ ((row >> 1) & 7);
-                bf[ks][tn] = *(const h8*)(Bs + row * 128 + ph * 16);
-            }
-            if (ks == 0) __builtin_amdgcn_sched_barrier(0);   // first-half reads are issued first
-        }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm)
-                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[ks][tn], af[ks][tm], acc[tn][tm], 0, 0, 0);
-            if (ks == 0) {
-                // interleave the second-half reads with the first TM+TN MFMAs of the first half, then the rest
-#pragma unroll
-                for (int i = 0; i < TM + TN; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+                for (int tm = 0; tm < TM; ++tm) {
+                    const int row = wm * (BM / WM) + tm * 16 + frow;
+                    const int ph = (ks * 4 + fq) ^ ((row >> 1) & 7);
+                    af[ks][tm] = *(const h8*)(As + row * 128 + ph * 16);
                 }
-                __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - (TM + TN), 0);
-                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    const int row = wn * (BN / WN) + tn * 16 + frow;
+                    const int ph = (ks * 4 + fq) ^ ((row >> 1) & 7);
+                    bf[ks][tn] = *(const h8*)(Bs + row * 128 + ph * 16);
+                }
+                if (ks == 0) __builtin_amdgcn_sched_barrier(0);   // first-half reads are issued first
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+                        acc[tn][tm] =
+                            __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[ks][tn], af[ks][tm], acc[tn][tm], 0, 0, 0);
+                if (ks == 0) {
+                    // interleave the second-half reads with the first TM+TN MFMAs of the first half, then the rest
+#pragma unroll
+                    for (int i = 0; i < TM + TN; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - (TM + TN), 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else {
+            // big wave tile: one 32-wide half at a time (the register file holds 128 accumulators); the other wave of
+            // the SIMD covers the read latency
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                h8 af[TM], bf[TN];
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+                    const int row = wm * (BM / WM) + tm * 16 + frow;
+                    const int ph = (ks * 4 + fq) ^ ((row >> 1) & 7);
+                    af[tm] = *(const h8*)(As + row * 128 + ph * 16);
+                }
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    const int row = wn * (BN / WN) + tn * 16 + frow;
+                    const int ph = (ks * 4 + fq) ^ ((row >> 1) & 7);
+                    bf[tn] = *(const h8*)(Bs + row * 128 + ph * 16);
+                }
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+                        acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[tn], af[tm], acc[tn][tm], 0, 0, 0);
             }
         }
     };
@@ -222,28 +255,40 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     }
 }
 
-template <int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN>
 static int launch_bn(const IgemmArgs& a, int maxM, int copad, bool out_f32, hipStream_t st) {
-    dim3 grid((maxM + 127) / 128, copad / BN, a.ncls * a.splits);
-    const int lds = 2 * (128 * 128 + BN * 128);
+    dim3 grid((maxM + BM - 1) / BM, copad / BN, a.ncls * a.splits);
+    constexpr int NT = WM * WN * 64;
+    const int lds = 2 * (BM * 128 + BN * 128);
     // fp32-slab output is used for split-K / fp32 consumers; UNI = K-steps never straddle taps
     const bool uni = (a.Ci & 63) == 0;
+    auto go = [&](auto kern) {
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL(kern, grid, dim3(NT), lds, st, a);
+    };
     if (out_f32) {
-        if (uni) hipLaunchKernelGGL((igemm_kernel<BN, WM, WN, true, true>), grid, dim3(256), lds, st, a);
-        else hipLaunchKernelGGL((igemm_kernel<BN, WM, WN, true, false>), grid, dim3(256), lds, st, a);
+        if (uni) go(igemm_kernel<BM, BN, WM, WN, true, true>);
+        else go(igemm_kernel<BM, BN, WM, WN, true, false>);
     } else {
-        if (uni) hipLaunchKernelGGL((igemm_kernel<BN, WM, WN, false, true>), grid, dim3(256), lds, st, a);
-        else hipLaunchKernelGGL((igemm_kernel<BN, WM, WN, false, false>), grid, dim3(256), lds, st, a);
+        if (uni) go(igemm_kernel<BM, BN, WM, WN, false, true>);
+        else go(igemm_kernel<BM, BN, WM, WN, false, false>);
     }
     return hipGetLastError() == hipSuccess ? OK : E_LAUNCH;
 }
 
-// host entry used by api.hip.  bn_tile in {32, 64, 128}.
+// host entry used by api.hip.  bn_tile in {32, 64, 128}; a 128-channel tiling of a layer with >= 256 output channels
+// and enough 256-pixel tiles to fill the chip is promoted to the 256 x 256 tile (FMRI_BIG=off disables).
 int igemm_launch(const IgemmArgs& a, int maxM, int bn_tile, int copad, bool out_f32, hipStream_t st) {
+    static const char* big_env = getenv("FMRI_BIG");
+    static const bool no_big = big_env && !strcmp(big_env, "off");
+    static const int big_min = big_env && big_env[0] >= '0' && big_env[0] <= '9' ? atoi(big_env) : 192;
+    if (!no_big && bn_tile == 128 && !out_f32 && a.splits == 1 && (copad & 255) == 0 &&
+        (int64_t)((maxM + 255) / 256) * (copad / 256) * a.ncls >= big_min)
+        return launch_bn<256, 256, 2, 4>(a, maxM, copad, out_f32, st);
     switch (bn_tile) {
-        case 128: return launch_bn<128, 2, 2>(a, maxM, copad, out_f32, st);
-        case 64: return launch_bn<64, 2, 2>(a, maxM, copad, out_f32, st);
-        case 32: return launch_bn<32, 4, 1>(a, maxM, copad, out_f32, st);
+        case 128: return launch_bn<128, 128, 2, 2>(a, maxM, copad, out_f32, st);
+        case 64: return launch_bn<128, 64, 2, 2>(a, maxM, copad, out_f32, st);
+        case 32: return launch_bn<128, 32, 4, 1>(a, maxM, copad, out_f32, st);
         default: return E_UNSUPPORTED;
     }
 }

@@ -172,7 +172,7 @@ def _choose_splits(blocks: int, ksteps: int) -> int:
 PROFILE = None
 
 
-def igemm_kernel_label(N, Hi, Wi, Ci, CoStore, Co, k, stride, pad, mode, out_f32, splits, tile) -> str:
+def igemm_kernel_label(N, Hi, Wi, Ci, Ho, Wo, CoStore, Co, k, stride, pad, mode, out_f32, splits, tile) -> str:
     """Name of the kernel instantiation csrc/api.hip::fmri_igemm routes this geometry to (mirrors its rules)."""
     spatial = Hi * Wi > 1
     if (mode in (MODE_CONV, MODE_CONV_FLIP) and stride == 1 and k == 5 and pad == 2 and Ci in (8, 32) and Co <= 32
@@ -185,9 +185,15 @@ def igemm_kernel_label(N, Hi, Wi, Ci, CoStore, Co, k, stride, pad, mode, out_f32
         return f"fmri::igemm_win_kernel<{tile},2,2>"
     if unit and mode != MODE_TCONV2 and Ci in (8, 32):
         return f"fmri::igemm_patch_kernel<{tile}>"
+    uni = "true" if Ci % 64 == 0 else "false"
+    copad = ceil_to(Co, tile)
+    M = N * Ho * Wo if mode != MODE_TCONV2 else N * ((Ho + 1) // 2) * ((Wo + 1) // 2)
+    ncls = 4 if mode == MODE_TCONV2 else 1
+    if (tile == 128 and not out_f32 and splits == 1 and copad % 256 == 0
+            and ((M + 255) // 256) * (copad // 256) * ncls >= 192):
+        return f"fmri::igemm_kernel<256,256,2,4,false,{uni}>"
     wm, wn = (4, 1) if tile == 32 else (2, 2)
-    return (f"fmri::igemm_kernel<{tile},{wm},{wn},{'true' if out_f32 else 'false'},"
-            f"{'true' if Ci % 64 == 0 else 'false'}>")
+    return f"fmri::igemm_kernel<128,{tile},{wm},{wn},{'true' if out_f32 else 'false'},{uni}>"
 
 
 def run_igemm(x, pw: PackedWeight, out, bias, N, Hi, Wi, Ci, Ho, Wo, CoStore, Co, k, stride, pad, mode, act, out_f32,
@@ -201,7 +207,8 @@ def run_igemm(x, pw: PackedWeight, out, bias, N, Hi, Wi, Ci, Ho, Wo, CoStore, Co
              CoStore, Co, k, stride, pad, mode, act, 1 if out_f32 else 0, splits, slab_stride, tile)
     if prof:
         e1.record()
-        PROFILE.append((igemm_kernel_label(N, Hi, Wi, Ci, CoStore, Co, k, stride, pad, mode, out_f32, splits, tile),
+        PROFILE.append((igemm_kernel_label(N, Hi, Wi, Ci, Ho, Wo, CoStore, Co, k, stride, pad, mode, out_f32, splits,
+                                           tile),
                         e0, e1, flops))
 
 

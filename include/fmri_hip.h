@@ -81,6 +81,9 @@ int fmri_wgrad(const void* P, const void* Q, float* out, const void* zero16, int
  * to out + z*apad*ldo (stride-2, 128-row, 32-channel-block geometries only -- csrc/wgrad_win.hip -- else
  * FMRI_E_UNSUPPORTED).  For that kernel `splits` is the block budget per (128-row, 32-channel) group over the 4
  * parity planes; the number of slabs it writes is fmri_wgrad_slabs().
+ * atomic = 3: 5x5 stride-1 layers with A = 32, Bc = 8 only (csrc/wgrad_narrow.hip, else FMRI_E_UNSUPPORTED): out
+ * holds `splits` pre-zeroed slabs of apad*ldo floats that the blocks add into round-robin; fmri_unpack_grad sums
+ * them.
  * flip = 0: Q pixel = m*stride + tap - pad.  flip = 1 (stride 1 only): Q pixel = m + pad - tap, i.e. the roles of
  * the two activations are exchanged so that the GATHERED operand is the one with fewer channels. */
 int fmri_wgrad_slabs(int N, int Yc, int Xc, int k, int pad, int splits);

@@ -99,6 +99,22 @@ def test_conv_forward_dgrad_wgrad(cin, cout, stride, H, W, N):
     _close(g.grads["w"].cpu() * 4.0, wr.grad, "conv wgrad", tol=3e-3)
 
 
+def test_conv0_wgrad_large_batch_routes_to_narrow_kernel():
+    """discriminator.conv.0-shaped weight gradient with enough 8x8 tiles (>= 32768) to take the wave-private window
+    kernel (csrc/wgrad_narrow.hip); the small-batch cases above stay on the generic kernel."""
+    from fmri_hip.ops import ConvLayer
+    torch.manual_seed(5)
+    N, H = 512, 64
+    w = _h(torch.randn(32, 3, 5, 5) * 0.1)
+    x = _h(torch.randn(N, 3, H, H))
+    dy = _h(torch.randn(N, 32, H, H) * 0.1)
+    g = _G({"w": w})
+    layer = ConvLayer(g, "w", None, "conv", 3, 32, 5, 1, 2)
+    layer.wgrad(_nhwc16(x), _nhwc16(dy), 2.0)
+    ref = torch.nn.grad.conv2d_weight(x, w.shape, dy, stride=1, padding=2)
+    _close(g.grads["w"].cpu() * 2.0, ref, "conv0 wgrad (narrow kernel)", tol=3e-3)
+
+
 DECONV_CASES = [
     # cin, cout, H, out_pad, N
     (256, 256, 8, 1, 3),

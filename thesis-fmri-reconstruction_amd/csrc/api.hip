@@ -346,14 +346,14 @@ int fmri_wgrad(const void* P, const void* Q, float* out, const void* zero16, int
     const int T = k * k;
     if (ldo % 128 || ldo < T * Bc) return FMRI_E_BADARG;
     if (splits > 1 && !atomic) return FMRI_E_BADARG;
-    if (atomic < 0 || atomic > 2) return FMRI_E_BADARG;
+    if (atomic < 0 || atomic > 3) return FMRI_E_BADARG;
     const int64_t M = (int64_t)N * Yc * Xc;
     if (M < 1 || M > 0x7fffff00LL) return FMRI_E_BADARG;
     // stride-2 sampling, >= 128 rows, 32-channel column blocks, pre-zeroed fp32 output (atomic accumulation):
     // window-resident kernel (csrc/wgrad_win.hip).  FMRI_WGRAD_WIN=off disables.
     static const char* ww_env = getenv("FMRI_WGRAD_WIN");
     static const bool no_ww = ww_env && !strcmp(ww_env, "off");
-    if (!no_ww && stride == 2 && !flip && atomic && ba_tile == 128 && (Bc & 31) == 0 && Yc * Xc > 1 &&
+    if (!no_ww && stride == 2 && !flip && (atomic == 1 || atomic == 2) && ba_tile == 128 && (Bc & 31) == 0 && Yc * Xc > 1 &&
         (int64_t)N * Hq * Wq * Bc < 0x7fffffffLL && M * A < 0x7fffffffLL) {
         WgradWinArgs w;
         w.P = (const half_t*)P; w.Q = (const half_t*)Q; w.out = out; w.zero = (const half_t*)zero16;
@@ -389,6 +389,28 @@ int fmri_wgrad(const void* P, const void* Q, float* out, const void* zero16, int
             w.fdTX = make_fastdiv((uint32_t)w.tiles_x);
             return wgrad_win_launch(w, apad, S(stream));
         }
+    }
+    // 5x5 stride-1 layers between 32 and 3(8) channels, pre-zeroed output: wave-private window kernel
+    // (csrc/wgrad_narrow.hip).  FMRI_WGRAD_NARROW=off disables.
+    static const char* wn_env = getenv("FMRI_WGRAD_NARROW");
+    static const bool no_wn = wn_env && !strcmp(wn_env, "off");
+    if (atomic == 3 && (no_wn || !(stride == 1 && k == 5 && pad == 2 && A == 32 && Bc == 8 && apad == 32 && Yc == Hq &&
+                           Xc == Wq)))
+        return FMRI_E_UNSUPPORTED;
+    if (atomic == 3 && stride == 1 && k == 5 && pad == 2 && A == 32 && Bc == 8 && apad == 32 && Yc == Hq &&
+        Xc == Wq && (int64_t)N * Yc * Xc * 32 < 0x7fffffffLL) {
+        WgradNarrowArgs w;
+        w.P = (const half_t*)P; w.Q = (const half_t*)Q; w.out = out; w.zero = (const half_t*)zero16;
+        w.N = N; w.H = Yc; w.W = Xc; w.ldo = ldo; w.flip = flip;
+        w.tiles_y = (Yc + 7) / 8; w.tiles_x = (Xc + 7) / 8;
+        w.ntiles = N * w.tiles_y * w.tiles_x;
+        int nb = (w.ntiles + 63) / 64;              // >= 16 tiles per wave, at most two 4-wave blocks per CU
+        if (nb > 512) nb = 512;
+        if (nb < 1) nb = 1;
+        w.nslabs = splits < 1 ? 1 : splits;         // the caller allocated `splits` zeroed slabs of apad x ldo
+        w.pad0 = 0;
+        w.slab_stride = (int64_t)apad * ldo;
+        return wgrad_narrow_launch(w, nb, S(stream));
     }
     if (atomic == 2) return FMRI_E_UNSUPPORTED;      // per-split slabs exist only in the window-resident kernel
     WgradArgs a;

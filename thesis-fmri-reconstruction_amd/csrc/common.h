@@ -208,6 +208,19 @@ struct WgradWinArgs {
     FastDiv fdTPI, fdTX;
 };
 
+// weight gradient of the 5x5 stride-1 convolutions between 32 and 3(8) channels (wgrad_narrow.hip)
+struct WgradNarrowArgs {
+    const half_t* P;       // [N][H][W][32]
+    const half_t* Q;       // [N][H][W][8]
+    float* out;            // [32..][ldo] fp32, pre-zeroed (atomic accumulation), column = tap*8 + b
+    const half_t* zero;
+    int32_t N, H, W;
+    int32_t ldo, flip;
+    int32_t tiles_y, tiles_x, ntiles;
+    int32_t nslabs, pad0;          // out holds nslabs pre-zeroed partial matrices, slab_stride elements apart
+    int64_t slab_stride;
+};
+
 // 16-byte global -> LDS DMA.  LDS destination = wave-uniform base + lane*16.
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,

@@ -39,6 +39,7 @@ int igemm_tc32_launch(const Tc32Args& a, int nblocks, hipStream_t st);
 int igemm_narrow_launch(const NarrowArgs& a, int ci, int co_tiles, bool flip, hipStream_t st);
 int wgrad_launch(const WgradArgs& a, int apad, int ba_tile, hipStream_t st);
 int wgrad_win_launch(const WgradWinArgs& a, int apad, hipStream_t st);
+int wgrad_narrow_launch(const WgradNarrowArgs& a, int nblocks, hipStream_t st);
 
 int pack_weight_launch(const PackArgs& p, hipStream_t st);
 int unpack_grad_launch(const UnpackArgs& p, hipStream_t st);

@@ -214,6 +214,7 @@ def run_igemm(x, pw: PackedWeight, out, bias, N, Hi, Wi, Ci, Ho, Wo, CoStore, Co
 
 # window-resident wgrad kernel: on/off, resident-block target (2 per CU), largest split count still written as slabs
 _WW_ON = os.environ.get("FMRI_WGRAD_WIN") != "off"
+_WN_ON = os.environ.get("FMRI_WGRAD_NARROW") != "off"
 _WW_BLOCKS = int(os.environ.get("FMRI_WW_BLOCKS", "512"))
 _WW_SLABS = int(os.environ.get("FMRI_WW_SLABS", "24"))
 
@@ -236,6 +237,16 @@ def run_wgrad(P, Q, N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad, flip=0):
             out = torch.zeros(apad, ldo, dtype=torch.float32, device=P.device)
         lib.call("fmri_wgrad", _P(P), _P(Q), _P(out), _P(zero_page(P.device)), N, Yc, Xc, A, Hq, Wq, Bc, k, stride,
                  pad, flip, apad, ba, ldo, splits, 2 if slabs else 1)
+        return out, ldo
+    if (stride == 1 and k == 5 and pad == 2 and A == 32 and Bc == 8 and Yc == Hq and Xc == Wq and _WN_ON
+            and N * ((Yc + 7) // 8) * ((Xc + 7) // 8) >= 32768):
+        # wave-private window kernel (csrc/wgrad_narrow.hip): atomic accumulation into zeroed 32 x ldo slab(s).  It
+        # needs >= ~16 tiles per wave to amortise its block reduction: measured 1.9x on the 3B-image discriminator
+        # layer, a loss on the B-image decoder layer
+        nslabs = 1
+        out = torch.zeros(nslabs, apad, ldo, dtype=torch.float32, device=P.device)
+        lib.call("fmri_wgrad", _P(P), _P(Q), _P(out), _P(zero_page(P.device)), N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad,
+                 flip, apad, ba, ldo, nslabs, 3)
         return out, ldo
     tiles = (ldo // 128) * (apad // ba)
     steps = (N * Yc * Xc + 63) // 64

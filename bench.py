@@ -80,7 +80,9 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="images per GPU (weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--local-bn", action="store_true", help="per-rank BN statistics (no SyncBN exchange)")
-    ap.add_argument("--eager", action="store_true", help="issue every launch from Python instead of replaying a graph")
+    ap.add_argument("--eager", action="store_true", help="issue every launch from Python (no graph capture)")
+    ap.add_argument("--graph", action="store_true", help="always replay the captured graph(s) (default: whichever of "
+                    "eager / graph replay probes faster on this host)")
     a = ap.parse_args()
 
     # stdout must carry exactly one JSON line: native libraries (the RCCL version banner at communicator creation)
@@ -127,15 +129,40 @@ def main():
             log("first step done")
     barrier()
     log("warm-up done")
-    # Single process: the step (forward, losses, gate, two-stream backward, three optimizer updates, weight repack) is
-    # recorded once into a HIP graph and the K timed steps are K replays -- the same launches, issued by the GPU front
-    # end instead of ~370 Python/ctypes calls, so the number no longer depends on the host CPU of the box.
-    # Multi-process runs (RCCL collectives between the launches) issue the step eagerly.
-    use_graph = world == 1 and not a.eager and not force_dist
-    run = st.capture(x, nz[0], nz[1]) if use_graph else (lambda: st.step(x, nz[0], nz[1]))
-    if use_graph:
-        run()
-        log("step captured into a HIP graph")
+    # The step (forward, losses, gate, two-stream backward, three optimizer updates, weight repack) is recorded once
+    # into HIP graphs and the K timed steps are K replays -- the same launches, issued by the GPU front end instead of
+    # ~370 Python/ctypes calls, so the number does not depend on the host CPU of the box.  In multi-process runs the
+    # RCCL collectives stay eager calls between the graph segments.  --eager issues every launch from Python.
+    eager_run = lambda: st.step(x, nz[0], nz[1])
+    use_graph = False
+    run = eager_run
+    graph_run = None
+    if not a.eager:
+        try:
+            graph_run = st.capture(x, nz[0], nz[1])
+            graph_run()
+            log("step captured into HIP graph(s)")
+        except Exception as e:               # capture is an optimisation: fall back to eager launches
+            log(f"graph capture failed ({type(e).__name__}: {e}); continuing with eager launches")
+            graph_run = None
+    if graph_run is not None:
+
+        def probe(fn, n=3):
+            barrier()
+            t = time.perf_counter()
+            for _ in range(n):
+                fn()
+            barrier()
+            tt = torch.tensor([time.perf_counter() - t], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)      # every rank takes the same decision
+            return float(tt.item()) / n
+
+        t_eager, t_graph = probe(eager_run), probe(graph_run)
+        use_graph = a.graph or t_graph <= t_eager
+        run = graph_run if use_graph else eager_run
+        log(f"probe: eager {1e3 * t_eager:.2f} ms/step, graph {1e3 * t_graph:.2f} ms/step -> "
+            f"{'graph' if use_graph else 'eager'}")
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -183,7 +210,8 @@ def main():
                          "launches_per_step": nl // max(prof_steps, 1),
                          "avg_launch_ms": round(ms / nl, 4),
                          "avg_launch_gflop": round(fl / nl / 1e9, 2)},
-            "launch": "hip-graph replay" if use_graph else "eager",
+            "launch": ("hip-graph replay" if world == 1 and not force_dist else "hip-graph segments + eager collectives")
+            if use_graph else "eager",
             "step_mfma_frac": round(value / world * FLOP_PER_IMAGE / 1e12 / MFMA_PEAK_TFLOPS, 4),
             "losses_last_step": {k: logs[k] for k in ("loss_encoder", "loss_decoder", "loss_discriminator", "kl")},
         }

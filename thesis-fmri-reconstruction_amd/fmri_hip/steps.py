@@ -83,6 +83,41 @@ class _Optim:
         g.version += 1
 
 
+class _SegmentRecorder:
+    """Records a step as an alternating list of HIP graphs and eagerly issued collectives.
+
+    Collectives stay outside the graphs (they are issued exactly as in the eager step, RCCL sees nothing new); every
+    run of kernel launches between two collectives becomes one graph.  A data-parallel step is then ~37 graph launches
+    + 36 collective calls on the host instead of ~400 kernel launches."""
+
+    def __init__(self):
+        self.pool = torch.cuda.graph_pool_handle()
+        self.items = []          # torch.cuda.CUDAGraph or a zero-argument callable
+        self.cur = None
+
+    def begin(self):
+        self.cur = torch.cuda.CUDAGraph()
+        self.cur.capture_begin(pool=self.pool, capture_error_mode="thread_local")
+
+    def end(self):
+        self.cur.capture_end()
+        self.items.append(self.cur)
+        self.cur = None
+
+    def collective(self, fn):
+        self.end()
+        fn()                     # communicator warm, same call order as at replay; operates on not-yet-computed data
+        self.items.append(fn)
+        self.begin()
+
+    def replay(self):
+        for it in self.items:
+            if isinstance(it, torch.cuda.CUDAGraph):
+                it.replay()
+            else:
+                it()
+
+
 class _Dist:
     """Data-parallel glue (one process per GPU, RCCL): SUM all-reduce of flat gradients / loss scalars and
     the SyncBN statistic exchange.  Inactive (world size 1) unless torch.distributed is initialised."""
@@ -96,8 +131,14 @@ class _Dist:
         self.world = dist.get_world_size() if self.on else 1
         self.sync_bn = sync_bn
 
+    recorder: Optional[_SegmentRecorder] = None
+
     def all_reduce(self, t: torch.Tensor):
-        if self.on:
+        if not self.on:
+            return
+        if self.recorder is not None:
+            self.recorder.collective(lambda: self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM))
+        else:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
 
     def bn_reducer(self):
@@ -105,7 +146,7 @@ class _Dist:
             return None
 
         def red(sums):
-            self.dist.all_reduce(sums, op=self.dist.ReduceOp.SUM)
+            self.all_reduce(sums)
             return self.world
         return red
 
@@ -177,15 +218,35 @@ class _GanStepBase:
         gate, the stream normalisation and the optimizer gating all live on the device), so the ~370 launches of a
         step can be replayed as one graph: the step time then no longer depends on how fast the host can issue them.
         Inputs are read from ``static_inputs`` at every replay -- copy each new batch into those tensors.  RMSprop
-        steps only (Adam's bias correction is a host-side scalar per step)."""
-        if self.dd.on:
-            raise RuntimeError("graph capture is only wired for single-process runs")
+        steps only (Adam's bias correction is a host-side scalar per step).  In a data-parallel run the collectives
+        are kept out of the graphs (see _SegmentRecorder)."""
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
                 self.step(*static_inputs)
         torch.cuda.current_stream().wait_stream(side)
+        if self.dd.on:
+            # data-parallel: the collectives stay eager, the launches between them become graphs
+            rec = _SegmentRecorder()
+            self.dd.recorder = rec
+            try:
+                with torch.cuda.stream(side):
+                    rec.begin()
+                    self.step(*static_inputs)
+                    rec.end()
+            except BaseException:
+                if rec.cur is not None:          # leave no stream capture open behind a failed recording
+                    try:
+                        rec.cur.capture_end()
+                    except Exception:
+                        pass
+                raise
+            finally:
+                self.dd.recorder = None
+            torch.cuda.current_stream().wait_stream(side)
+            self._graph = rec
+            return rec.replay
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             self.step(*static_inputs)

@@ -118,11 +118,15 @@ class EncoderNet:
         head32 = self.heads.forward(hfc)
         return head32, dict(acts=acts, raws=raws, svs=svs, flat=flat, raw_fc=raw_fc, hfc=hfc, svfc=svfc)
 
-    def backward(self, ctx, dhead16: torch.Tensor, scale: float):
-        """Accumulate encoder parameter gradients of (1/scale)*<dhead16, head>."""
+    def backward(self, ctx, dhead16: torch.Tensor, scale: float, after_fc=None):
+        """Accumulate encoder parameter gradients of (1/scale)*<dhead16, head>.  ``after_fc`` is called once the
+        gradients of fc.0 / fc.1 / l_mu / l_var -- the tail of the flat buffer from ``fc.0.weight`` on, 93 % of its
+        bytes -- are final, so a data-parallel run can start reducing them under the conv backward."""
         dh = self.heads.backward(ctx["hfc"], dhead16, scale)
         draw_fc, _ = self.fc_bn.backward(ctx["raw_fc"], dh, ctx["svfc"], True, scale)
         self.fc.wgrad(ctx["flat"], draw_fc, scale)
+        if after_fc is not None:
+            after_fc()
         dflat, _ = self.fc.dgrad(draw_fc)
         d = dflat.reshape(ctx["acts"][3].shape)
         for i in (2, 1, 0):

@@ -88,6 +88,15 @@ int fmri_wgrad(const void* P, const void* Q, float* out, const void* zero16, int
  * the two activations are exchanged so that the GATHERED operand is the one with fewer channels. */
 int fmri_wgrad_slabs(int N, int Yc, int Xc, int k, int pad, int splits);
 
+/* ---- evaluation metrics of the validation loop (train/train_utils.py) ------------------------------
+ * fmri_pcc : PearsonCorrelation.forward (:276-292) over n fp32 elements (whole batch), *out = coefficient.
+ * fmri_ssim: StructuralSimilarity.forward (:343-420, size_average=True): mean SSIM (and the mean contrast term of
+ *            full=True) over planes = N*C images of H x W (>= 11), 11x11 Gaussian sigma 1.5, zero padding.
+ * ws5 / ws2: 5 / 2 doubles of device scratch (zeroed by the call). */
+int fmri_pcc(const float* pred, const float* truth, int64_t n, double* ws5, float* out, void* stream);
+int fmri_ssim(const float* img1, const float* img2, int planes, int H, int W, double* ws2, float* ssim,
+              float* contrast, void* stream);
+
 /* ---- layout casts ------------------------------------------------------------------------------- */
 int fmri_nchw_to_nhwc(const float* src, void* dst, int N, int C, int HW, int Cp, void* stream);
 int fmri_nhwc_to_nchw(const void* src, float* dst, int N, int C, int HW, int Cp, float scale, void* stream);

@@ -569,6 +569,72 @@ def case_dual1(name, cfg, B, seed, perturb, steps=3, lam=1.0):
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
 
 
+def case_metrics(name):
+    """PearsonCorrelation / StructuralSimilarity of the reference's train/train_utils.py on seeded image batches."""
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    tv = types.ModuleType("torchvision")
+    tvm = types.ModuleType("torchvision.models")
+    tvu = types.ModuleType("torchvision.utils")
+    tvu.make_grid = tvu.save_image = lambda *a, **k: None
+    tv.models, tv.utils = tvm, tvu
+    sys.modules.update({"torchvision": tv, "torchvision.models": tvm, "torchvision.utils": tvu})
+    for m in ("train.train_utils", "train"):
+        sys.modules.pop(m, None)
+    tu = importlib.import_module("train.train_utils")
+    pcc, ssim = tu.PearsonCorrelation(), tu.StructuralSimilarity()
+    out = {"meta/case": np.array("metrics")}
+    cases = [("b8_64", 8, 64, 64, 21), ("b3_100", 3, 100, 100, 22), ("b2_50x37", 2, 50, 37, 23)]
+    out["meta/cases"] = np.array([c[0] for c in cases])
+    for tag, n, h, w, seed in cases:
+        rs = np.random.RandomState(seed)
+        a = torch.from_numpy(rs.uniform(-1, 1, (n, 3, h, w)).astype(np.float32))
+        b = (0.6 * a + 0.4 * torch.from_numpy(rs.uniform(-1, 1, (n, 3, h, w)).astype(np.float32)))
+        s, c = ssim(a, b, full=True)
+        out[f"{tag}/shape"] = np.array([n, 3, h, w, seed])
+        out[f"{tag}/pcc"] = np.float64(pcc(a, b).item())
+        out[f"{tag}/ssim"] = np.float64(s.item())
+        out[f"{tag}/contrast"] = np.float64(c.item())
+        out[f"{tag}/ssim_default"] = np.float64(ssim(a, b).item())
+        print(name, tag, out[f"{tag}/pcc"], out[f"{tag}/ssim"], out[f"{tag}/contrast"])
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+
+
+def eval_state(cfg, seed):
+    """Recipe weights with non-trivial BN running statistics (as after some training)."""
+    sd = O.fill_state(O.vaegan_spec(cfg), seed, True)
+    rs = np.random.RandomState(seed + 1000)
+    for k in sd:
+        if k.endswith("running_mean"):
+            sd[k] = torch.from_numpy(rs.uniform(-0.2, 0.2, tuple(sd[k].shape)).astype(np.float32))
+        elif k.endswith("running_var"):
+            sd[k] = torch.from_numpy(rs.uniform(0.5, 1.5, tuple(sd[k].shape)).astype(np.float32))
+    return sd
+
+
+def case_eval(name, cfg, B, seed):
+    """Eval-mode forward of the reference VaeGan (models/vae_gan.py:288-297): BN with running statistics."""
+    vg = load_reference(cfg)
+    model = vg.VaeGan(device="cpu", z_size=cfg.latent_dim)
+    model.load_state_dict(eval_state(cfg, seed))
+    model.eval()
+    data = O.synth_batch(B, cfg, seed=1234, steps=1)
+    x, eps = data["x"], data["noise"][0, 0]
+    with torch.no_grad():
+        mus, lv = model.encoder(x)
+        x_tilde = model.decoder(eps * torch.exp(0.5 * lv) + mus)
+        x_p = model.decoder(data["noise"][0, 1])
+        torch.manual_seed(3)
+        ref = model(x)
+        torch.manual_seed(3)
+        e2 = torch.empty(B, cfg.latent_dim).normal_()
+        assert torch.equal(ref, model.decoder(e2 * torch.exp(0.5 * lv) + mus))
+    out = {"meta/case": np.array("eval"), "meta/B": B, "meta/seed": seed, "meta/image_size": cfg.image_size}
+    pack(out, "fw", {k: O.tensor_summary(v) for k, v in dict(mus=mus, log_variances=lv, x_tilde=x_tilde, x_p=x_p).items()})
+    print(name, float(x_tilde.norm()))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     which = sys.argv[1:] or ["all"]
@@ -594,3 +660,7 @@ if __name__ == "__main__":
         case_wae23("wae3_b4", O.ArchCfg.px64(), B=4, V=4096, seed=7, stage=3)
     if want("dual1_b4"):
         case_dual1("dual1_b4", O.ArchCfg.px64(), B=4, seed=8, perturb=True)
+    if want("metrics"):
+        case_metrics("metrics")
+    if want("eval_b4"):
+        case_eval("eval_b4", O.ArchCfg.px64(), B=4, seed=9)

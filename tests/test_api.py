@@ -144,3 +144,35 @@ def test_literal_reference_loop_body_runs_on_engine():
     assert out.shape == (B, 3, 64, 64) and torch.isfinite(out).all()
     gen = model(None, 5)
     assert gen.shape == (5, 3, 64, 64)
+
+
+@pytest.mark.gpu
+def test_eval_forward_matches_reference_golden(golden_dir):
+    """Inference path of the drop-in modules (BN with running statistics) against the reference's eval forward."""
+    from oracle import vaegan_oracle as O
+    from test_oracle_golden import eval_state
+    _cfg64()
+    import models.vae_gan as vg
+    cfg = O.ArchCfg.px64()
+    g = np.load(os.path.join(golden_dir, "eval_b4.npz"))
+    B, seed = int(g["meta/B"]), int(g["meta/seed"])
+    dev = "cuda:0"
+    model = vg.VaeGan(device=dev, z_size=128).to(dev)
+    model.load_state_dict(eval_state(cfg, seed))
+    model.eval()
+    data = O.synth_batch(B, cfg, seed=1234, steps=1)
+    with torch.no_grad():
+        mus, lv = model.encoder(data["x"].to(dev))
+        x_tilde = model.decoder(data["noise"][0, 0].to(dev) * torch.exp(0.5 * lv) + mus)
+        x_p = model.decoder(data["noise"][0, 1].to(dev))
+        assert model(data["x"].to(dev)).shape == x_tilde.shape
+    for k, v in dict(mus=mus, log_variances=lv, x_tilde=x_tilde, x_p=x_p).items():
+        ref = g[f"fw/{k}"]
+        got = O.tensor_summary(v.float().cpu())
+        assert abs(got[0] - ref[0]) < 2e-3 * abs(ref[0]), (k, got[0], ref[0])          # L2 norm
+        assert np.abs(got[2:] - ref[2:]).max() < 5e-3 * max(np.abs(ref[2:]).max(), 1e-3), k   # head / tail elements
+    # running statistics and counters are untouched by eval-mode forwards
+    sd = model.state_dict()
+    ref_sd = eval_state(cfg, seed)
+    for k in ("encoder.conv.0.bn.running_mean", "decoder.fc.1.running_var", "decoder.conv.2.bn.num_batches_tracked"):
+        assert torch.equal(sd[k].cpu().reshape(-1).float(), ref_sd[k].reshape(-1).float()), k

@@ -175,3 +175,29 @@ def test_dual_stage1_matches_reference(golden_dir):
     for s in range(steps):
         out = O.dual_stage1_step(P, opts, data["x"], data["noise"][s], cfg, lam=float(g["meta/lam"]), keep_grads=True)
         _check_step(g, f"step{s}", out, P)
+
+
+def eval_state(cfg, seed):
+    sd = O.fill_state(O.vaegan_spec(cfg), seed, True)
+    rs = np.random.RandomState(seed + 1000)
+    for k in sd:
+        if k.endswith("running_mean"):
+            sd[k] = torch.from_numpy(rs.uniform(-0.2, 0.2, tuple(sd[k].shape)).astype(np.float32))
+        elif k.endswith("running_var"):
+            sd[k] = torch.from_numpy(rs.uniform(0.5, 1.5, tuple(sd[k].shape)).astype(np.float32))
+    return sd
+
+
+def test_eval_forward_matches_reference(golden_dir):
+    """Inference path (models/vae_gan.py:288-297): BN layers use their running statistics."""
+    cfg = O.ArchCfg.px64()
+    g = _load(golden_dir, "eval_b4")
+    B, seed = int(g["meta/B"]), int(g["meta/seed"])
+    P = eval_state(cfg, seed)
+    data = O.synth_batch(B, cfg, seed=1234, steps=1)
+    with torch.no_grad():
+        mus, lv = O.encoder_fwd(P, "encoder.", data["x"], cfg, train=False)
+        x_tilde = O.decoder_fwd(P, "decoder.", O.reparameterize(mus, lv, data["noise"][0, 0]), cfg, train=False)
+        x_p = O.decoder_fwd(P, "decoder.", data["noise"][0, 1], cfg, train=False)
+    for k, v in dict(mus=mus, log_variances=lv, x_tilde=x_tilde, x_p=x_p).items():
+        _check_summ(g[f"fw/{k}"], O.tensor_summary(v), f"eval fw {k}")

@@ -34,6 +34,17 @@ void tconv_classes(int k, int pad, int ci, int rows_pad, TClass out[4]) {
 
 extern "C" {
 
+/* ---- evaluation metrics (train/train_utils.py:267-292, :295-420) ---- */
+int fmri_pcc(const float* pred, const float* truth, int64_t n, double* ws5, float* out, void* stream) {
+    if (!pred || !truth || !ws5 || !out || n < 2) return FMRI_E_BADARG;
+    return pcc_launch(pred, truth, n, ws5, out, S(stream));
+}
+int fmri_ssim(const float* img1, const float* img2, int planes, int H, int W, double* ws2, float* ssim,
+              float* contrast, void* stream) {
+    if (!img1 || !img2 || !ws2 || planes < 1 || H < 1 || W < 1 || (!ssim && !contrast)) return FMRI_E_BADARG;
+    return ssim_launch(img1, img2, planes, H, W, ws2, ssim, contrast, S(stream));
+}
+
 int fmri_version(void) { return 100; }
 
 const char* fmri_last_error_string(int code) {

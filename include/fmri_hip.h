@@ -88,6 +88,15 @@ int fmri_wgrad(const void* P, const void* Q, float* out, const void* zero16, int
  * the two activations are exchanged so that the GATHERED operand is the one with fewer channels. */
 int fmri_wgrad_slabs(int N, int Yc, int Xc, int k, int pad, int splits);
 
+/* ---- batch ingest: uint8 [N][H][W][C = 1|3] (already cropped / resized) -> normalised fp16 NHWC8 (engine input)
+ * and / or fp32 NCHW (module API input).  Per image: optional horizontal flip (flip_dev[n] != 0, may be NULL), then an
+ * integer shift (shift_dev[2n] rows, [2n+1] columns, edge-replicated like scipy.ndimage.shift(order=0, 'nearest'),
+ * may be NULL), u8/255, grey -> 3 channels, (v - mean) / std.  Replaces RandomHorizontalFlip / RandomShift / ToTensor
+ * / GreyToColor / Normalize of train_vgan_stage1.py:162-170 and data_preprocessing/data_loader.py:186-217,374-401. */
+int fmri_ingest_u8(const uint8_t* src, int N, int H, int W, int C, const int* flip_dev, const int* shift_dev,
+                   float mean0, float mean1, float mean2, float std0, float std1, float std2, void* dst16,
+                   float* dst32, void* stream);
+
 /* ---- evaluation metrics of the validation loop (train/train_utils.py) ------------------------------
  * fmri_pcc : PearsonCorrelation.forward (:276-292) over n fp32 elements (whole batch), *out = coefficient.
  * fmri_ssim: StructuralSimilarity.forward (:343-420, size_average=True): mean SSIM (and the mean contrast term of

@@ -635,6 +635,37 @@ def case_eval(name, cfg, B, seed):
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
 
 
+def case_ingest(name):
+    """Tail of the image pipeline on uint8 images: torchvision-0.5 / scipy semantics evaluated with the real libraries
+    that are present here (scipy.ndimage.shift as called at data_preprocessing/data_loader.py:216; ToTensor /
+    Normalize / flip restated with torch ops -- torchvision itself is not installed in the build container)."""
+    from scipy.ndimage import shift as nd_shift
+    rs = np.random.RandomState(31)
+    out = {"meta/case": np.array("ingest")}
+    for tag, n, h, w, c in (("rgb", 3, 20, 24, 3), ("grey", 2, 17, 13, 1)):
+        img = rs.randint(0, 256, (n, h, w, c)).astype(np.uint8)
+        flip = rs.randint(0, 2, n).astype(np.int32)
+        shifts = rs.randint(-5, 6, (n, 2)).astype(np.int32)
+        mean, std = (0.5, 0.5, 0.5), (0.5, 0.5, 0.5)
+        res = []
+        for i in range(n):
+            a = img[i]
+            if flip[i]:
+                a = np.ascontiguousarray(a[:, ::-1, :])
+            a = nd_shift(a, [int(shifts[i, 0]), int(shifts[i, 1]), 0], prefilter=False, order=0, mode="nearest")
+            t = torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1))).float().div(255)      # ToTensor
+            if t.shape[0] != 3:
+                t = t.expand(3, h, w).clone()                                                       # GreyToColor
+            t = (t - torch.tensor(mean).view(3, 1, 1)) / torch.tensor(std).view(3, 1, 1)           # Normalize
+            res.append(t.numpy())
+        out[f"{tag}/img"] = img
+        out[f"{tag}/flip"] = flip
+        out[f"{tag}/shift"] = shifts
+        out[f"{tag}/out"] = np.stack(res).astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "written")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     which = sys.argv[1:] or ["all"]
@@ -664,3 +695,5 @@ if __name__ == "__main__":
         case_metrics("metrics")
     if want("eval_b4"):
         case_eval("eval_b4", O.ArchCfg.px64(), B=4, seed=9)
+    if want("ingest"):
+        case_ingest("ingest")

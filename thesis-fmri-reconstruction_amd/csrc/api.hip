@@ -34,6 +34,17 @@ void tconv_classes(int k, int pad, int ci, int rows_pad, TClass out[4]) {
 
 extern "C" {
 
+/* ---- batch ingest (tail of the image transforms of train_vgan_stage1.py:162-170, data_loader.py:186-217,374-401) ---- */
+int fmri_ingest_u8(const uint8_t* src, int N, int H, int W, int C, const int* flip_dev, const int* shift_dev,
+                   float mean0, float mean1, float mean2, float std0, float std1, float std2, void* dst16,
+                   float* dst32, void* stream) {
+    if (!src || N < 1 || H < 1 || W < 1 || (C != 1 && C != 3) || (!dst16 && !dst32) || std0 == 0.f || std1 == 0.f ||
+        std2 == 0.f)
+        return FMRI_E_BADARG;
+    const float m[3] = {mean0, mean1, mean2}, sd[3] = {std0, std1, std2};
+    return ingest_u8_launch(src, N, H, W, C, flip_dev, shift_dev, m, sd, (half_t*)dst16, dst32, S(stream));
+}
+
 /* ---- evaluation metrics (train/train_utils.py:267-292, :295-420) ---- */
 int fmri_pcc(const float* pred, const float* truth, int64_t n, double* ws5, float* out, void* stream) {
     if (!pred || !truth || !ws5 || !out || n < 2) return FMRI_E_BADARG;

@@ -98,6 +98,8 @@ int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, float l
                 float bc1, float bc2_sqrt, float gscale, const float* gdev, float clamp, const int* flag,
                 hipStream_t st);
 
+int ingest_u8_launch(const uint8_t* src, int N, int H, int W, int C, const int* flip, const int* shift,
+                     const float* mean3, const float* std3, half_t* dst16, float* dst32, hipStream_t st);
 int pcc_launch(const float* x, const float* y, int64_t n, double* sums5, float* out, hipStream_t st);
 int ssim_launch(const float* a, const float* b, int planes, int H, int W, double* acc2, float* ssim, float* contrast,
                 hipStream_t st);

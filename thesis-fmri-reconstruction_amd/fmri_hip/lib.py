@@ -23,6 +23,7 @@ _SIGS = {
     "fmri_pack_entry_bytes": [],
     "fmri_pack_entry_fill": [_p, _p, _p, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i],
     "fmri_pack_weight_batch": [_p, _i, _i, _p],
+    "fmri_ingest_u8": [_p, _i, _i, _i, _i, _p, _p, _f, _f, _f, _f, _f, _f, _p, _p, _p],
     "fmri_pcc": [_p, _p, _l, _p, _p, _p],
     "fmri_ssim": [_p, _p, _i, _i, _i, _p, _p, _p, _p],
     "fmri_unpack_grad": [_p, _p, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _l, _p],

@@ -646,3 +646,23 @@ def axpby(x: torch.Tensor, y: Optional[torch.Tensor], a: float, b: float, out: O
         out = torch.empty_like(x)
     lib.call("fmri_axpby_f16", _P(x), _P(y), _P(out), x.numel(), float(a), float(b), _P(a_dev))
     return out
+
+
+def ingest_u8(images_u8: torch.Tensor, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), flip: Optional[torch.Tensor] = None,
+              shift: Optional[torch.Tensor] = None, want16: bool = True, want32: bool = False):
+    """uint8 [N,H,W,C] (C = 1 or 3, device) -> (fp16 NHWC8 engine input or None, fp32 NCHW or None): per-image
+    horizontal flip (int32 [N]) and integer shift (int32 [N,2] = rows, cols; edge replicated), /255, grey -> RGB,
+    (v - mean) / std in one pass (csrc/ingest.hip)."""
+    require_gpu(images_u8)
+    assert images_u8.dtype == torch.uint8 and images_u8.dim() == 4 and images_u8.is_contiguous()
+    N, H, W, C = images_u8.shape
+    dev = images_u8.device
+    o16 = torch.empty(N, H, W, 8, dtype=torch.float16, device=dev) if want16 else None
+    o32 = torch.empty(N, 3, H, W, dtype=torch.float32, device=dev) if want32 else None
+    if flip is not None:
+        flip = flip.to(device=dev, dtype=torch.int32).contiguous()
+    if shift is not None:
+        shift = shift.to(device=dev, dtype=torch.int32).contiguous()
+    lib.call("fmri_ingest_u8", _P(images_u8), N, H, W, C, _P(flip), _P(shift), float(mean[0]), float(mean[1]),
+             float(mean[2]), float(std[0]), float(std[1]), float(std[2]), _P(o16), _P(o32))
+    return o16, o32

@@ -221,6 +221,12 @@ struct WgradNarrowArgs {
     int64_t slab_stride;
 };
 
+// Pin a wave-uniform kernel-argument value in an SGPR.  Fields of the by-value argument struct live in the kernarg
+// segment; under register pressure the compiler re-loads them (s_load + s_waitcnt lgkmcnt(0)) wherever they are used --
+// inside a K loop that is a chain of scalar-cache round trips per step that also drains the LDS counter.  After this
+// the value is opaque to the compiler: it must keep (or spill) the register instead of re-loading.
+#define FMRI_KEEP(x) asm volatile("" : "+s"(x))
+
 // 16-byte global -> LDS DMA.  LDS destination = wave-uniform base + lane*16.
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,

@@ -75,6 +75,18 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmArgs a) 
 
     const half_t* wrow = a.w + c.w_off + (int64_t)(co0 + trow) * c.Kpad + clog * 8;
 
+    // loop-invariant scalars of the K loop, pinned in SGPRs (see FMRI_KEEP)
+    int kT = c.T, kTW = c.TW, kdy0 = c.dy0, kdx0 = c.dx0, kdstep = c.dstep, kHi = a.Hi, kWi = a.Wi, kCi = a.Ci;
+    int kKpad = c.Kpad;
+    uint32_t tw_magic = c.fdTW.magic, tw_sh = c.fdTW.sh, cpt_magic = a.fdCpt.magic, cpt_sh = a.fdCpt.sh;
+    uint32_t ci_magic = a.fdCi.magic, ci_sh = a.fdCi.sh;
+    const half_t* kin = a.in;
+    const half_t* kzero = a.zero;
+    FMRI_KEEP(kT); FMRI_KEEP(kTW); FMRI_KEEP(kdy0); FMRI_KEEP(kdx0); FMRI_KEEP(kdstep); FMRI_KEEP(kHi); FMRI_KEEP(kWi);
+    FMRI_KEEP(kCi); FMRI_KEEP(kKpad); FMRI_KEEP(tw_magic); FMRI_KEEP(tw_sh); FMRI_KEEP(cpt_magic); FMRI_KEEP(cpt_sh);
+    FMRI_KEEP(ci_magic); FMRI_KEEP(ci_sh); FMRI_KEEP(kin); FMRI_KEEP(kzero);
+    const FastDiv fTW{tw_magic, tw_sh, (uint32_t)kTW, 0}, fCpt{cpt_magic, cpt_sh, 0, 0}, fCi{ci_magic, ci_sh, 0, 0};
+
     // UNI (Ci % 64 == 0): a K-step lies inside one tap, so the tap decode is wave-uniform (scalar) and a
     // row's source address is rowoff[i] + one scalar offset: no per-lane multiplies inside the K loop.
     int rowoff[4];
@@ -88,44 +100,44 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmArgs a) 
     auto stage_load = [&](int buf, int kstep) {
         char* dstA = smem + buf * STAGE + wave * (8 * 128);
         if (UNI) {
-            const int tap = (int)fd_div((uint32_t)kstep, a.fdCpt);
+            const int tap = (int)fd_div((uint32_t)kstep, fCpt);
             const int cstep = kstep - tap * cpt;
-            const int ty = (int)fd_div((uint32_t)tap, c.fdTW);
-            const int tx = tap - ty * c.TW;
-            const int dy = c.dy0 + ty * c.dstep;
-            const int dx = c.dx0 + tx * c.dstep;
-            const bool tv = tap < c.T;
-            const int tapoff = (dy * a.Wi + dx) * a.Ci + cstep * 64;
+            const int ty = (int)fd_div((uint32_t)tap, fTW);
+            const int tx = tap - ty * kTW;
+            const int dy = kdy0 + ty * kdstep;
+            const int dx = kdx0 + tx * kdstep;
+            const bool tv = tap < kT;
+            const int tapoff = (dy * kWi + dx) * kCi + cstep * 64;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int iy = iy0[i] + dy;
                 const int ix = ix0[i] + dx;
-                const bool ok = tv && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
-                const half_t* src = ok ? a.in + (rowoff[i] + tapoff) : a.zero;
+                const bool ok = tv && (unsigned)iy < (unsigned)kHi && (unsigned)ix < (unsigned)kWi;
+                const half_t* src = ok ? kin + (rowoff[i] + tapoff) : kzero;
                 glds16(src, dstA + i * (RPP * 128));
             }
         } else {
             const int k = kstep * 64 + clog * 8;
-            const int tap = (int)fd_div((uint32_t)k, a.fdCi);
-            const int ci = k - tap * a.Ci;
-            const int ty = (int)fd_div((uint32_t)tap, c.fdTW);
-            const int tx = tap - ty * c.TW;
-            const int dy = c.dy0 + ty * c.dstep;
-            const int dx = c.dx0 + tx * c.dstep;
-            const bool tv = tap < c.T;
+            const int tap = (int)fd_div((uint32_t)k, fCi);
+            const int ci = k - tap * kCi;
+            const int ty = (int)fd_div((uint32_t)tap, fTW);
+            const int tx = tap - ty * kTW;
+            const int dy = kdy0 + ty * kdstep;
+            const int dx = kdx0 + tx * kdstep;
+            const bool tv = tap < kT;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int iy = iy0[i] + dy;
                 const int ix = ix0[i] + dx;
-                const bool ok = tv && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
-                const half_t* src = ok ? a.in + ((int64_t)(pixbase[i] + iy * a.Wi + ix) * a.Ci + ci) : a.zero;
+                const bool ok = tv && (unsigned)iy < (unsigned)kHi && (unsigned)ix < (unsigned)kWi;
+                const half_t* src = ok ? kin + ((int64_t)(pixbase[i] + iy * kWi + ix) * kCi + ci) : kzero;
                 glds16(src, dstA + i * (RPP * 128));
             }
         }
         char* dstB = smem + buf * STAGE + A_BYTES + wave * (8 * 128);
         const half_t* wsrc = wrow + (int64_t)kstep * 64;
 #pragma unroll
-        for (int i = 0; i < BROWS; ++i) glds16(wsrc + (int64_t)i * RPP * c.Kpad, dstB + i * (RPP * 128));
+        for (int i = 0; i < BROWS; ++i) glds16(wsrc + (int64_t)i * RPP * kKpad, dstB + i * (RPP * 128));
     };
 
     f4 acc[TN][TM];

@@ -55,29 +55,45 @@ __global__ __launch_bounds__(256, 2) void igemm_win_kernel(const WinArgs a) {
     // q = e*256 + tid holds channels 8*cc..8*cc+7 of window pixel q>>3, cc = (q&7) ^ ((pixel>>1)&7))
     const int total_units = (c.IPB * IHW) << 3;
     int soff[MAXE];
+    {
+        // pinned (FMRI_KEEP): otherwise every unrolled iteration re-loads these inside its own `if`
+        int pIHW = IHW, pIW = c.IW, pIPB = c.IPB, pN = a.N, pHi = a.Hi, pWi = a.Wi, pCi = a.Ci;
+        int py0 = y0 + c.dymin, px0 = x0 + c.dxmin;
+        uint32_t ihw_magic = c.fdIHW.magic, ihw_sh = c.fdIHW.sh, iw_magic = c.fdIW.magic, iw_sh = c.fdIW.sh;
+        FMRI_KEEP(pIHW); FMRI_KEEP(pIW); FMRI_KEEP(pIPB); FMRI_KEEP(pN); FMRI_KEEP(pHi); FMRI_KEEP(pWi); FMRI_KEEP(pCi);
+        FMRI_KEEP(py0); FMRI_KEEP(px0); FMRI_KEEP(ihw_magic); FMRI_KEEP(ihw_sh); FMRI_KEEP(iw_magic); FMRI_KEEP(iw_sh);
+        const FastDiv fIHW{ihw_magic, ihw_sh, 0, 0}, fIW{iw_magic, iw_sh, 0, 0};
 #pragma unroll
-    for (int e = 0; e < MAXE; ++e) {
-        soff[e] = -1;
-        const int q = e * 256 + tid;
-        if (q < total_units) {
-            const int pixel = q >> 3;
-            const int ip = (int)fd_div((uint32_t)pixel, c.fdIHW);
-            const int rem = pixel - ip * IHW;
-            const int j = (int)fd_div((uint32_t)rem, c.fdIW);
-            const int i = rem - j * c.IW;
-            const int n = grp * c.IPB + ip;
-            const int iy = y0 + c.dymin + j, ix = x0 + c.dxmin + i;
-            if (n < a.N && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi)
-                soff[e] = ((n * a.Hi + iy) * a.Wi + ix) * a.Ci + (((q & 7) ^ ((pixel >> 1) & 7)) << 3);
+        for (int e = 0; e < MAXE; ++e) {
+            soff[e] = -1;
+            const int q = e * 256 + tid;
+            if (q < total_units) {
+                const int pixel = q >> 3;
+                const int ip = (int)fd_div((uint32_t)pixel, fIHW);
+                const int rem = pixel - ip * pIHW;
+                const int j = (int)fd_div((uint32_t)rem, fIW);
+                const int i = rem - j * pIW;
+                const int n = grp * pIPB + ip;
+                const int iy = py0 + j, ix = px0 + i;
+                if (n < pN && (unsigned)iy < (unsigned)pHi && (unsigned)ix < (unsigned)pWi)
+                    soff[e] = ((n * pHi + iy) * pWi + ix) * pCi + (((q & 7) ^ ((pixel >> 1) & 7)) << 3);
+            }
         }
     }
-    const int nsl = c.nslice;          // slices per window (wave-uniform), <= MAXE
+    // loop-invariant scalars of the K loop, pinned in SGPRs (see FMRI_KEEP)
+    int nsl = c.nslice;                // slices per window (wave-uniform), <= MAXE
+    int kwin = a.win_bytes, kKpad = c.Kpad, kCi = a.Ci, knch = a.nchunks, kpb = a.pbufs, kdstep = c.dstep, kTW = c.TW;
+    int kIW = c.IW;
+    const half_t* kin = a.in;
+    const half_t* kzero = a.zero;
+    FMRI_KEEP(nsl); FMRI_KEEP(kwin); FMRI_KEEP(kKpad); FMRI_KEEP(kCi); FMRI_KEEP(knch); FMRI_KEEP(kpb);
+    FMRI_KEEP(kdstep); FMRI_KEEP(kTW); FMRI_KEEP(kIW); FMRI_KEEP(kin); FMRI_KEEP(kzero);
     auto load_slices = [&](int buf, int chunk, int lo, int hi) {
-        char* dst = win0 + buf * a.win_bytes + wave * 1024;
-        const half_t* base = a.in + chunk * 64;
+        char* dst = win0 + buf * kwin + wave * 1024;
+        const half_t* base = kin + chunk * 64;
 #pragma unroll
         for (int e = 0; e < MAXE; ++e)
-            if (e >= lo && e < hi) glds16_raw(soff[e] >= 0 ? base + soff[e] : a.zero, dst + e * 4096);
+            if (e >= lo && e < hi) glds16_raw(soff[e] >= 0 ? base + soff[e] : kzero, dst + e * 4096);
     };
 
     // ---- weight tile DMA (rows = co, 64 k-values per step), XOR swizzled like igemm.hip
@@ -87,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void igemm_win_kernel(const WinArgs a) {
     auto load_w = [&](int buf, int k0) {
         char* dst = wbuf0 + buf * W_BYTES + wave * 1024;
 #pragma unroll
-        for (int i = 0; i < BROWS; ++i) glds16_raw(wrow + k0 + (int64_t)i * 32 * c.Kpad, dst + i * 4096);
+        for (int i = 0; i < BROWS; ++i) glds16_raw(wrow + k0 + (int64_t)i * 32 * kKpad, dst + i * 4096);
     };
 
     f4 acc[TN][TM];
@@ -112,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void igemm_win_kernel(const WinArgs a) {
 
     auto compute = [&](int wb, int pb, int dlt) {
         const char* Ws = wbuf0 + wb * W_BYTES;
-        const char* Ps = win0 + pb * a.win_bytes;
+        const char* Ps = win0 + pb * kwin;
         h8 af[2][TM], bf[2][TN];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -149,15 +165,15 @@ __global__ __launch_bounds__(256, 2) void igemm_win_kernel(const WinArgs a) {
     };
 
     // ---- K loop: chunk-major over 64-channel chunks, taps inner.  Weight row offset of (chunk, tap) = tap*Ci + chunk*64.
-    const int T = c.T;
-    const int nsteps = a.nchunks * T;
-    const int spt = c.spt;                       // window slices issued per tap (second buffer only)
+    int T = c.T, spt = c.spt;        // spt = window slices issued per tap (second buffer only)
+    FMRI_KEEP(T); FMRI_KEEP(spt);
+    const int nsteps = knch * T;
     load_slices(0, 0, 0, nsl);
     load_w(0, 0);
     int chunk = 0, tap = 0, tx = 0;
     int dlt = (c.dy0 - c.dymin) * c.IW + (c.dx0 - c.dxmin);       // window delta of tap 0
     const int dlt0 = dlt;
-    const int drow = c.dstep * c.IW - c.TW * c.dstep;              // delta correction at the end of a tap row
+    const int drow = kdstep * kIW - kTW * kdstep;              // delta correction at the end of a tap row
     int pend = 0;                                                  // slice DMAs issued behind the newest weight tile
     for (int s = 0; s < nsteps; ++s) {
         // weights of step s landed; at the first tap of a chunk the whole window must have landed too
@@ -170,9 +186,9 @@ __global__ __launch_bounds__(256, 2) void igemm_win_kernel(const WinArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         int ntap = tap + 1, nchunk = chunk;
         if (ntap == T) { ntap = 0; ++nchunk; }
-        if (s + 1 < nsteps) load_w((s + 1) & 1, ntap * a.Ci + nchunk * 64);
+        if (s + 1 < nsteps) load_w((s + 1) & 1, ntap * kCi + nchunk * 64);
         pend = 0;
-        if (a.pbufs == 2 && chunk + 1 < a.nchunks) {
+        if (kpb == 2 && chunk + 1 < knch) {
             const int lo = tap * spt;
             int hi = lo + spt;
             if (hi > nsl) hi = nsl;
@@ -181,16 +197,16 @@ __global__ __launch_bounds__(256, 2) void igemm_win_kernel(const WinArgs a) {
                 pend = hi - lo;
             }
         }
-        compute(s & 1, a.pbufs == 2 ? (chunk & 1) : 0, dlt);
+        compute(s & 1, kpb == 2 ? (chunk & 1) : 0, dlt);
         // advance the tap (scalar): next column, or first column of the next tap row
-        dlt += c.dstep;
-        if (++tx == c.TW) { tx = 0; dlt += drow; }
+        dlt += kdstep;
+        if (++tx == kTW) { tx = 0; dlt += drow; }
         tap = ntap;
         if (tap == 0) {
             chunk = nchunk;
             dlt = dlt0;
             tx = 0;
-            if (a.pbufs == 1 && chunk < a.nchunks) {
+            if (kpb == 1 && chunk < knch) {
                 // single window buffer: everyone is done with the old window, then reload (exposed once per chunk;
                 // the other block resident on the CU keeps the MFMAs busy meanwhile)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -63,20 +63,28 @@ __device__ __forceinline__ void wgrad_win_body(const WgradWinArgs& a, char* smem
     if (nsteps == 0 && a.slab_stride == 0) return;
     const int tpi = a.tiles_y * a.tiles_x;
 
+    // loop-invariant scalars of the K loop and the epilogue, pinned in SGPRs (see FMRI_KEEP)
+    int kYc = a.Yc, kXc = a.Xc, kA = a.A, kHq = a.Hq, kWq = a.Wq, kBc = a.Bc, ktx = a.tiles_x, ktpi = tpi;
+    uint32_t tpi_magic = a.fdTPI.magic, tpi_sh = a.fdTPI.sh, tx_magic = a.fdTX.magic, tx_sh = a.fdTX.sh;
+    const half_t* kzero = a.zero;
+    FMRI_KEEP(kYc); FMRI_KEEP(kXc); FMRI_KEEP(kA); FMRI_KEEP(kHq); FMRI_KEEP(kWq); FMRI_KEEP(kBc); FMRI_KEEP(ktx);
+    FMRI_KEEP(ktpi); FMRI_KEEP(tpi_magic); FMRI_KEEP(tpi_sh); FMRI_KEEP(tx_magic); FMRI_KEEP(tx_sh); FMRI_KEEP(kzero);
+    const FastDiv fTPI{tpi_magic, tpi_sh, 0, 0}, fTX{tx_magic, tx_sh, 0, 0};
+
     auto stage_load = [&](int buf, int t) {
         // tile -> (image, tile row, tile col): wave-uniform
-        const int n = (int)fd_div((uint32_t)t, a.fdTPI);
-        const int trem = t - n * tpi;
-        const int tyi = (int)fd_div((uint32_t)trem, a.fdTX);
-        const int txi = trem - tyi * a.tiles_x;
+        const int n = (int)fd_div((uint32_t)t, fTPI);
+        const int trem = t - n * ktpi;
+        const int tyi = (int)fd_div((uint32_t)trem, fTX);
+        const int txi = trem - tyi * ktx;
         const int y0 = tyi * 8, x0 = txi * 8;
         char* dstP = smem + buf * STAGE + wave * (4 * 256);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = trow + 16 * i;
             const int y = y0 + (r >> 3), x = x0 + (r & 7);
-            const bool ok = p_on && y < a.Yc && x < a.Xc;
-            const half_t* ps = ok ? pbase + (int64_t)((n * a.Yc + y) * a.Xc + x) * a.A : a.zero;
+            const bool ok = p_on && y < kYc && x < kXc;
+            const half_t* ps = ok ? pbase + (int64_t)((n * kYc + y) * kXc + x) * kA : kzero;
             glds16_raw(ps, dstP + i * (16 * 256));
         }
         char* dstW = smem + buf * STAGE + P_BYTES + wave * 1024;
@@ -85,8 +93,8 @@ __device__ __forceinline__ void wgrad_win_body(const WgradWinArgs& a, char* smem
             if (e * 4096 + wave * 1024 < W_BYTES) {      // wave-uniform
                 const int iy = 2 * (y0 + tminy + wj[e]) + py;
                 const int ix = 2 * (x0 + tminx + wi[e]) + px;
-                const bool ok = won[e] && (unsigned)iy < (unsigned)a.Hq && (unsigned)ix < (unsigned)a.Wq;
-                const half_t* qs = ok ? qbase + (int64_t)((n * a.Hq + iy) * a.Wq + ix) * a.Bc : a.zero;
+                const bool ok = won[e] && (unsigned)iy < (unsigned)kHq && (unsigned)ix < (unsigned)kWq;
+                const half_t* qs = ok ? qbase + (int64_t)((n * kHq + iy) * kWq + ix) * kBc : kzero;
                 glds16_raw(qs, dstW + e * 4096);
             }
         }
@@ -169,22 +177,25 @@ __device__ __forceinline__ void wgrad_win_body(const WgradWinArgs& a, char* smem
     // once: the four planes cover all taps) and fmri_unpack_grad sums the slabs -- no atomics, no pre-zeroed buffer.
     // slab_stride == 0 (many splits over a small matrix): atomic adds into one pre-zeroed matrix.
     const int bcol = b0 + wb * 16 + (lane & 15);
-    if (bcol >= a.Bc) return;
-    float* const slab = a.out + (int64_t)split * a.slab_stride;
+    if (bcol >= kBc) return;
+    int kldo = a.ldo, kpad = a.pad, kTW = a.TW;
+    const bool slabs = a.slab_stride != 0;
+    float* slab = a.out + (int64_t)split * a.slab_stride;
+    FMRI_KEEP(kldo); FMRI_KEEP(kpad); FMRI_KEEP(kTW); FMRI_KEEP(slab);
 #pragma unroll
     for (int sy = 0; sy < NSY; ++sy)
 #pragma unroll
         for (int sx = 0; sx < NSX; ++sx) {
-            const int ty = 2 * (tminy + sy) + py + a.pad;
-            const int tx = 2 * (tminx + sx) + px + a.pad;
-            const int col = (ty * a.TW + tx) * a.Bc + bcol;
+            const int ty = 2 * (tminy + sy) + py + kpad;
+            const int tx = 2 * (tminx + sx) + px + kpad;
+            const int col = (ty * kTW + tx) * kBc + bcol;
 #pragma unroll
             for (int ta = 0; ta < TA; ++ta) {
                 const int arow = a0 + wa * 64 + ta * 16 + (lane >> 4) * 4;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float* o = slab + (int64_t)(arow + r) * a.ldo + col;
-                    if (a.slab_stride) *o = acc[sy * NSX + sx][ta][r];
+                    float* o = slab + (int64_t)(arow + r) * kldo + col;
+                    if (slabs) *o = acc[sy * NSX + sx][ta][r];
                     else atomicAdd(o, acc[sy * NSX + sx][ta][r]);
                 }
             }

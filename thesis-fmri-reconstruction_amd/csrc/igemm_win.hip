@@ -52,7 +52,12 @@ __global__ __launch_bounds__(256, 2) void igemm_win_kernel(const WinArgs a) {
     const int IHW = c.IH * c.IW;
 
     // ---- window DMA slices of this thread (slice e covers LDS bytes [e*4096, +4096) of a window buffer; 16-B unit
-    // q = e*256 + tid holds channels 8*cc..8*cc+7 of window pixel q>>3, cc = (q&7) ^ ((pixel>>1)&7))
+    // q = e*256 + tid holds channels 8*cc..8*cc+7 of window pixel q>>3, cc = (q&7) ^ (pixel&6)).
+    // Why pixel&6: a ds_read_b128 is served in 16-lane groups that mix two k-chunks c and c^1 (fq 0/1 or 2/3), each from
+    // 8 of 16 consecutive window pixels -- whatever the tap shift, those are all 8 residues mod 8.  Bank slot of (pixel,
+    // c) = 8*(pixel&1) + (c ^ pixel&6): per pixel parity the four pixels give c^{0,2,4,6} and (c^1)^{0,2,4,6} = all 8
+    // slots, so every group touches 16 distinct 16-B slots at ANY alignment (the former (pixel>>1)&7 was conflict-free
+    // only for shifts that are multiples of 4: 1.75-2 x the LDS cycles over the taps of a 5x5 kernel).
     const int total_units = (c.IPB * IHW) << 3;
     int soff[MAXE];
     {
@@ -76,7 +81,7 @@ __global__ __launch_bounds__(256, 2) void igemm_win_kernel(const WinArgs a) {
                 const int n = grp * pIPB + ip;
                 const int iy = py0 + j, ix = px0 + i;
                 if (n < pN && (unsigned)iy < (unsigned)pHi && (unsigned)ix < (unsigned)pWi)
-                    soff[e] = ((n * pHi + iy) * pWi + ix) * pCi + (((q & 7) ^ ((pixel >> 1) & 7)) << 3);
+                    soff[e] = ((n * pHi + iy) * pWi + ix) * pCi + (((q & 7) ^ (pixel & 6)) << 3);
             }
         }
     }
@@ -115,6 +120,11 @@ __global__ __launch_bounds__(256, 2) void igemm_win_kernel(const WinArgs a) {
     const int wm = wave / WN, wn = wave % WN;
     const int frow = lane & 15, fq = lane >> 4;
     const int tp_log2 = c.pw_log2 + c.ph_log2;
+    // GEMM row rr of an image's tile -> tile column.  16-wide tiles: plain row-major.  8-wide tiles hold two tile rows
+    // per 16-lane fragment; rotating row y by -y*IW makes the window pixels (mod 8) of the two rows complementary, which
+    // is what keeps the ds_read_b128 of A conflict-free for every tap shift (see the swizzle note above).
+    const int rotIW = c.pw_log2 == 3 ? c.IW : 0;
+    auto tile_x = [&](int rr) { return (rr - (rr >> 3) * rotIW) & (PW - 1); };
 
     // window pixel (tap delta 0) of the TM output pixels this lane feeds
     int base_pix[TM];
@@ -123,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void igemm_win_kernel(const WinArgs a) {
         const int r = wm * (BM / WM) + tm * 16 + frow;
         const int ip = r >> tp_log2;
         const int rr = r & ((1 << tp_log2) - 1);
-        base_pix[tm] = ip * IHW + (rr >> c.pw_log2) * c.IW + (rr & (PW - 1));
+        base_pix[tm] = ip * IHW + (rr >> c.pw_log2) * c.IW + tile_x(rr);
     }
 
     auto compute = [&](int wb, int pb, int dlt) {
@@ -135,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void igemm_win_kernel(const WinArgs a) {
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
                 const int pix = base_pix[tm] + dlt;
-                af[ks][tm] = *(const h8*)(Ps + (pix << 7) + (((ks * 4 + fq) ^ ((pix >> 1) & 7)) << 4));
+                af[ks][tm] = *(const h8*)(Ps + (pix << 7) + (((ks * 4 + fq) ^ (pix & 6)) << 4));
             }
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
@@ -224,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void igemm_win_kernel(const WinArgs a) {
         const int ip = r >> tp_log2;
         const int rr = r & ((1 << tp_log2) - 1);
         const int n = grp * c.IPB + ip;
-        const int y = y0 + (rr >> c.pw_log2), x = x0 + (rr & (PW - 1));
+        const int y = y0 + (rr >> c.pw_log2), x = x0 + tile_x(rr);
         if (n >= a.N || y >= c.Yc || x >= c.Xc) continue;
         const int64_t opix = ((int64_t)n * a.Ho + (y * a.os + c.oy0)) * a.Wo + (x * a.os + c.ox0);
         half_t* orow = a.out + opix * a.CoStore;

@@ -72,6 +72,24 @@ def cpu_baseline(batch: int, steps: int):
                        f"(BASELINE configs[0]) after 1 warm-up, torch {torch.__version__} fp32, {cores} threads")
 
 
+def pmc_traffic(label):
+    """(2*FETCH_SIZE + WRITE_SIZE) * 1024 per launch of the kernel `label`, from the committed rocprofv3 PMC passes of
+    this same command (tools/pmc_traffic.py); None when the file or the kernel is not there."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            kernels = json.load(f)["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None
+    want = label.replace(" ", "")
+    for name, v in kernels.items():
+        n = name.replace(" ", "")
+        n = n[4:] if n.startswith("void") else n
+        if n.split("(")[0] == want:
+            return v["bytes_per_launch"]
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -205,7 +223,9 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world,
                        "parallelism": f"dp{world}" + ("" if world == 1 else ("-localbn" if a.local_bn else "-syncbn"))},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(label),
+                         "traffic_unit": "bytes per launch leaving L2 (PMC passes of this workload recorded in "
+                                         "profiles/r01_pmc_traffic.json; hardware counters cannot be read in-process)",
                          "kernel": label,
                          "launches_per_step": nl // max(prof_steps, 1),
                          "avg_launch_ms": round(ms / nl, 4),

@@ -97,17 +97,22 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmArgs a) 
     }
     const int cpt = a.Ci >> 6;     // K-steps per tap (UNI)
 
+    int ltap = 0, lcstep = 0;                    // UNI: position of the step being staged in the chunk-major order
     auto stage_load = [&](int buf, int kstep) {
         char* dstA = smem + buf * STAGE + wave * (8 * 128);
+        int wstep = kstep;                       // weight column block of this step
         if (UNI) {
-            const int tap = (int)fd_div((uint32_t)kstep, fCpt);
-            const int cstep = kstep - tap * cpt;
+            // chunk-major K order (all taps of a 64-channel chunk, then the next chunk): the input bytes a block
+            // re-reads across taps are then one chunk of its pixel region, not all channels -- the L2-resident set
+            // (tap, cstep) of this step are carried by the K loop below (ltap, lcstep)
+            const int tap = ltap, cstep = lcstep;
             const int ty = (int)fd_div((uint32_t)tap, fTW);
             const int tx = tap - ty * kTW;
             const int dy = kdy0 + ty * kdstep;
             const int dx = kdx0 + tx * kdstep;
             const bool tv = tap < kT;
             const int tapoff = (dy * kWi + dx) * kCi + cstep * 64;
+            wstep = tap * cpt + cstep;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int iy = iy0[i] + dy;
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmArgs a) 
             }
         }
         char* dstB = smem + buf * STAGE + A_BYTES + wave * (8 * 128);
-        const half_t* wsrc = wrow + (int64_t)kstep * 64;
+        const half_t* wsrc = wrow + (int64_t)wstep * 64;
 #pragma unroll
         for (int i = 0; i < BROWS; ++i) glds16(wsrc + (int64_t)i * RPP * kKpad, dstB + i * (RPP * 128));
     };
@@ -221,11 +226,13 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmArgs a) 
     const int per = (c.ksteps + a.splits - 1) / a.splits;
     const int kb = split * per;
     const int ke = (kb + per < c.ksteps) ? kb + per : c.ksteps;
+    if (UNI) { lcstep = kb / kT; ltap = kb - lcstep * kT; }
     if (kb < ke) stage_load(0, kb);
     for (int it = kb; it < ke; ++it) {
         const int cur = (it - kb) & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (UNI && ++ltap == kT) { ltap = 0; ++lcstep; }
         if (it + 1 < ke) stage_load(cur ^ 1, it + 1);
         compute(cur);
     }

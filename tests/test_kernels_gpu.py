@@ -425,3 +425,68 @@ def test_igemm_routing_variants(route):
                        env=env, capture_output=True, text=True, timeout=600,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE configs[1] sizes (B = 256: discriminator batch 3B = 768, decoder batch 2B = 512).  The CPU reference
+# cannot run these in seconds, so the full-size launches are pinned through size-independent properties:
+#   * per-image independence of a convolution: three sampled images of the full-batch result equal the CPU fp32
+#     convolution of those three images alone (same tolerance as the small cases);
+#   * adjointness, with y = layer(x):  <y, y> = <dgrad(y), x> = <wgrad(x, y), w>  -- one scalar that ties the forward,
+#     data-gradient and weight-gradient kernels of a layer together at any size (fp64 dot products on the device;
+#     the cotangent is y itself so that the product is a sum of squares and rounding noise averages out).
+FULL_SIZE = [
+    # kind, cin, cout, stride, H, out_pad, N
+    ("conv", 3, 32, 1, 64, 0, 768),       # discriminator.conv.0
+    ("conv", 32, 128, 2, 64, 0, 768),     # discriminator.conv.1  (dgrad: igemm_tc32)
+    ("conv", 128, 256, 2, 32, 0, 768),    # discriminator.conv.2  (256x256 tile; dgrad: window-resident kernel)
+    ("conv", 256, 256, 2, 16, 0, 768),    # discriminator.conv.3
+    ("conv", 3, 64, 2, 64, 0, 256),       # encoder.conv.0
+    ("conv", 64, 128, 2, 32, 0, 256),     # encoder.conv.1
+    ("conv", 128, 256, 2, 16, 0, 256),    # encoder.conv.2
+    ("deconv", 256, 256, 2, 8, 1, 512),   # decoder.conv.0
+    ("deconv", 256, 128, 2, 16, 1, 512),  # decoder.conv.1
+    ("deconv", 128, 32, 2, 32, 1, 512),   # decoder.conv.2        (igemm_tc32)
+    ("conv", 32, 3, 1, 64, 0, 512),       # decoder.conv.3        (igemm_narrow)
+]
+
+
+@pytest.mark.parametrize("kind,cin,cout,stride,H,op,N", FULL_SIZE)
+def test_full_size_layers_sampled_images_and_adjoint_identities(kind, cin, cout, stride, H, op, N):
+    from fmri_hip.ops import ConvLayer, ACT_NONE, images_to_nhwc, nhwc_to_images
+    torch.manual_seed(cin * 7 + cout + H + N)
+    shape = (cout, cin, 5, 5) if kind == "conv" else (cin, cout, 5, 5)
+    w = _h(torch.randn(shape) * (1.0 / (5.0 * cin ** 0.5)))
+    g = _G({"w": w})
+    layer = ConvLayer(g, "w", None, kind, cin, cout, 5, stride, 2, op)
+    x = torch.randn(N, cin, H, H, device=DEV).half().float()
+    x16 = images_to_nhwc(x)
+    y16 = layer.forward(x16, ACT_NONE)
+    Ho = y16.shape[1]
+    # (1) sampled images against the CPU convolution
+    pick = [0, N // 2 + 1, N - 1]
+    xs = x[pick].cpu()
+    if kind == "conv":
+        ref = F.conv2d(xs, w, None, stride, 2)
+    else:
+        ref = F.conv_transpose2d(xs, w, None, 2, 2, output_padding=op)
+    assert ref.shape[2] == Ho
+    _close(nhwc_to_images(y16[pick].contiguous(), cout).cpu(), ref, f"{kind} fwd, sampled images")
+    # (2) adjoint identities with the cotangent y
+    yy = y16[..., :cout].double().pow(2).sum().item()
+    dx16 = layer.dgrad(y16, H, H)
+    lhs_d = (dx16[..., :cin].double() * x16[..., :cin].double()).sum().item()
+    layer.wgrad(x16, y16, 1.0)
+    lhs_w = (g.grads["w"].double() * g.views["w"].double()).sum().item()
+    assert yy > 0
+    # dgrad result is stored in fp16 (relative 2^-11 per element, random sign); the weight gradient is fp32
+    assert abs(lhs_d - yy) < 1e-3 * yy, (lhs_d, yy)
+    assert abs(lhs_w - yy) < 1e-3 * yy, (lhs_w, yy)
+    # (3) sampled images of the data gradient against the CPU (per-image independence holds for dgrad too)
+    ys = nhwc_to_images(y16[pick].contiguous(), cout).cpu()
+    xr = xs.clone().requires_grad_(True)
+    if kind == "conv":
+        F.conv2d(xr, w, None, stride, 2).backward(ys)
+    else:
+        F.conv_transpose2d(xr, w, None, 2, 2, output_padding=op).backward(ys)
+    _close(nhwc_to_images(dx16[pick].contiguous(), cin).cpu(), xr.grad, f"{kind} dgrad, sampled images")

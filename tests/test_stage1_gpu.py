@@ -118,3 +118,31 @@ def test_stage1_matches_reference_golden(golden_dir):
             continue
         got = eng[0]["state"][k].double().norm().item()
         assert _rel(got, summ[i][0]) < 2e-3, (k, got, summ[i][0])
+
+
+def test_stage1_full_batch_first_step_matches_oracle():
+    """BASELINE configs[1] (B = 256, the batch bench.py times): every logged loss of the first step against the CPU
+    oracle run live on the same seeded inputs (~10-20 s of CPU), gates equal, and the BatchNorm running statistics
+    after the step."""
+    from oracle import vaegan_oracle as O
+    from fmri_hip.params import ArchConfig
+    B, seed = 256, 0
+    cfg_o, cfg_e = O.ArchCfg.px64(), ArchConfig.px64()
+    data = O.synth_batch(B, cfg_o, seed=1234, steps=1)
+    eng = _run_engine(cfg_e, B, seed, True, 1, data["noise"], data["x"])[0]
+    P = O.fill_state(O.vaegan_spec(cfg_o), seed, True)
+    opts = {n: O.OptState(kind="rmsprop", lr=1e-4) for n in ("encoder", "decoder", "discriminator")}
+    ref = O.stage1_step(P, opts, data["x"], data["noise"][0, 0], data["noise"][0, 1], cfg_o)
+    for k in ("loss_encoder", "loss_decoder", "loss_discriminator", "nle", "kl", "mse", "bce_orig", "bce_pred",
+              "bce_samp"):
+        r = _rel(eng["logs"][k], ref["logs"][k])
+        print(k, eng["logs"][k], ref["logs"][k], r)
+        assert r < LOSS_RTOL, (k, eng["logs"][k], ref["logs"][k], r)
+    assert eng["logs"]["train_dis"] == ref["logs"]["train_dis"] and eng["logs"]["train_dec"] == ref["logs"]["train_dec"]
+    for k in ("x_tilde", "disc_class", "mus", "log_variances"):
+        err = _tensor_err(eng["outputs"][k], ref["fw"][k])
+        assert err < FW_TOL, (k, err)
+    for k, v in P.items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            err = _tensor_err(eng["state"][k], v)
+            assert err < 5e-3, (k, err)

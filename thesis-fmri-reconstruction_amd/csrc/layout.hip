@@ -122,9 +122,18 @@ __global__ __launch_bounds__(256) void unpack_tile_kernel(const UnpackArgs p, in
     for (int e = threadIdx.x; e < run * 32; e += 256) {
         const int tb = e >> 5, bl = e & 31;
         if (b0 + bl < p.B) {
-            float v = s[tb * p.Bp + bl];
-            for (int z = 1; z < p.nslabs; ++z) v += s[z * p.slab_stride + tb * p.Bp + bl];
-            t[bl * stride + tb] = v;
+            // slab sum with four loads in flight (a one-at-a-time loop is a chain of memory latencies)
+            const float* q = s + tb * p.Bp + bl;
+            float v0 = q[0], v1 = 0.f, v2 = 0.f, v3 = 0.f;
+            int z = 1;
+            for (; z + 3 < p.nslabs; z += 4) {
+                v0 += q[z * p.slab_stride];
+                v1 += q[(z + 1) * p.slab_stride];
+                v2 += q[(z + 2) * p.slab_stride];
+                v3 += q[(z + 3) * p.slab_stride];
+            }
+            for (; z < p.nslabs; ++z) v0 += q[z * p.slab_stride];
+            t[bl * stride + tb] = (v0 + v1) + (v2 + v3);
         }
     }
     __syncthreads();
@@ -274,7 +283,16 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int nslabs,
         const int64_t m = i / ld;
         float v = 0.f;
         if (c < C) {
-            for (int s = 0; s < nslabs; ++s) v += slabs[s * slab_stride + i];
+            float v1 = 0.f, v2 = 0.f, v3 = 0.f;
+            int s = 0;
+            for (; s + 3 < nslabs; s += 4) {       // four loads in flight
+                v += slabs[s * slab_stride + i];
+                v1 += slabs[(s + 1) * slab_stride + i];
+                v2 += slabs[(s + 2) * slab_stride + i];
+                v3 += slabs[(s + 3) * slab_stride + i];
+            }
+            for (; s < nslabs; ++s) v += slabs[s * slab_stride + i];
+            v = (v + v1) + (v2 + v3);
             if (bias) v += bias[c];
             v = act_apply(v, act);
         }

@@ -134,29 +134,31 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const half_t* __restrict
 // flight per thread): the partial matrix is small but a single serial chain per column is latency bound.
 // Optionally accumulates the folded sums into parameter gradients (BN backward: g0 += gscale * sums[0..C) = d beta,
 // g1 += gscale * sums[C..2C) = d gamma) -- one writer per element, no atomics.
-__global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restrict__ part, int nparts, int n,
-                                                            float* __restrict__ sums, float* __restrict__ g0,
-                                                            float* __restrict__ g1, float gscale) {
-    __shared__ float red[8][33];
+__global__ __launch_bounds__(1024) void fold_partials_kernel(const float* __restrict__ part, int nparts, int n,
+                                                             float* __restrict__ sums, float* __restrict__ g0,
+                                                             float* __restrict__ g1, float gscale) {
+    // 32 columns x 32 row lanes per block: the kernel is a chain of memory latencies (few blocks, tiny data), so the
+    // partial rows are spread over as many lanes as a block has and each lane keeps four loads in flight
+    __shared__ float red[32][33];
     const int cx = threadIdx.x & 31, gy = threadIdx.x >> 5;
     const int i = blockIdx.x * 32 + cx;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (i < n) {
         int p = gy;
-        for (; p + 24 < nparts; p += 32) {
+        for (; p + 96 < nparts; p += 128) {
             s0 += part[(int64_t)p * n + i];
-            s1 += part[(int64_t)(p + 8) * n + i];
-            s2 += part[(int64_t)(p + 16) * n + i];
-            s3 += part[(int64_t)(p + 24) * n + i];
+            s1 += part[(int64_t)(p + 32) * n + i];
+            s2 += part[(int64_t)(p + 64) * n + i];
+            s3 += part[(int64_t)(p + 96) * n + i];
         }
-        for (; p < nparts; p += 8) s0 += part[(int64_t)p * n + i];
+        for (; p < nparts; p += 32) s0 += part[(int64_t)p * n + i];
     }
     red[gy][cx] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (gy == 0 && i < n) {
         float s = 0.f;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) s += red[r][cx];
+        for (int r = 0; r < 32; ++r) s += red[r][cx];
         sums[i] = s;
         const int C = n >> 1;
         if (g0 && i < C) g0[i] += gscale * s;
@@ -282,7 +284,7 @@ static int reduce_launch(const half_t* x, const half_t* dy, half_t* dout, int M,
                        mean, rstd, gamma, beta, flag, sums ? ws : (float*)nullptr);
     if (sums) {
         const int n = 2 * C;
-        hipLaunchKernelGGL(fold_partials_kernel, dim3((n + 31) / 32), dim3(256), 0, st, ws, g.gy, n, sums, g0, g1,
+        hipLaunchKernelGGL(fold_partials_kernel, dim3((n + 31) / 32), dim3(1024), 0, st, ws, g.gy, n, sums, g0, g1,
                            gscale);
     }
     return LAUNCH_OK();

@@ -165,7 +165,7 @@ def main():
             graph_run = None
     if graph_run is not None:
 
-        def probe(fn, n=3):
+        def probe(fn, n=6):
             barrier()
             t = time.perf_counter()
             for _ in range(n):

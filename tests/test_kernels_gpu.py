@@ -29,6 +29,12 @@ def _close(got, ref, what, tol=2e-3):
     assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} off; max err {err.max():.3e} rms {rms:.3e}"
 
 
+def _join():
+    """Weight gradients are issued on the engine's side stream (ops.side_run): join before reading them."""
+    from fmri_hip.ops import join_side
+    join_side()
+
+
 def _nhwc16(x):   # NCHW fp32 cpu -> NHWC fp16 cuda, channels padded to 8
     from fmri_hip.ops import images_to_nhwc
     return images_to_nhwc(x.to(DEV))
@@ -96,6 +102,7 @@ def test_conv_forward_dgrad_wgrad(cin, cout, stride, H, W, N):
     dx16 = layer.dgrad(dy16, H, W)
     _close(_from_nhwc(dx16, cin), xr.grad, "conv dgrad")
     layer.wgrad(x16, dy16, 4.0)          # scale 4 -> grad accumulates dW/4
+    _join()
     _close(g.grads["w"].cpu() * 4.0, wr.grad, "conv wgrad", tol=3e-3)
 
 
@@ -111,6 +118,7 @@ def test_conv0_wgrad_large_batch_routes_to_narrow_kernel():
     g = _G({"w": w})
     layer = ConvLayer(g, "w", None, "conv", 3, 32, 5, 1, 2)
     layer.wgrad(_nhwc16(x), _nhwc16(dy), 2.0)
+    _join()
     ref = torch.nn.grad.conv2d_weight(x, w.shape, dy, stride=1, padding=2)
     _close(g.grads["w"].cpu() * 2.0, ref, "conv0 wgrad (narrow kernel)", tol=3e-3)
 
@@ -147,6 +155,7 @@ def test_deconv_forward_dgrad_wgrad(cin, cout, H, op, N):
     dx16 = layer.dgrad(dy16, H, H)
     _close(_from_nhwc(dx16, cin), xr.grad, "deconv dgrad")
     layer.wgrad(x16, dy16, 1.0)
+    _join()
     _close(g.grads["w"].cpu(), wr.grad, "deconv wgrad", tol=3e-3)
 
 
@@ -226,6 +235,7 @@ def test_dense_forward_dgrad_wgrad(M, K, N, in_perm, out_perm):
     _, dx32 = layer.dgrad(dy16, want32=True)
     _close(from_engine_in(dx32.cpu()), xr.grad, "dense dgrad fp32", tol=1e-3)
     layer.wgrad(x16, dy16, 2.0)
+    _join()
     _close(g.grads["w"].cpu() * 2.0, wr.grad, "dense wgrad", tol=3e-3)
     if not out_perm:
         layer.bias_grad(dy16, 2.0)
@@ -477,6 +487,7 @@ def test_full_size_layers_sampled_images_and_adjoint_identities(kind, cin, cout,
     dx16 = layer.dgrad(y16, H, H)
     lhs_d = (dx16[..., :cin].double() * x16[..., :cin].double()).sum().item()
     layer.wgrad(x16, y16, 1.0)
+    _join()
     lhs_w = (g.grads["w"].double() * g.views["w"].double()).sum().item()
     assert yy > 0
     # dgrad result is stored in fp16 (relative 2^-11 per element, random sign); the weight gradient is fp32

@@ -114,16 +114,17 @@ def test_wae_step_matches_oracle_and_golden(golden_dir, stage):
                     e = (grads[k].float().cpu() - v).norm().item() / max(v.norm().item(), 2e-3 * sib.norm().item())
                 if e > 0.1:
                     print("grad", k, e, float(v.norm()), float(grads[k].float().norm()))
-                if not (k.startswith("discriminator.") and k.endswith("bias")):
+                if k.startswith("discriminator."):
+                    # The "fake" and the "real" pass push the latent discriminator in opposite directions; with this
+                    # near-constant random-init discriminator (d = 0.505 for every row) they cancel 20-50 x in the
+                    # sum (oracle: main.6.weight 1.42 and 1.45 leave 0.047), and which hidden units sit exactly at
+                    # their ReLU threshold differs per row by less than fp16 resolution.  The error is therefore
+                    # bounded against the magnitude of the two terms (1 %), or 10 % of the remainder if that is larger.
+                    terms = ref["grad_terms"][k]
+                    d = (grads[k].float().cpu() - v).norm().item()
+                    assert d < max(0.1 * v.norm().item(), 1e-2 * terms), (k, d, v.norm().item(), terms)
+                else:
                     worst = max(worst, e)
-                if k.startswith("discriminator.") and k.endswith("bias"):
-                    # hidden-layer bias gradients are sums over the 2B rows of terms of both signs ("real" rows +, "fake"
-                    # rows -) that largely cancel; one ReLU mask flip (a pre-activation below fp16 resolution: ~4 are
-                    # expected among the 512 x 2B of a layer) moves an element by a whole row's contribution, so the
-                    # relative error of these vectors depends on which units flip (measured 0.03 ... 0.2)
-                    assert e < 0.35, (k, e)
-                elif k.startswith("discriminator."):
-                    assert e < 0.1, (k, e)        # 4 ReLU layers on fp16 latents: mask flips as in Stage I
             print(stage, "worst grad err", worst)
             assert worst < 0.25
         # running statistics after the first (sign-like) parameter update follow the 5e-2 "next forward" bound

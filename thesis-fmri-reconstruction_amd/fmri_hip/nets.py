@@ -15,7 +15,7 @@ from typing import List, Optional
 import torch
 
 from . import lib
-from .ops import (ACT_NONE, ACT_RELU, ACT_TANH, BatchNorm, ConvLayer, DenseLayer, act_backward, pad8)
+from .ops import (ACT_NONE, ACT_RELU, ACT_TANH, BatchNorm, ConvLayer, DenseLayer, act_backward, join_side, pad8)
 from .params import (ArchConfig, FlatGroup, cognitive_encoder_spec, decoder_spec, discriminator_spec, encoder_spec,
                      wae_discriminator_spec)
 
@@ -55,7 +55,7 @@ class FusedHeads:
         g = self.group.grads
         z = self.z
         self.gw.zero_()
-        self.dense.wgrad(h16, dhead16, scale)
+        self.dense._wgrad(h16, dhead16, scale)      # current stream: gw is read right below
         g["l_mu.weight"].add_(self.gw[:z])
         g["l_var.weight"].add_(self.gw[z:])
         bs = dhead16.float().sum(0) * (1.0 / scale)
@@ -118,7 +118,15 @@ class EncoderNet:
         head32 = self.heads.forward(hfc)
         return head32, dict(acts=acts, raws=raws, svs=svs, flat=flat, raw_fc=raw_fc, hfc=hfc, svfc=svfc)
 
-    def backward(self, ctx, dhead16: torch.Tensor, scale: float, after_fc=None):
+    def backward(self, *args, join: bool = True, **kwargs):
+        """``_backward`` + join of the side stream its weight gradients were issued on (ops.side_run).  ``join=False``
+        leaves them in flight (the caller joins with ops.join_side() before the gradients are read)."""
+        out = self._backward(*args, **kwargs)
+        if join:
+            join_side()
+        return out
+
+    def _backward(self, ctx, dhead16: torch.Tensor, scale: float, after_fc=None):
         """Accumulate encoder parameter gradients of (1/scale)*<dhead16, head>.  ``after_fc`` is called once the
         gradients of fc.0 / fc.1 / l_mu / l_var -- the tail of the flat buffer from ``fc.0.weight`` on, 93 % of its
         bytes -- are final, so a data-parallel run can start reducing them under the conv backward."""
@@ -126,6 +134,7 @@ class EncoderNet:
         draw_fc, _ = self.fc_bn.backward(ctx["raw_fc"], dh, ctx["svfc"], True, scale)
         self.fc.wgrad(ctx["flat"], draw_fc, scale)
         if after_fc is not None:
+            join_side()                                 # fc.0 weight gradient (side stream) is final
             after_fc()
         dflat, _ = self.fc.dgrad(draw_fc)
         d = dflat.reshape(ctx["acts"][3].shape)
@@ -155,7 +164,15 @@ class CognitiveEncoderNet:
         h, sv = self.fc1_bn.forward(raw, relu=True, updates=upd)
         return self.heads.forward(h), dict(x=fmri16, raw=raw, h=h, sv=sv)
 
-    def backward(self, ctx, dhead16, scale):
+    def backward(self, *args, join: bool = True, **kwargs):
+        """``_backward`` + join of the side stream its weight gradients were issued on (ops.side_run).  ``join=False``
+        leaves them in flight (the caller joins with ops.join_side() before the gradients are read)."""
+        out = self._backward(*args, **kwargs)
+        if join:
+            join_side()
+        return out
+
+    def _backward(self, ctx, dhead16, scale):
         dh = self.heads.backward(ctx["h"], dhead16, scale)
         draw, _ = self.fc1_bn.backward(ctx["raw"], dh, ctx["sv"], True, scale)
         self.fc1.wgrad(ctx["x"], draw, scale)
@@ -216,7 +233,15 @@ class DecoderNet:
         y = self.c3.forward(h, ACT_TANH, out=out)
         return y, dict(z=z16, raw_fc=raw_fc, sv_fc=sv_fc, acts=acts, raws=raws, svs=svs, y=y, B=B, groups=groups)
 
-    def backward(self, ctx, cot: torch.Tensor, entries: List[dict]):
+    def backward(self, *args, join: bool = True, **kwargs):
+        """``_backward`` + join of the side stream its weight gradients were issued on (ops.side_run).  ``join=False``
+        leaves them in flight (the caller joins with ops.join_side() before the gradients are read)."""
+        out = self._backward(*args, **kwargs)
+        if join:
+            join_side()
+        return out
+
+    def _backward(self, ctx, cot: torch.Tensor, entries: List[dict]):
         """cot [E*B,H,W,8] fp16 stacks E cotangent blocks w.r.t. the decoder output; entries[e] =
         dict(g=<forward group whose activations it belongs to>, scale=<float>, train=<accumulate param grads>,
         need_dz=<bool>).  Returns {e: dz fp32 [B, z] (true scale)} for entries with need_dz."""
@@ -308,7 +333,15 @@ class DiscriminatorNet:
         ctx.update(flat=flat, raw_fc=raw_fc, hfc=hfc, svfc=svfc)
         return raws[2], logit32, ctx
 
-    def backward(self, ctx, dlogit16: Optional[torch.Tensor], scale_a: float, dfeat16: Optional[torch.Tensor],
+    def backward(self, *args, join: bool = True, **kwargs):
+        """``_backward`` + join of the side stream its weight gradients were issued on (ops.side_run).  ``join=False``
+        leaves them in flight (the caller joins with ops.join_side() before the gradients are read)."""
+        out = self._backward(*args, **kwargs)
+        if join:
+            join_side()
+        return out
+
+    def _backward(self, ctx, dlogit16: Optional[torch.Tensor], scale_a: float, dfeat16: Optional[torch.Tensor],
                  scale_b: float, train: bool, img_rows: Optional[slice], img_streams=(True, True),
                  train_b: bool = False):
         """Two cotangent streams through one saved forward:
@@ -412,7 +445,15 @@ class WaeDiscriminatorNet:
         _, logit32 = self.layers[-1].forward(h, ACT_NONE, want16=False, want32=True)
         return logit32, dict(hs=hs)
 
-    def backward(self, ctx, dlogit16, scale, train: bool, need_dz: bool):
+    def backward(self, *args, join: bool = True, **kwargs):
+        """``_backward`` + join of the side stream its weight gradients were issued on (ops.side_run).  ``join=False``
+        leaves them in flight (the caller joins with ops.join_side() before the gradients are read)."""
+        out = self._backward(*args, **kwargs)
+        if join:
+            join_side()
+        return out
+
+    def _backward(self, ctx, dlogit16, scale, train: bool, need_dz: bool):
         d = dlogit16
         hs = ctx["hs"]
         for j in range(4, -1, -1):

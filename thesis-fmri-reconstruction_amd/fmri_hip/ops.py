@@ -219,6 +219,58 @@ _WW_BLOCKS = int(os.environ.get("FMRI_WW_BLOCKS", "512"))
 _WW_SLABS = int(os.environ.get("FMRI_WW_SLABS", "24"))
 
 
+# ------------------------------------------------------------------------------------------------
+# side stream for weight gradients
+# ------------------------------------------------------------------------------------------------
+# A layer's weight gradient depends only on (input activation, output cotangent) and nothing downstream of the backward
+# pass depends on it before the gradient buffers are all-reduced / consumed by the optimizer.  Issued on a second HIP
+# stream it runs beside the HBM-bound BatchNorm-backward kernels and the data-gradient GEMM of the same layer (MFMA-bound
+# next to bandwidth-bound work, and the tail of one GEMM grid filled by the next).  Under HIP-graph capture the fork /
+# join events become parallel branches of the graph.  FMRI_SIDE_STREAM=off keeps everything on one stream.
+_SIDE = {"on": os.environ.get("FMRI_SIDE_STREAM") != "off", "streams": {}, "pending": []}
+
+
+def _side_stream(device):
+    if not _SIDE["on"]:
+        return None
+    key = (device.type, device.index)
+    st = _SIDE["streams"].get(key)
+    if st is None:
+        st = _SIDE["streams"][key] = torch.cuda.Stream(device)
+    return st
+
+
+def side_run(device, fn, *keep):
+    """Run ``fn`` (kernel launches only) on the side stream, ordered after everything issued so far on the current
+    stream.  ``keep``: tensors ``fn`` reads -- referenced until ``join_side`` so that the caching allocator cannot hand
+    their memory to later current-stream work while the side stream still reads it."""
+    st = _side_stream(device)
+    if st is None:
+        fn()
+        return
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(device))
+    st.wait_event(ev)
+    with torch.cuda.stream(st):
+        fn()
+    _SIDE["pending"].append((st, keep))
+
+
+def join_side(device=None):
+    """Make the current stream wait for all side-stream work issued since the last join."""
+    if not _SIDE["pending"]:
+        return
+    seen = []
+    for st, _ in _SIDE["pending"]:
+        if st not in seen:
+            seen.append(st)
+    for st in seen:
+        ev = torch.cuda.Event()
+        ev.record(st)
+        torch.cuda.current_stream(st.device).wait_event(ev)
+    _SIDE["pending"].clear()
+
+
 def run_wgrad(P, Q, N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad, flip=0):
     """Returns the packed fp32 gradient [apad][ldo]."""
     ba = tile_for(A)
@@ -347,7 +399,10 @@ class ConvLayer:
         return out
 
     def wgrad(self, x: torch.Tensor, dy: torch.Tensor, scale: float):
-        """weight.grad += (1/scale) * dW(x, dy)."""
+        """weight.grad += (1/scale) * dW(x, dy)  (on the side stream: ops.join_side() before the gradient is read)."""
+        side_run(x.device, lambda: self._wgrad(x, dy, scale), x, dy)
+
+    def _wgrad(self, x: torch.Tensor, dy: torch.Tensor, scale: float):
         N, Hi, Wi, _ = x.shape
         _, Ho, Wo, _ = dy.shape
         if self.kind == "conv" and self.stride == 1 and self.cinp > self.coutp:
@@ -444,6 +499,9 @@ class DenseLayer:
                           want32)
 
     def wgrad(self, x: torch.Tensor, dy: torch.Tensor, scale: float):
+        side_run(x.device, lambda: self._wgrad(x, dy, scale), x, dy)
+
+    def _wgrad(self, x: torch.Tensor, dy: torch.Tensor, scale: float):
         M = x.shape[0]
         packed, ldo = run_wgrad(dy, x, M, 1, 1, self.np_, 1, 1, self.kp, 1, 1, 0)
         unpack_grad(packed, self.wg, self.gspec, ldo, 1.0 / scale)

@@ -23,7 +23,7 @@ from typing import Dict, Optional
 import numpy as np
 import torch
 
-from . import lib
+from . import lib, ops
 from .nets import CognitiveEncoderNet, DecoderNet, DiscriminatorNet, EncoderNet, WaeDiscriminatorNet
 from .ops import axpby, images_to_nhwc, nhwc_to_images, pad8, require_gpu, rows_to_f16
 from .params import ArchConfig
@@ -100,6 +100,7 @@ class _SegmentRecorder:
         self.cur.capture_begin(pool=self.pool, capture_error_mode="thread_local")
 
     def end(self):
+        ops.join_side()          # a capture cannot end with forked side-stream work (weight gradients) un-joined
         self.cur.capture_end()
         self.items.append(self.cur)
         self.cur = None
@@ -247,6 +248,18 @@ class _GanStepBase:
         Inputs are read from ``static_inputs`` at every replay -- copy each new batch into those tensors.  RMSprop
         steps only (Adam's bias correction is a host-side scalar per step).  In a data-parallel run the collectives
         are kept out of the graphs (see _SegmentRecorder)."""
+        # The weight-gradient side stream (ops.side_run) is switched off while recording: a replayed HIP graph runs
+        # its parallel branches no faster than a chain (measured 8.8 ms chained, 9.0-9.5 ms with the fork/join
+        # branches, 8.4 ms eager with two streams), so the recorded step keeps everything on one stream.
+        side_was = ops._SIDE["on"]
+        ops.join_side()
+        ops._SIDE["on"] = False
+        try:
+            return self._capture(static_inputs, warmup)
+        finally:
+            ops._SIDE["on"] = side_was
+
+    def _capture(self, static_inputs, warmup):
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -361,9 +374,12 @@ class Stage1Step(_GanStepBase):
         for n in (self.enc, self.dec, self.dis):
             n.group.zero_grad()
         dlogit16, dfeat16 = self._start_cotangents(fw["feat"], fw["logit32"], B)
-        dimg_a, dimg_b = self.dis.backward(fw["sctx"], dlogit16, sc.a, dfeat16, sc.b, True, slice(B, 3 * B))
-        # data parallel: every sub-network's gradient reduction starts as soon as its buffer is final and runs under
+        # weight gradients run on the side stream (ops.side_run).  One GPU: they are joined once, at the end of the
+        # backward pass, so that a sub-network's last weight gradients overlap the next one's backward.  Data parallel:
+        # joined per sub-network, because its gradient reduction starts as soon as its buffer is final and runs under
         # the backward of the next one (discriminator 43.8 MB -> decoder 18.8 MB -> encoder fc tail 67 MB -> rest)
+        dp = self.dd.on
+        dimg_a, dimg_b = self.dis.backward(fw["sctx"], dlogit16, sc.a, dfeat16, sc.b, True, slice(B, 3 * B), join=dp)
         self.dd.all_reduce_async(self.dis.group.grad)
         # decoder cotangent, stored = dec * nA * (lambda*B_true - (1-lambda)*A_true)
         cot = torch.empty(3 * B, H, W, 8, dtype=torch.float16, device=dev)
@@ -373,7 +389,7 @@ class Stage1Step(_GanStepBase):
         cot[2 * B:].copy_(dimg_b[:B])
         entries = [dict(g=0, scale=sc.dec, train=True), dict(g=1, scale=sc.dec, train=True),
                    dict(g=0, scale=sc.b, train=False, need_dz=True)]
-        dz = self.dec.backward(fw["dctx"], cot, entries)[2]          # = nB * dz_true
+        dz = self.dec.backward(fw["dctx"], cot, entries, join=dp)[2]  # = nB * dz_true
         self.dd.all_reduce_async(self.dec.group.grad)
         dhead32 = torch.empty(B, 2 * Z, dtype=torch.float32, device=dev)
         lib.call("fmri_latent_bwd", _P(fw["head32"]), _P(fw["eps"]), _P(dz), Z, 1.0, 1.0, _P(self._slot(S_NB)), B, Z,
@@ -384,7 +400,7 @@ class Stage1Step(_GanStepBase):
         eg = self.enc.group
         tail = eg.offsets["fc.0.weight"]
         self.enc.backward(fw["ectx"], dhead16, sc.enc,                  # grads = S_NE * true
-                          after_fc=lambda: self.dd.all_reduce_async(eg.grad[tail:]))
+                          after_fc=(lambda: self.dd.all_reduce_async(eg.grad[tail:])) if dp else None)
         self.dd.all_reduce(eg.grad[:tail])
         self.dd.wait_all()
 

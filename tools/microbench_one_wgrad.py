@@ -11,5 +11,5 @@ g = G({"w": torch.randn(cout, cin, 5, 5, device="cuda") * 0.05})
 L = ops.ConvLayer(g, "w", None, "conv", cin, cout, 5, 2, 2)
 x = torch.randn(N, H, H, ops.pad8(cin), device="cuda").half()
 y = L.forward(x); dy = torch.randn_like(y)
-for _ in range(3): L.wgrad(x, dy, 1.0)
+for _ in range(3): L._wgrad(x, dy, 1.0)
 torch.cuda.synchronize()

@@ -15,7 +15,7 @@ def run(tag, cin, cout, stride, N, H, kind="conv"):
     y = L.forward(x)
     fl = L._flops(N, H, H, y.shape[1], y.shape[2])
     dy = torch.randn_like(y)
-    f = lambda: L.wgrad(x, dy, 1.0)
+    f = lambda: L._wgrad(x, dy, 1.0)   # current stream (L.wgrad would go to the side stream)
     for _ in range(2): f()
     torch.cuda.synchronize(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()

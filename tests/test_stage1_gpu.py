@@ -146,3 +146,43 @@ def test_stage1_full_batch_first_step_matches_oracle():
         if k.endswith("running_mean") or k.endswith("running_var"):
             err = _tensor_err(eng["state"][k], v)
             assert err < 5e-3, (k, err)
+
+
+def test_fused_step_equals_separate_calls():
+    """``Stage1Step.step`` (weight gradients, discriminator / decoder optimizer updates and weight repacks queued on the
+    side stream under the rest of the backward pass) against the same step issued as forward / gate / backward / apply
+    on one stream: same losses and the same parameters after the step.  (One step only: the fp32 atomics of the
+    weight-gradient kernels make two runs of the SAME code differ by ~1e-6 after one step, and RMSprop's sign-like
+    first updates grow that to 1e-2 within three steps -- measured with tools/debug_fused.py.)"""
+    from oracle import vaegan_oracle as O
+    from fmri_hip import ops
+    from fmri_hip.params import ArchConfig
+    from fmri_hip.steps import Stage1Step
+    B = 8
+    data = O.synth_batch(B, O.ArchCfg.px64(), seed=1234, steps=1)
+    x = data["x"].to(DEV)
+    e, zp = data["noise"][0, 0].to(DEV), data["noise"][0, 1].to(DEV)
+    res = []
+    side_was = ops._SIDE["on"]
+    try:
+        for fused in (True, False):
+            st = Stage1Step(ArchConfig.px64(), DEV)
+            st.load_recipe(0, True)
+            ops._SIDE["on"] = fused
+            if fused:
+                st.step(x, e, zp)
+            else:
+                st.forward(x, e, zp)
+                st.gate(B)
+                st.backward()
+                st.apply()
+            ops.join_side()
+            torch.cuda.synchronize()
+            res.append((st.logs(), {k: v.float().cpu() for k, v in st.state_dict().items()}))
+    finally:
+        ops._SIDE["on"] = side_was
+    (la, sa), (lb, sb) = res
+    for k in ("loss_encoder", "loss_decoder", "loss_discriminator", "kl"):
+        assert _rel(la[k], lb[k]) < 1e-5, (k, la[k], lb[k])
+    for k in sa:
+        assert _tensor_err(sa[k], sb[k]) < 2e-5, (k, _tensor_err(sa[k], sb[k]))

@@ -139,6 +139,12 @@ def _repack_group(group):
         pw.version = group.version
 
 
+def repack_group(group):
+    """Refresh the fp16 GEMM copies of ``group`` now (they are otherwise refreshed lazily at their next use)."""
+    if group.packed and any(pw.version != group.version for pw in group.packed):
+        _repack_group(group)
+
+
 def _single(master, group, sp: PackSpec, tile: int) -> PackedWeight:
     rows_pad = ceil_to(sp.rows, tile)
     return PackedWeight(master, group, [sp], rows_pad, [ceil_to(sp.kcols, 64)], [0])

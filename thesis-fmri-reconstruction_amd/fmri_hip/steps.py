@@ -365,8 +365,12 @@ class Stage1Step(_GanStepBase):
     def gate(self, B_global: int):
         self._gate(B_global, self.fw["F"], True)
 
-    def backward(self, extra_dmu: Optional[torch.Tensor] = None):
-        """``extra_dmu`` [B, z] fp32: an additional true-scale cotangent on the encoder means (Dual step)."""
+    def backward(self, extra_dmu: Optional[torch.Tensor] = None, early_apply: bool = False):
+        """``extra_dmu`` [B, z] fp32: an additional true-scale cotangent on the encoder means (Dual step).
+        ``early_apply`` (one GPU, used by ``step``): the discriminator's and the decoder's optimizer update + weight
+        repack are queued on the side stream right behind their last weight gradient, i.e. they run under the backward
+        pass of the next sub-network instead of after the whole backward (nothing later in the step reads those weights);
+        ``apply`` then only updates the encoder."""
         fw, sc, hp, cfg = self.fw, self.sc, self.hp, self.cfg
         B, H, W = fw["B"], fw["H"], fw["W"]
         Z = cfg.latent_dim
@@ -379,8 +383,12 @@ class Stage1Step(_GanStepBase):
         # joined per sub-network, because its gradient reduction starts as soon as its buffer is final and runs under
         # the backward of the next one (discriminator 43.8 MB -> decoder 18.8 MB -> encoder fc tail 67 MB -> rest)
         dp = self.dd.on
+        early = early_apply and not dp and ops._SIDE["on"]
+        self._applied_early = early
         dimg_a, dimg_b = self.dis.backward(fw["sctx"], dlogit16, sc.a, dfeat16, sc.b, True, slice(B, 3 * B), join=dp)
         self.dd.all_reduce_async(self.dis.group.grad)
+        if early:
+            ops.side_run(dev, lambda: self._apply_one(self.opt_dis, self.flags[0:1], S_NA))
         # decoder cotangent, stored = dec * nA * (lambda*B_true - (1-lambda)*A_true)
         cot = torch.empty(3 * B, H, W, 8, dtype=torch.float16, device=dev)
         lam = hp.lambda_mse
@@ -391,6 +399,8 @@ class Stage1Step(_GanStepBase):
                    dict(g=0, scale=sc.b, train=False, need_dz=True)]
         dz = self.dec.backward(fw["dctx"], cot, entries, join=dp)[2]  # = nB * dz_true
         self.dd.all_reduce_async(self.dec.group.grad)
+        if early:
+            ops.side_run(dev, lambda: self._apply_one(self.opt_dec, self.flags[1:2], S_NA))
         dhead32 = torch.empty(B, 2 * Z, dtype=torch.float32, device=dev)
         lib.call("fmri_latent_bwd", _P(fw["head32"]), _P(fw["eps"]), _P(dz), Z, 1.0, 1.0, _P(self._slot(S_NB)), B, Z,
                  1.0, None, _P(dhead32), 1)                              # = nB * dhead_true
@@ -404,8 +414,16 @@ class Stage1Step(_GanStepBase):
         self.dd.all_reduce(eg.grad[:tail])
         self.dd.wait_all()
 
+    def _apply_one(self, opt, flag, slot):
+        """Optimizer update of one sub-network + refresh of its fp16 GEMM weights (on the current stream)."""
+        opt.step(flag, gdev=self._slot(slot))
+        ops.repack_group(opt.g)
+
     def apply(self):
         self.opt_enc.step(None, gdev=self._slot(S_NE))
+        if getattr(self, "_applied_early", False):
+            self._applied_early = False
+            return
         self.opt_dec.step(self.flags[1:2], gdev=self._slot(S_NA))
         self.opt_dis.step(self.flags[0:1], gdev=self._slot(S_NA))
 
@@ -413,7 +431,7 @@ class Stage1Step(_GanStepBase):
         """One full training step; returns the device scalar block (see LOG_KEYS) without syncing."""
         fw = self.forward(x, eps, z_p)
         self.gate(fw["B"] * self.dd.world)
-        self.backward()
+        self.backward(early_apply=True)
         self.apply()
         return self.scal
 

@@ -98,6 +98,9 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="images per GPU (weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--local-bn", action="store_true", help="per-rank BN statistics (no SyncBN exchange)")
+    ap.add_argument("--serial", action="store_true",
+                    help="keep every launch on one stream (no weight-gradient side stream): the mode the per-kernel "
+                         "roofline pass always uses, and the one to profile with rocprofv3 for per-kernel durations")
     ap.add_argument("--eager", action="store_true", help="issue every launch from Python (no graph capture)")
     ap.add_argument("--graph", action="store_true", help="always replay the captured graph(s) (default: whichever of "
                     "eager / graph replay probes faster on this host)")
@@ -121,6 +124,8 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
+    if a.serial:
+        os.environ["FMRI_SIDE_STREAM"] = "off"
     from fmri_hip import lib, ops
     from fmri_hip.params import ArchConfig
     from fmri_hip.steps import Stage1Step
@@ -190,12 +195,17 @@ def main():
     log(f"timed region done: {1e3 * dt / a.steps:.2f} ms/step ({'graph replay' if use_graph else 'eager'})")
     # dominant-kernel timing: HIP events around every launch of that kernel over a few eagerly issued steps (events
     # cannot be placed inside a replayed graph)
+    # The side stream is switched off for this pass: next to concurrently running weight-gradient kernels a launch's
+    # duration says nothing about the kernel (igemm_win: 276 us alone, 345 us while sharing the CUs).
+    ops.join_side()
+    side_was, ops._SIDE["on"] = ops._SIDE["on"], False
     ops.PROFILE = [] if rank == 0 else None
     prof_steps = min(a.steps, 5)
     for _ in range(prof_steps):
         st.step(x, nz[0], nz[1])
     barrier()
     prof, ops.PROFILE = ops.PROFILE, None
+    ops._SIDE["on"] = side_was
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -227,11 +237,13 @@ def main():
                          "traffic_unit": "bytes per launch leaving L2 (PMC passes of this workload recorded in "
                                          "profiles/r01_pmc_traffic.json; hardware counters cannot be read in-process)",
                          "kernel": label,
+                         "measured": "HIP events around each launch of the kernel, 5 steps issued on ONE stream (the "
+                                     "timed region overlaps weight gradients on a second stream when launched eagerly)",
                          "launches_per_step": nl // max(prof_steps, 1),
                          "avg_launch_ms": round(ms / nl, 4),
                          "avg_launch_gflop": round(fl / nl / 1e9, 2)},
             "launch": ("hip-graph replay" if world == 1 and not force_dist else "hip-graph segments + eager collectives")
-            if use_graph else "eager",
+            if use_graph else ("eager, one stream" if not ops._SIDE["on"] else "eager, weight gradients on a side stream"),
             "step_mfma_frac": round(value / world * FLOP_PER_IMAGE / 1e12 / MFMA_PEAK_TFLOPS, 4),
             "losses_last_step": {k: logs[k] for k in ("loss_encoder", "loss_decoder", "loss_discriminator", "kl")},
         }

@@ -97,7 +97,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU (weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--local-bn", action="store_true", help="per-rank BN statistics (no SyncBN exchange)")
+    ap.add_argument("--sync-bn", action="store_true",
+                    help="data-parallel runs: all-reduce the BatchNorm partial sums (statistics of the GLOBAL batch, 32 "
+                         "small collectives per step).  Default: per-rank statistics over the rank's own 256 images, "
+                         "i.e. what the single-GPU reference computes per batch and what torch DDP does by default")
+    ap.add_argument("--local-bn", action="store_true", help="(default; kept for compatibility)")
     ap.add_argument("--serial", action="store_true",
                     help="keep every launch on one stream (no weight-gradient side stream): the mode the per-kernel "
                          "roofline pass always uses, and the one to profile with rocprofv3 for per-kernel durations")
@@ -133,7 +137,7 @@ def main():
 
     cfg = ArchConfig.px64()
     B = a.batch
-    st = Stage1Step(cfg, dev, distributed=world > 1 or force_dist, sync_bn=not a.local_bn)
+    st = Stage1Step(cfg, dev, distributed=world > 1 or force_dist, sync_bn=a.sync_bn)
     st.load_recipe(0, False)
     x = torch.from_numpy(np.random.RandomState(1234 + rank).uniform(-1, 1, (B, 3, 64, 64)).astype(np.float32)).to(dev)
     nz = torch.from_numpy(np.random.RandomState(1236 + rank).standard_normal((2, B, cfg.latent_dim))
@@ -231,7 +235,7 @@ def main():
             "config": {"workload": "Stage-I VAE/GAN training step, 64x64x3 random images, latent 128, "
                                    "RMSprop x3, random-init weights (BASELINE configs[1])",
                        "batch_per_gpu": B, "global_batch": B * world,
-                       "parallelism": f"dp{world}" + ("" if world == 1 else ("-localbn" if a.local_bn else "-syncbn"))},
+                       "parallelism": f"dp{world}" + ("" if world == 1 else ("-syncbn" if a.sync_bn else "-localbn"))},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(label),
                          "traffic_unit": "bytes per launch leaving L2 (PMC passes of this workload recorded in "

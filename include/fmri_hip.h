@@ -125,6 +125,12 @@ int fmri_bn_finalize(const float* sums2C, int C, float count, const float* gamma
                      float momentum, int updates, float* running_mean, float* running_var, float* mean, float* rstd,
                      float* scale, float* shift, int64_t* num_batches_tracked /* += updates, may be NULL */,
                      void* stream);
+/* fmri_bn_stats + fmri_bn_finalize in two launches instead of three (the fold of the partial sums finalizes): the
+ * forward of nn.BatchNorm2d/1d in train mode when no statistics are exchanged between ranks (models/vae_gan.py:21). */
+int fmri_bn_stats_finalize(const void* x, int M, int C, float* sums2C, float* ws, int64_t ws_floats, float count,
+                           const float* gamma, const float* beta, float eps, float momentum, int updates,
+                           float* running_mean, float* running_var, float* mean, float* rstd, float* scale,
+                           float* shift, int64_t* num_batches_tracked, void* stream);
 int fmri_bn_apply(const void* x, void* y, int M, int C, const float* scale, const float* shift, int relu,
                   void* stream);
 int fmri_bn_bwd_reduce(const void* x, const void* dy, int M, int C, const float* mean, const float* rstd,

@@ -182,7 +182,10 @@ def test_two_rank_stage1_step_equals_single_process_global_batch():
             tol = 0.15 if k == "decoder.conv.3.0.bias" else 0.05
             assert abs(gn[k] - v) < tol * v + 1e-6, (rank, k, gn[k], v)
         for k, v in sd1.items():
-            assert abs(sdn[k] - v) < 2e-3 * v + 1e-6, (rank, k, sdn[k], v)
+            # same 3-element bias: RMSprop's first update is +-3.16e-4 per element whatever the gradient's size, so
+            # one sign flip of a near-zero gradient element moves the norm by that much
+            slack = 7e-4 if k == "decoder.conv.3.0.bias" else 1e-6
+            assert abs(sdn[k] - v) < 2e-3 * v + slack, (rank, k, sdn[k], v)
     # both ranks hold identical parameters after the step
     for k in res[0][3]:
         assert abs(res[0][3][k] - res[1][3][k]) <= 1e-6 * abs(res[0][3][k]) + 1e-9, k

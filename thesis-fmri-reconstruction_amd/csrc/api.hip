@@ -495,6 +495,16 @@ int fmri_bn_finalize(const float* sums2C, int C, float count, const float* gamma
     return bn_finalize_launch(sums2C, C, count, gamma, beta, eps, momentum, updates, running_mean, running_var, mean,
                               rstd, scale, shift, (long long*)num_batches_tracked, S(stream));
 }
+int fmri_bn_stats_finalize(const void* x, int M, int C, float* sums2C, float* ws, int64_t ws_floats, float count,
+                           const float* gamma, const float* beta, float eps, float momentum, int updates,
+                           float* running_mean, float* running_var, float* mean, float* rstd, float* scale,
+                           float* shift, int64_t* num_batches_tracked, void* stream) {
+    if (!x || !sums2C || (C & 7) || M < 1 || !gamma || !beta || !mean || !rstd || !scale || !shift)
+        return FMRI_E_BADARG;
+    return bn_stats_finalize_launch((const half_t*)x, M, C, sums2C, ws, ws_floats, count, gamma, beta, eps, momentum,
+                                    updates, running_mean, running_var, mean, rstd, scale, shift,
+                                    (long long*)num_batches_tracked, S(stream));
+}
 int fmri_bn_apply(const void* x, void* y, int M, int C, const float* scale, const float* shift, int relu,
                   void* stream) {
     if (!x || !y || (C & 7)) return FMRI_E_BADARG;

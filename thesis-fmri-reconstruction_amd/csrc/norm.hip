@@ -166,18 +166,13 @@ __global__ __launch_bounds__(1024) void fold_partials_kernel(const float* __rest
     }
 }
 
-// one thread per channel
-__global__ void bn_finalize_kernel(const float* __restrict__ sums, int C, float count, const float* __restrict__ gamma,
-                                   const float* __restrict__ beta, float eps, float momentum, int updates,
-                                   float* __restrict__ running_mean, float* __restrict__ running_var,
-                                   float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                   float* __restrict__ scale_out, float* __restrict__ shift_out,
-                                   long long* __restrict__ nbt) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0 && nbt && updates > 0) *nbt += updates;      // num_batches_tracked
-    if (c >= C) return;
-    const float mean = sums[c] / count;
-    float var = sums[C + c] / count - mean * mean;
+// shared by bn_finalize_kernel and fold_finalize_kernel: channel c from its batch sums
+__device__ __forceinline__ void bn_finalize_channel(int c, float sx, float sxx, float count, const float* gamma,
+                                                    const float* beta, float eps, float momentum, int updates,
+                                                    float* running_mean, float* running_var, float* mean_out,
+                                                    float* rstd_out, float* scale_out, float* shift_out) {
+    const float mean = sx / count;
+    float var = sxx / count - mean * mean;
     var = var > 0.f ? var : 0.f;
     const float rstd = rsqrtf(var + eps);
     mean_out[c] = mean;
@@ -195,6 +190,64 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, int C, float 
         running_mean[c] = rm;
         running_var[c] = rv;
     }
+}
+
+// fold of the statistics partials [nparts][2][C] + finalize in one launch (forward BatchNorm without a statistics
+// exchange between ranks): block = 32 channels x 32 row lanes, both sums of a channel are folded by the same lanes.
+__global__ __launch_bounds__(1024) void fold_finalize_kernel(const float* __restrict__ part, int nparts, int C,
+                                                             float* __restrict__ sums, float count,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float eps, float momentum,
+                                                             int updates, float* __restrict__ running_mean,
+                                                             float* __restrict__ running_var,
+                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                             float* __restrict__ scale_out,
+                                                             float* __restrict__ shift_out, long long* __restrict__ nbt) {
+    __shared__ float red[2][32][33];
+    const int cx = threadIdx.x & 31, gy = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx;
+    const int n = 2 * C;
+    float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+    if (c < C) {
+        int p = gy;
+        for (; p + 32 < nparts; p += 64) {
+            a0 += part[(int64_t)p * n + c];
+            b0 += part[(int64_t)p * n + C + c];
+            a1 += part[(int64_t)(p + 32) * n + c];
+            b1 += part[(int64_t)(p + 32) * n + C + c];
+        }
+        for (; p < nparts; p += 32) {
+            a0 += part[(int64_t)p * n + c];
+            b0 += part[(int64_t)p * n + C + c];
+        }
+    }
+    red[0][gy][cx] = a0 + a1;
+    red[1][gy][cx] = b0 + b1;
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0 && nbt && updates > 0) *nbt += updates;      // num_batches_tracked
+    if (gy == 0 && c < C) {
+        float sx = 0.f, sxx = 0.f;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) { sx += red[0][r][cx]; sxx += red[1][r][cx]; }
+        sums[c] = sx;
+        sums[C + c] = sxx;
+        bn_finalize_channel(c, sx, sxx, count, gamma, beta, eps, momentum, updates, running_mean, running_var, mean_out,
+                            rstd_out, scale_out, shift_out);
+    }
+}
+
+// one thread per channel
+__global__ void bn_finalize_kernel(const float* __restrict__ sums, int C, float count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float eps, float momentum, int updates,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                   float* __restrict__ scale_out, float* __restrict__ shift_out,
+                                   long long* __restrict__ nbt) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && nbt && updates > 0) *nbt += updates;      // num_batches_tracked
+    if (c >= C) return;
+    bn_finalize_channel(c, sums[c], sums[C + c], count, gamma, beta, eps, momentum, updates, running_mean, running_var,
+                        mean_out, rstd_out, scale_out, shift_out);
 }
 
 // MODE 0: y = act(x*scale + shift).   MODE 1: dx = gamma*rstd*(g - sum_g/M - xhat*sum_gx/M), g = dy*mask
@@ -290,6 +343,19 @@ static int reduce_launch(const half_t* x, const half_t* dy, half_t* dout, int M,
     return LAUNCH_OK();
 }
 
+int bn_stats_finalize_launch(const half_t* x, int M, int C, float* sums, float* ws, int64_t ws_floats, float count,
+                             const float* gamma, const float* beta, float eps, float momentum, int updates, float* rm,
+                             float* rv, float* mean, float* rstd, float* scale, float* shift, long long* nbt,
+                             hipStream_t st) {
+    if (!ws || ws_floats < 2 * (int64_t)C) return E_WORKSPACE;
+    const RowGeom g = row_geometry(M, C, (int)(ws_floats / (2 * (int64_t)C)));
+    hipLaunchKernelGGL((bn_reduce_kernel<0>), dim3(g.gx, g.gy), dim3(256), 0, st, x, (const half_t*)nullptr,
+                       (half_t*)nullptr, M, C, g.cx_log2, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, 0, ws);
+    hipLaunchKernelGGL(fold_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, st, ws, g.gy, C, sums, count, gamma,
+                       beta, eps, momentum, updates, rm, rv, mean, rstd, scale, shift, nbt);
+    return LAUNCH_OK();
+}
 int bn_stats_launch(const half_t* x, int M, int C, float* sums, float* ws, int64_t ws_floats, hipStream_t st) {
     return reduce_launch<0>(x, nullptr, nullptr, M, C, nullptr, nullptr, nullptr, nullptr, 0, sums, ws, ws_floats,
                             st);

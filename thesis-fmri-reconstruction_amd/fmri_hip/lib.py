@@ -38,6 +38,7 @@ _SIGS = {
     "fmri_permute_chw": [_p, _p, _i, _i, _i, _f, _i, _p],
     "fmri_bn_stats": [_p, _i, _i, _p, _p, _l, _p],
     "fmri_bn_finalize": [_p, _i, _f, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p, _p, _p, _p],
+    "fmri_bn_stats_finalize": [_p, _i, _i, _p, _p, _l, _f, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p, _p, _p, _p],
     "fmri_bn_apply": [_p, _p, _i, _i, _p, _p, _i, _p],
     "fmri_bn_bwd_reduce": [_p, _p, _i, _i, _p, _p, _p, _p, _i, _p, _p, _l, _p, _p, _f, _p],
     "fmri_bn_bwd_apply": [_p, _p, _p, _i, _i, _f, _p, _p, _p, _p, _i, _p, _p],

@@ -581,18 +581,23 @@ class BatchNorm:
         gamma, beta, rm, rv = self._params()
         sums = torch.empty(2, C, dtype=torch.float32, device=dev)
         ws = _reduce_ws(M, C, dev)
-        lib.call("fmri_bn_stats", _P(x2), M, C, _P(sums), _P(ws), ws.numel())
         count = float(M)
-        if self.reducer is not None:
-            count *= self.reducer(sums)
         sv = BNSaved()
         buf = torch.empty(4, C, dtype=torch.float32, device=dev)
-        sv.mean, sv.rstd, sv.scale, sv.shift, sv.count = buf[0], buf[1], buf[2], buf[3], count
+        sv.mean, sv.rstd, sv.scale, sv.shift = buf[0], buf[1], buf[2], buf[3]
         if updates > 0:
             self._running_in()
-        lib.call("fmri_bn_finalize", _P(sums), C, count, _P(gamma), _P(beta), 1e-5, 0.9, updates,
-                 _P(rm) if updates > 0 else None, _P(rv) if updates > 0 else None, _P(sv.mean), _P(sv.rstd),
-                 _P(sv.scale), _P(sv.shift), _P(self.nbt) if updates > 0 else None)
+        fin = (_P(gamma), _P(beta), 1e-5, 0.9, updates, _P(rm) if updates > 0 else None,
+               _P(rv) if updates > 0 else None, _P(sv.mean), _P(sv.rstd), _P(sv.scale), _P(sv.shift),
+               _P(self.nbt) if updates > 0 else None)
+        if self.reducer is None:
+            # no statistics exchange: the fold of the partial sums finalizes (one launch less on the critical path)
+            lib.call("fmri_bn_stats_finalize", _P(x2), M, C, _P(sums), _P(ws), ws.numel(), count, *fin)
+        else:
+            lib.call("fmri_bn_stats", _P(x2), M, C, _P(sums), _P(ws), ws.numel())
+            count *= self.reducer(sums)
+            lib.call("fmri_bn_finalize", _P(sums), C, count, *fin)
+        sv.count = count
         if updates > 0:
             self._running_out()
         if out is None:

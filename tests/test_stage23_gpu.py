@@ -115,3 +115,57 @@ def test_stage3_px128_bold5000_shape_matches_oracle():
         assert _rel(logs[k], ref["logs"][k]) < 1e-3, (k, logs[k], ref["logs"][k])
     for k in ("x_tilde", "disc_class", "disc_layer", "mus"):
         assert _terr(outs[k], ref["fw"][k]) < 1e-2, k
+
+
+def test_checkpoint_bridge_stage1_to_stage2_to_stage3(tmp_path):
+    """The on-disk format either side of the path: a Stage-I step's ``state_dict`` saved with
+    ``torch.save`` is a reference-format ``VaeGan`` checkpoint (keys / shapes / fp32, (C,H,W)-ordered fc weights); the
+    Stage-II step takes it as its teacher (train_vgan_stage2.py:212-217), trains, saves; the Stage-III step loads that
+    file (train_vgan_stage3.py:241).  Every hop is bit-exact on the tensors it carries over."""
+    from oracle import vaegan_oracle as O
+    from fmri_hip.params import ArchConfig
+    from fmri_hip.steps import CognitiveStep, Stage1Step
+    cfg, cfg_o = ArchConfig.px64(), O.ArchCfg.px64()
+    B, V = 4, 256
+    data = O.synth_batch(B, cfg_o, n_voxels=V, seed=1234, steps=1)
+    x, fmri = data["x"].to(DEV), data["fmri"].to(DEV)
+    nz = [data["noise"][0, i].to(DEV) for i in range(3)]
+    s1 = Stage1Step(cfg, DEV)
+    s1.load_recipe(0, True)
+    s1.step(x, nz[0], nz[1])
+    f1 = str(tmp_path / "vgan_stage1.pth")
+    torch.save({k: v.cpu() for k, v in s1.state_dict().items()}, f1)
+    ck1 = torch.load(f1, map_location="cpu")
+    spec = {k: tuple(s) for k, s, _ in O.vaegan_spec(cfg_o)}
+    assert list(ck1.keys()) == list(spec.keys())                       # reference key order
+    for k, v in ck1.items():
+        assert tuple(v.shape) == spec[k] and (v.dtype == torch.float32 or "num_batches" in k), k
+    # fresh Stage-I engine from the file: identical state
+    s1b = Stage1Step(cfg, DEV)
+    s1b.load_state_dict(ck1)
+    for k, v in s1b.state_dict().items():
+        assert torch.equal(v.cpu(), ck1[k]), k
+    # Stage II: the file is the teacher
+    s2 = CognitiveStep(cfg, V, DEV, stage=2)
+    s2.load_recipe(5, True)
+    s2.load_teacher(ck1)
+    sd2 = {k: v.cpu() for k, v in s2.state_dict().items()}
+    for k, v in ck1.items():
+        pre, rest = k.split(".", 1)
+        assert torch.equal(sd2["teacher_net." + k], v), k
+        if pre in ("decoder", "discriminator"):
+            assert torch.equal(sd2[k], v), k
+    s2.step(fmri, x, nz[0], nz[1], nz[2])
+    logs = s2.logs()
+    assert all(np.isfinite(logs[k]) for k in ("loss_encoder", "loss_discriminator"))
+    f2 = str(tmp_path / "vgan_stage2.pth")
+    torch.save({k: v.cpu() for k, v in s2.state_dict().items()}, f2)
+    ck2 = torch.load(f2, map_location="cpu")
+    # Stage III loads the Stage-II file
+    s3 = CognitiveStep(cfg, V, DEV, stage=3)
+    s3.load_state_dict(ck2)
+    sd3 = {k: v.cpu() for k, v in s3.state_dict().items()}
+    for k, v in sd3.items():
+        assert torch.equal(v, ck2[k]), k
+    s3.step(fmri, x, nz[0], nz[1])
+    assert np.isfinite(s3.logs()["loss_decoder"])

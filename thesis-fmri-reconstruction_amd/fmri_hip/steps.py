@@ -499,6 +499,25 @@ class CognitiveStep(_GanStepBase):
             sd.update(self.dis.group.state_dict("teacher_net.discriminator."))
         return sd
 
+    def load_state_dict(self, sd):
+        """A Stage-II / Stage-III checkpoint as the scripts write it (``model.state_dict()`` of ``VaeGanCognitive``):
+        ``encoder.`` = cognitive encoder, ``decoder.``, ``discriminator.`` and, for stage 2, ``teacher_net.encoder.``
+        (train/train_vgan_stage3.py:241 loads the Stage-II file this way; its ``teacher_net.decoder./discriminator.``
+        entries alias ``decoder.`` / ``discriminator.`` in Stage II and are not needed in Stage III)."""
+        self.cog.group.load_state_dict(sd, "encoder.")
+        self.dec.group.load_state_dict(sd, "decoder.")
+        self.dis.group.load_state_dict(sd, "discriminator.")
+        if self.teacher_enc is not None:
+            self.teacher_enc.group.load_state_dict(sd, "teacher_net.encoder.")
+
+    def load_teacher(self, sd):
+        """A Stage-I ``VaeGan`` checkpoint as the teacher (train/train_vgan_stage2.py:212-217,230): its decoder and
+        discriminator become the model's own (frozen decoder, trained discriminator), its encoder the teacher encoder."""
+        if self.teacher_enc is not None:
+            self.teacher_enc.group.load_state_dict(sd, "encoder.")
+        self.dec.group.load_state_dict(sd, "decoder.")
+        self.dis.group.load_state_dict(sd, "discriminator.")
+
     def forward(self, fmri: torch.Tensor, image: torch.Tensor, eps: torch.Tensor, z_p: torch.Tensor,
                 eps_teacher: Optional[torch.Tensor] = None):
         require_gpu(fmri)

@@ -161,42 +161,52 @@ def main():
     # ~370 Python/ctypes calls, so the number does not depend on the host CPU of the box.  In multi-process runs the
     # RCCL collectives stay eager calls between the graph segments.  --eager issues every launch from Python.
     eager_run = lambda: st.step(x, nz[0], nz[1])
-    use_graph = False
-    run = eager_run
-    graph_run = None
+    modes = {"eager": eager_run}
+    single = world == 1 and not force_dist
     if not a.eager:
         try:
-            graph_run = st.capture(x, nz[0], nz[1])
-            graph_run()
+            modes["graph"] = st.capture(x, nz[0], nz[1])
+            modes["graph"]()
             log("step captured into HIP graph(s)")
         except Exception as e:               # capture is an optimisation: fall back to eager launches
             log(f"graph capture failed ({type(e).__name__}: {e}); continuing with eager launches")
-            graph_run = None
-    if graph_run is not None:
+            modes.pop("graph", None)
+        if single and ops._SIDE["on"] and not a.graph:
+            # hybrid: recorded forward + eagerly issued two-stream backward (half the Python work of a step)
+            try:
+                modes["hybrid"] = st.capture_forward(x, nz[0], nz[1])
+                modes["hybrid"]()
+            except Exception as e:
+                log(f"forward capture failed ({type(e).__name__}: {e})")
+                modes.pop("hybrid", None)
 
-        def probe(fn, n=6):
-            barrier()
-            t = time.perf_counter()
-            for _ in range(n):
-                fn()
-            barrier()
-            tt = torch.tensor([time.perf_counter() - t], dtype=torch.float64, device=dev)
-            if world > 1:
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)      # every rank takes the same decision
-            return float(tt.item()) / n
+    def probe(fn, n=6):
+        barrier()
+        t = time.perf_counter()
+        for _ in range(n):
+            fn()
+        barrier()
+        tt = torch.tensor([time.perf_counter() - t], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)      # every rank takes the same decision
+        return float(tt.item()) / n
 
-        t_eager, t_graph = probe(eager_run), probe(graph_run)
-        use_graph = a.graph or t_graph <= t_eager
-        run = graph_run if use_graph else eager_run
-        log(f"probe: eager {1e3 * t_eager:.2f} ms/step, graph {1e3 * t_graph:.2f} ms/step -> "
-            f"{'graph' if use_graph else 'eager'}")
+    mode = "eager"
+    if a.graph and "graph" in modes:
+        mode = "graph"
+    elif len(modes) > 1:
+        times = {k: probe(fn) for k, fn in modes.items()}
+        mode = min(times, key=times.get)
+        log("probe: " + ", ".join(f"{k} {1e3 * v:.2f} ms/step" for k, v in times.items()) + f" -> {mode}")
+    run = modes[mode]
+    use_graph = mode == "graph"
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         run()
     barrier()
     dt = time.perf_counter() - t0
-    log(f"timed region done: {1e3 * dt / a.steps:.2f} ms/step ({'graph replay' if use_graph else 'eager'})")
+    log(f"timed region done: {1e3 * dt / a.steps:.2f} ms/step ({mode})")
     # dominant-kernel timing: HIP events around every launch of that kernel over a few eagerly issued steps (events
     # cannot be placed inside a replayed graph)
     # The side stream is switched off for this pass: next to concurrently running weight-gradient kernels a launch's
@@ -246,8 +256,11 @@ def main():
                          "launches_per_step": nl // max(prof_steps, 1),
                          "avg_launch_ms": round(ms / nl, 4),
                          "avg_launch_gflop": round(fl / nl / 1e9, 2)},
-            "launch": ("hip-graph replay" if world == 1 and not force_dist else "hip-graph segments + eager collectives")
-            if use_graph else ("eager, one stream" if not ops._SIDE["on"] else "eager, weight gradients on a side stream"),
+            "launch": {"graph": "hip-graph replay" if single else "hip-graph segments + eager collectives",
+                       "hybrid": "forward + gate replayed from a HIP graph, backward eager with weight gradients on a "
+                                 "side stream",
+                       "eager": "eager, one stream" if not ops._SIDE["on"]
+                       else "eager, weight gradients on a side stream"}[mode],
             "step_mfma_frac": round(value / world * FLOP_PER_IMAGE / 1e12 / MFMA_PEAK_TFLOPS, 4),
             "losses_last_step": {k: logs[k] for k in ("loss_encoder", "loss_decoder", "loss_discriminator", "kl")},
         }

@@ -186,3 +186,37 @@ def test_fused_step_equals_separate_calls():
         assert _rel(la[k], lb[k]) < 1e-5, (k, la[k], lb[k])
     for k in sa:
         assert _tensor_err(sa[k], sb[k]) < 2e-5, (k, _tensor_err(sa[k], sb[k]))
+
+
+def test_hybrid_recorded_forward_step_equals_eager_step():
+    """``Stage1Step.capture_forward``: forward + gate replayed from a HIP graph, backward / updates issued eagerly on two
+    streams -- against the plain ``step`` of a second engine started from the same parameters and RMSprop state: same
+    losses, same parameters after the step (to the run-to-run spread of the fp32 atomics), twice in a row (the second
+    replay must see the weights the first one's early updates produced)."""
+    from oracle import vaegan_oracle as O
+    from fmri_hip import ops
+    from fmri_hip.params import ArchConfig
+    from fmri_hip.steps import Stage1Step
+    B = 8
+    data = O.synth_batch(B, O.ArchCfg.px64(), seed=1234, steps=1)
+    x = data["x"].to(DEV)
+    e, zp = data["noise"][0, 0].to(DEV), data["noise"][0, 1].to(DEV)
+    a = Stage1Step(ArchConfig.px64(), DEV)
+    a.load_recipe(0, True)
+    run = a.capture_forward(x, e, zp, warmup=1)
+    b = Stage1Step(ArchConfig.px64(), DEV)
+    b.load_state_dict(a.state_dict())
+    for oa, ob in ((a.opt_enc, b.opt_enc), (a.opt_dec, b.opt_dec), (a.opt_dis, b.opt_dis)):
+        ob.s1.copy_(oa.s1)
+    for it in range(2):
+        run()
+        b.step(x, e, zp)
+        ops.join_side()
+        torch.cuda.synchronize()
+        la, lb = a.logs(), b.logs()
+        for k in ("loss_encoder", "loss_decoder", "loss_discriminator", "kl"):
+            assert _rel(la[k], lb[k]) < (1e-5 if it == 0 else 2e-3), (it, k, la[k], lb[k])
+        sa, sb = a.state_dict(), b.state_dict()
+        for k in sa:
+            err = _tensor_err(sa[k], sb[k])
+            assert err < (2e-5 if it == 0 else 2e-2), (it, k, err)

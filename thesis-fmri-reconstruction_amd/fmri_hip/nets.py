@@ -15,7 +15,8 @@ from typing import List, Optional
 import torch
 
 from . import lib
-from .ops import (ACT_NONE, ACT_RELU, ACT_TANH, BatchNorm, ConvLayer, DenseLayer, act_backward, join_side, pad8)
+from .ops import (ACT_NONE, ACT_RELU, ACT_TANH, BatchNorm, ConvLayer, DenseLayer, act_backward, join_side, pad8,
+                  repack_group)
 from .params import (ArchConfig, FlatGroup, cognitive_encoder_spec, decoder_spec, discriminator_spec, encoder_spec,
                      wae_discriminator_spec)
 
@@ -32,8 +33,15 @@ class FusedHeads:
         self.wcat = torch.empty(2 * z, k_in, dtype=torch.float32, device=dev)
         self.bcat = torch.empty(2 * z, dtype=torch.float32, device=dev)
         self.gw = torch.zeros(2 * z, k_in, dtype=torch.float32, device=dev)
-        self.dense = DenseLayer(_Versioned(group), (self.wcat, self.gw), (self.bcat, None), k_in, 2 * z)
+        self._vg = _Versioned(group)
+        self.dense = DenseLayer(self._vg, (self.wcat, self.gw), (self.bcat, None), k_in, 2 * z)
         self._v = -1
+
+    def refresh(self):
+        """Bring the concatenated scratch weights and their fp16 GEMM copies up to date now (instead of lazily at the
+        next forward)."""
+        self._sync()
+        repack_group(self._vg)
 
     def _sync(self):
         if self._v != self.group.version:
@@ -65,6 +73,18 @@ class FusedHeads:
             dh, _ = self.dense.dgrad(dhead16)
             return dh
         return None
+
+
+def refresh_net(net):
+    """Everything a sub-network derives from its master parameters -- fp16 GEMM weights, (C,H,W)-permuted BatchNorm
+    vectors, the fused heads' concatenated weights -- refreshed NOW on the current stream.  They are otherwise
+    refreshed lazily inside the next forward; a recorded forward (HIP graph) must not contain those launches."""
+    repack_group(net.group)
+    for bn in net.all_bns():
+        bn._params()
+    heads = getattr(net, "heads", None)
+    if heads is not None:
+        heads.refresh()
 
 
 class _Versioned:

@@ -24,7 +24,8 @@ import numpy as np
 import torch
 
 from . import lib, ops
-from .nets import CognitiveEncoderNet, DecoderNet, DiscriminatorNet, EncoderNet, WaeDiscriminatorNet
+from .nets import (CognitiveEncoderNet, DecoderNet, DiscriminatorNet, EncoderNet, WaeDiscriminatorNet,
+                   refresh_net)
 from .ops import axpby, images_to_nhwc, nhwc_to_images, pad8, require_gpu, rows_to_f16
 from .params import ArchConfig
 
@@ -388,7 +389,7 @@ class Stage1Step(_GanStepBase):
         dimg_a, dimg_b = self.dis.backward(fw["sctx"], dlogit16, sc.a, dfeat16, sc.b, True, slice(B, 3 * B), join=dp)
         self.dd.all_reduce_async(self.dis.group.grad)
         if early:
-            ops.side_run(dev, lambda: self._apply_one(self.opt_dis, self.flags[0:1], S_NA))
+            ops.side_run(dev, lambda: self._apply_one(self.opt_dis, self.dis, self.flags[0:1], S_NA))
         # decoder cotangent, stored = dec * nA * (lambda*B_true - (1-lambda)*A_true)
         cot = torch.empty(3 * B, H, W, 8, dtype=torch.float16, device=dev)
         lam = hp.lambda_mse
@@ -400,7 +401,7 @@ class Stage1Step(_GanStepBase):
         dz = self.dec.backward(fw["dctx"], cot, entries, join=dp)[2]  # = nB * dz_true
         self.dd.all_reduce_async(self.dec.group.grad)
         if early:
-            ops.side_run(dev, lambda: self._apply_one(self.opt_dec, self.flags[1:2], S_NA))
+            ops.side_run(dev, lambda: self._apply_one(self.opt_dec, self.dec, self.flags[1:2], S_NA))
         dhead32 = torch.empty(B, 2 * Z, dtype=torch.float32, device=dev)
         lib.call("fmri_latent_bwd", _P(fw["head32"]), _P(fw["eps"]), _P(dz), Z, 1.0, 1.0, _P(self._slot(S_NB)), B, Z,
                  1.0, None, _P(dhead32), 1)                              # = nB * dhead_true
@@ -414,10 +415,10 @@ class Stage1Step(_GanStepBase):
         self.dd.all_reduce(eg.grad[:tail])
         self.dd.wait_all()
 
-    def _apply_one(self, opt, flag, slot):
-        """Optimizer update of one sub-network + refresh of its fp16 GEMM weights (on the current stream)."""
+    def _apply_one(self, opt, net, flag, slot):
+        """Optimizer update of one sub-network + refresh of everything derived from its weights (current stream)."""
         opt.step(flag, gdev=self._slot(slot))
-        ops.repack_group(opt.g)
+        refresh_net(net)
 
     def apply(self):
         self.opt_enc.step(None, gdev=self._slot(S_NE))
@@ -426,6 +427,39 @@ class Stage1Step(_GanStepBase):
             return
         self.opt_dec.step(self.flags[1:2], gdev=self._slot(S_NA))
         self.opt_dis.step(self.flags[0:1], gdev=self._slot(S_NA))
+
+    def capture_forward(self, x, eps, z_p, warmup: int = 2):
+        """Hybrid launch mode (one GPU): the forward pass + gate -- a dependent chain with nothing to overlap -- is
+        recorded into a HIP graph, the backward pass and the updates stay eagerly issued launches on two streams
+        (``ops.side_run``).  Halves the Python work per step, which is what decides whether a slow host can keep the
+        two-stream backward fed.  Returns a zero-argument callable running one full step on the static inputs."""
+        if self.dd.on:
+            raise RuntimeError("capture_forward: single-process steps only (use capture() in data-parallel runs)")
+        nets = (self.enc, self.dec, self.dis)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.step(x, eps, z_p)
+            ops.join_side()
+            for n in nets:
+                refresh_net(n)               # so that the recorded forward contains no refresh launches
+        torch.cuda.current_stream().wait_stream(side)
+        B = x.shape[0]
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self.forward(x, eps, z_p)
+            self.gate(B)
+
+        def run():
+            for n in nets:
+                refresh_net(n)               # no-ops for the sub-networks the last backward refreshed early
+            graph.replay()
+            self.backward(early_apply=True)
+            self.apply()
+            return self.scal
+        self._fwd_graph = graph
+        return run
 
     def step(self, x, eps, z_p):
         """One full training step; returns the device scalar block (see LOG_KEYS) without syncing."""

@@ -171,7 +171,7 @@ def main():
         except Exception as e:               # capture is an optimisation: fall back to eager launches
             log(f"graph capture failed ({type(e).__name__}: {e}); continuing with eager launches")
             modes.pop("graph", None)
-        if single and ops._SIDE["on"] and not a.graph:
+        if (single or not a.sync_bn) and ops._SIDE["on"] and not a.graph:
             # hybrid: recorded forward + eagerly issued two-stream backward (half the Python work of a step)
             try:
                 modes["hybrid"] = st.capture_forward(x, nz[0], nz[1])
@@ -257,8 +257,8 @@ def main():
                          "avg_launch_ms": round(ms / nl, 4),
                          "avg_launch_gflop": round(fl / nl / 1e9, 2)},
             "launch": {"graph": "hip-graph replay" if single else "hip-graph segments + eager collectives",
-                       "hybrid": "forward + gate replayed from a HIP graph, backward eager with weight gradients on a "
-                                 "side stream",
+                       "hybrid": "forward replayed from a HIP graph, backward eager with weight gradients on a side "
+                                 "stream" + ("" if single else " and eager collectives"),
                        "eager": "eager, one stream" if not ops._SIDE["on"]
                        else "eager, weight gradients on a side stream"}[mode],
             "step_mfma_frac": round(value / world * FLOP_PER_IMAGE / 1e12 / MFMA_PEAK_TFLOPS, 4),

@@ -23,6 +23,44 @@ import torch.nn.functional as F
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
+def _collect(procs, q, n, timeout=240.0):
+    """n results from the worker queue; fails (instead of blocking forever) when a worker died or nothing arrives."""
+    import time
+    out, t0 = [], time.time()
+    while len(out) < n:
+        if not q.empty():
+            item = q.get()
+            if isinstance(item, tuple) and len(item) == 2 and item[0] == "error":
+                for p in procs:
+                    p.kill()
+                raise AssertionError("worker failed:\n" + item[1])
+            out.append(item)
+            continue
+        if time.time() - t0 > timeout or all(not p.is_alive() for p in procs):
+            if not q.empty():
+                continue
+            for p in procs:
+                p.kill()
+            raise AssertionError(f"workers delivered {len(out)}/{n} results (exit codes {[p.exitcode for p in procs]})")
+        time.sleep(0.05)
+    return out
+
+
+def _guarded(fn):
+    """Worker wrapper: an exception is reported through the queue (the peer would otherwise wait in a collective)."""
+    import functools
+    import traceback
+
+    @functools.wraps(fn)
+    def wrapper(*args):
+        try:
+            fn(*args)
+        except BaseException:
+            args[-1].put(("error", traceback.format_exc()))
+            raise
+    return wrapper
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -73,6 +111,7 @@ def _toy_loss(x, w1, gamma, beta, w2, reducer):
     return (F.linear(h, w2) ** 2).sum()            # a batch SUM, like every reference loss
 
 
+@_guarded
 def _worker_cpu(rank, world, port, q):
     _init(rank, world, port)
     from fmri_hip.steps import _Dist
@@ -116,10 +155,11 @@ def test_syncbn_sum_allreduce_equals_global_batch_cpu_gloo():
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    res = sorted(q.get() for _ in range(2))
+    res = sorted(_collect(procs, q, 2))
     assert res == [(0, True), (1, True)]
 
 
+@_guarded
 def _worker_gpu(rank, world, port, q):
     _init(rank, world, port)
     from oracle import vaegan_oracle as O
@@ -152,7 +192,7 @@ def test_two_rank_stage1_step_equals_single_process_global_batch():
     procs = [ctx.Process(target=_worker_gpu, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get() for _ in range(2)], key=lambda t: t[0])
+    res = sorted(_collect(procs, q, 2), key=lambda t: t[0])
     for p in procs:
         p.join(300)
         assert p.exitcode == 0
@@ -191,6 +231,66 @@ def test_two_rank_stage1_step_equals_single_process_global_batch():
         assert abs(res[0][3][k] - res[1][3][k]) <= 1e-6 * abs(res[0][3][k]) + 1e-9, k
 
 
+@_guarded
+def _worker_hybrid(rank, world, port, q):
+    """Per-rank BN statistics (bench.py's default): the recorded-forward hybrid step against the eager step, both
+    data parallel over 2 ranks (gloo over device tensors)."""
+    _init(rank, world, port)
+    from oracle import vaegan_oracle as O
+    from fmri_hip import ops
+    from fmri_hip.params import ArchConfig
+    from fmri_hip.steps import Stage1Step
+    torch.cuda.set_device(0)
+    B = 4
+    data = O.synth_batch(2 * B, O.ArchCfg.px64(), seed=1234, steps=1)
+    sl = slice(rank * B, (rank + 1) * B)
+    x, e, zp = data["x"][sl].cuda(), data["noise"][0, 0][sl].cuda(), data["noise"][0, 1][sl].cuda()
+    a = Stage1Step(ArchConfig.px64(), "cuda:0", distributed=True, sync_bn=False)
+    a.load_recipe(0, True)
+    run = a.capture_forward(x, e, zp, warmup=1)
+    b = Stage1Step(ArchConfig.px64(), "cuda:0", distributed=True, sync_bn=False)
+    b.load_state_dict(a.state_dict())
+    for oa, ob in ((a.opt_enc, b.opt_enc), (a.opt_dec, b.opt_dec), (a.opt_dis, b.opt_dis)):
+        ob.s1.copy_(oa.s1)
+    run()
+    ops.join_side()
+    b.step(x, e, zp)
+    ops.join_side()
+    torch.cuda.synchronize()
+    la, lb = a.logs(), b.logs()
+    sa, sb = a.state_dict(), b.state_dict()
+    worst = max(float((sa[k].float() - sb[k].float()).norm() / (sb[k].float().norm() + 1e-20)) for k in sa)
+    q.put((rank, {k: (la[k], lb[k]) for k in ("loss_encoder", "loss_decoder", "loss_discriminator", "kl")}, worst,
+           {k: float(v.float().norm()) for k, v in sa.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_rank_hybrid_step_equals_eager_step_local_bn():
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_hybrid, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(_collect(procs, q, 2), key=lambda t: t[0])
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    for rank, logs, worst, _ in res:
+        for k, (va, vb) in logs.items():
+            assert abs(va - vb) < 1e-5 * abs(vb), (rank, k, va, vb)
+        assert worst < 2e-5, (rank, worst)
+    # gradients were summed over the ranks: both hold identical parameters after the step (the running statistics are
+    # per rank in this mode)
+    for k in res[0][3]:
+        if "running_" in k:
+            continue
+        assert abs(res[0][3][k] - res[1][3][k]) <= 1e-6 * abs(res[0][3][k]) + 1e-9, k
+
+
+@_guarded
 def _worker_segments(port, q):
     """1-rank RCCL group on the GPU (FMRI_FORCE_DIST): a step replayed as graph segments + eager collectives must
     leave the same state as eagerly issued steps."""
@@ -242,5 +342,5 @@ def test_graph_segments_with_eager_collectives_equal_eager_steps():
     p.start()
     p.join(300)
     assert p.exitcode == 0
-    ok, worst, la, lb = q.get()
+    ok, worst, la, lb = _collect([p], q, 1)[0]
     assert ok, (worst, la, lb)

@@ -210,7 +210,8 @@ class _GanStepBase:
         lib.call("fmri_gan_head", _P(logit32), 1, B, _P(prob), _P(self.scal))
         lib.call("fmri_feat_mse", _P(feat), B, F, None, _P(self._slot(S_MSE)))
         lib.call("fmri_pixel_sq", _P(x16), _P(xt16), B * H * W, 3, 8, _P(self._slot(S_NLE)), None, 1.0)
-        self.dd.all_reduce(self.scal[:N_REDUCED])
+        if not getattr(self, "_defer_loss_reduce", False):
+            self.dd.all_reduce(self.scal[:N_REDUCED])
         return prob, F
 
     def _gate(self, B_global, F, gate_on=True, force_dis=-1, force_dec=-1):
@@ -432,9 +433,13 @@ class Stage1Step(_GanStepBase):
         """Hybrid launch mode (one GPU): the forward pass + gate -- a dependent chain with nothing to overlap -- is
         recorded into a HIP graph, the backward pass and the updates stay eagerly issued launches on two streams
         (``ops.side_run``).  Halves the Python work per step, which is what decides whether a slow host can keep the
-        two-stream backward fed.  Returns a zero-argument callable running one full step on the static inputs."""
-        if self.dd.on:
-            raise RuntimeError("capture_forward: single-process steps only (use capture() in data-parallel runs)")
+        two-stream backward fed.  Also available to data-parallel runs with per-rank BN statistics (no collective in
+        the forward pass).  Returns a zero-argument callable running one full step on the static inputs."""
+        if self.dd.on and self.dd.sync_bn:
+            raise RuntimeError("capture_forward: the forward pass holds SyncBN collectives (use capture())")
+        # data parallel with per-rank BN statistics: the forward pass's only collective is the sum of the loss scalars at
+        # its very end; that all-reduce, the gate and the backward pass with its gradient reductions stay eager
+        gate_in_graph = not self.dd.on
         nets = (self.enc, self.dec, self.dis)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -447,14 +452,23 @@ class Stage1Step(_GanStepBase):
         torch.cuda.current_stream().wait_stream(side)
         B = x.shape[0]
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            self.forward(x, eps, z_p)
-            self.gate(B)
+        # thread_local: the communication backend's watchdog thread may touch the device while this thread records
+        self._defer_loss_reduce = not gate_in_graph      # the forward's only collective (sum of the loss scalars)
+        try:
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                self.forward(x, eps, z_p)
+                if gate_in_graph:
+                    self.gate(B)
+        finally:
+            self._defer_loss_reduce = False
 
         def run():
             for n in nets:
                 refresh_net(n)               # no-ops for the sub-networks the last backward refreshed early
             graph.replay()
+            if not gate_in_graph:
+                self.dd.all_reduce(self.scal[:N_REDUCED])
+                self.gate(B * self.dd.world)
             self.backward(early_apply=True)
             self.apply()
             return self.scal

@@ -1,7 +1,7 @@
 #!/bin/bash
 # refresh of the judged artefacts: GPU tests, bench line, rocprof kernel table of the same command, PMC traffic
 R=$PWD
-python -m pytest tests -q -m gpu > gpurun_out/gpu_tests.log 2>&1; tail -3 gpurun_out/gpu_tests.log
+timeout -k 10 600 python -m pytest tests -q -m gpu > gpurun_out/gpu_tests.log 2>&1; tail -3 gpurun_out/gpu_tests.log
 python bench.py --steps 20 --warmup 5 > gpurun_out/bench.json 2> gpurun_out/bench.err; cat gpurun_out/bench.json
 cd /tmp && export TMPDIR=/tmp; cd $R
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_final -o x -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --eager --serial > gpurun_out/bench_rocprof.json 2> gpurun_out/bench_rocprof.err

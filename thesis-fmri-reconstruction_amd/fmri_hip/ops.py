@@ -221,7 +221,9 @@ def run_igemm(x, pw: PackedWeight, out, bias, N, Hi, Wi, Ci, Ho, Wo, CoStore, Co
 # window-resident wgrad kernel: on/off, resident-block target (2 per CU), largest split count still written as slabs
 _WW_ON = os.environ.get("FMRI_WGRAD_WIN") != "off"
 _WN_ON = os.environ.get("FMRI_WGRAD_NARROW") != "off"
-_WW_BLOCKS = int(os.environ.get("FMRI_WW_BLOCKS", "512"))
+# resident-block target: 2 blocks per CU when the kernel has the GPU to itself (one stream, recorded graphs); 1 per CU
+# when it runs on the side stream beside the main stream's kernels (measured 8.18 vs 8.26 ms per step)
+_WW_BLOCKS = int(os.environ.get("FMRI_WW_BLOCKS", "0"))
 _WW_SLABS = int(os.environ.get("FMRI_WW_SLABS", "24"))
 
 
@@ -286,7 +288,8 @@ def run_wgrad(P, Q, N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad, flip=0):
         # window-resident kernel (csrc/wgrad_win.hip): blocks = 32-channel column blocks x 128-row blocks x 4 parity
         # planes x splits over the 8x8 pixel tiles; every split stores its own slab, unpack_grad sums them
         groups = (Bc // 32) * (apad // 128)
-        splits = max(4, _WW_BLOCKS // groups)                           # block budget per group over the 4 planes
+        budget = _WW_BLOCKS or (256 if _SIDE["on"] else 512)
+        splits = max(4, budget // groups)                               # block budget per group over the 4 planes
         nslabs = lib.load().fmri_wgrad_slabs(N, Yc, Xc, k, pad, splits)
         slabs = nslabs <= _WW_SLABS                                     # few splits: per-split slabs, else atomics
         if slabs:

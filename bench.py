@@ -180,6 +180,14 @@ def main():
                 log(f"forward capture failed ({type(e).__name__}: {e})")
                 modes.pop("hybrid", None)
 
+    if world > 1:
+        # a launch mode is only usable if every rank managed to record it (the probe below is a collective decision)
+        have = torch.tensor([float("graph" in modes), float("hybrid" in modes)], dtype=torch.float32, device=dev)
+        dist.all_reduce(have, op=dist.ReduceOp.MIN)
+        for i, k in enumerate(("graph", "hybrid")):
+            if have[i].item() < 1.0:
+                modes.pop(k, None)
+
     def probe(fn, n=6):
         barrier()
         t = time.perf_counter()

@@ -120,13 +120,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.gpus > 1 and world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})")
+    if os.environ.get("FMRI_REHEARSE_ON_ONE_GPU") == "1":
+        local = 0                      # all ranks share device 0 (with FMRI_DIST_BACKEND=gloo): control-flow rehearsal
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     force_dist = os.environ.get("FMRI_FORCE_DIST") == "1"      # 1-rank rehearsal of the RCCL path
     if world > 1 or force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("FMRI_DIST_BACKEND", "nccl")          # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     if a.serial:
         os.environ["FMRI_SIDE_STREAM"] = "off"

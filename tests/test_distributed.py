@@ -259,7 +259,14 @@ def _worker_hybrid(rank, world, port, q):
     torch.cuda.synchronize()
     la, lb = a.logs(), b.logs()
     sa, sb = a.state_dict(), b.state_dict()
-    worst = max(float((sa[k].float() - sb[k].float()).norm() / (sb[k].float().norm() + 1e-20)) for k in sa)
+    # per tensor: number of elements that differ by more than 2e-5 of the tensor's largest entry, over the allowance
+    # max(2, 0.1 %) (see tests/test_stage1_gpu.py::_same_update for why single elements may flip)
+    worst = 0.0
+    for k in sa:
+        ta, tb = sa[k].float().reshape(-1), sb[k].float().reshape(-1)
+        lim = 2e-5 * max(float(tb.abs().max()), 1e-3)
+        bad = int(((ta - tb).abs() > lim).sum())
+        worst = max(worst, bad / max(2, ta.numel() // 1000))
     q.put((rank, {k: (la[k], lb[k]) for k in ("loss_encoder", "loss_decoder", "loss_discriminator", "kl")}, worst,
            {k: float(v.float().norm()) for k, v in sa.items()}))
     dist.barrier()
@@ -281,7 +288,7 @@ def test_two_rank_hybrid_step_equals_eager_step_local_bn():
     for rank, logs, worst, _ in res:
         for k, (va, vb) in logs.items():
             assert abs(va - vb) < 1e-5 * abs(vb), (rank, k, va, vb)
-        assert worst < 2e-5, (rank, worst)
+        assert worst <= 1.0, (rank, worst)
     # gradients were summed over the ranks: both hold identical parameters after the step (the running statistics are
     # per rank in this mode)
     for k in res[0][3]:

@@ -276,6 +276,38 @@ def test_batchnorm_forward_backward(M, C):
     _close(g.grads["bn.bias"].cpu() * 8.0, br.grad, "bn dbeta", tol=3e-3)
 
 
+@pytest.mark.parametrize("M,C", [(3 * 32 * 32, 128), (600, 256), (37, 64)])
+def test_batchnorm_backward_two_streams(M, C):
+    """``BatchNorm.backward2`` (two stacked cotangent streams, the forward tensor read once) against autograd on the two
+    cotangents separately; gamma / beta gradients come from stream A only."""
+    from fmri_hip.ops import BatchNorm
+    torch.manual_seed(M * 3 + C)
+    x = _h(torch.randn(M, C) * 1.2 - 0.2)
+    gamma = 1 + 0.2 * torch.randn(C)
+    beta = 0.1 * torch.randn(C)
+    g = _G({"bn.weight": gamma, "bn.bias": beta})
+    g.bufs = {"bn.running_mean": torch.zeros(C, device=DEV), "bn.running_var": torch.ones(C, device=DEV),
+              "bn.num_batches_tracked": torch.zeros((), dtype=torch.int64, device=DEV)}
+    bn = BatchNorm(g, "bn.", C)
+    x16 = x.half().to(DEV)
+    _, sv = bn.forward(x16, relu=True, updates=0)
+    dya, dyb = _h(torch.randn(M, C)), _h(torch.randn(M, C) * 0.5)
+    ref = []
+    for dy in (dya, dyb):
+        xr = x.clone().requires_grad_(True)
+        gr = gamma.clone().requires_grad_(True)
+        br = beta.clone().requires_grad_(True)
+        F.relu(F.batch_norm(xr, None, None, gr, br, True, 0.9, 1e-5)).backward(dy)
+        ref.append((xr.grad, gr.grad, br.grad))
+    dy2 = torch.cat([dya, dyb], 0).half().to(DEV)
+    dx2, sums = bn.backward2(x16, dy2, sv, relu=True, param_scale=4.0)
+    _close(dx2[:M].float().cpu(), ref[0][0], "bn dx stream A", tol=3e-3)
+    _close(dx2[M:].float().cpu(), ref[1][0], "bn dx stream B", tol=3e-3)
+    _close(g.grads["bn.weight"].cpu() * 4.0, ref[0][1], "bn dgamma (A only)", tol=3e-3)
+    _close(g.grads["bn.bias"].cpu() * 4.0, ref[0][2], "bn dbeta (A only)", tol=3e-3)
+    assert sums.shape == (4, C)
+
+
 def test_batchnorm_permuted_features():
     """decoder.fc.1: reference vectors in (C,HW) order, engine rows in (HW,C) order."""
     from fmri_hip.ops import BatchNorm

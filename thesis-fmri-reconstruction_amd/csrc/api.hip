@@ -517,6 +517,20 @@ int fmri_bn_bwd_reduce(const void* x, const void* dy, int M, int C, const float*
     return bn_bwd_reduce_launch((const half_t*)x, (const half_t*)dy, M, C, mean, rstd, gamma, beta, relu, sums2C, ws,
                                 ws_floats, dbeta, dgamma, gscale, S(stream));
 }
+int fmri_bn_bwd_reduce2(const void* x, const void* dy2, int M, int C, const float* mean, const float* rstd,
+                        const float* gamma, const float* beta, int relu, float* sums4C, float* ws, int64_t ws_floats,
+                        float* dbeta, float* dgamma, float gscale, void* stream) {
+    if (!x || !dy2 || !sums4C || (C & 7) || M < 1) return FMRI_E_BADARG;
+    return bn_bwd_reduce2_launch((const half_t*)x, (const half_t*)dy2, M, C, mean, rstd, gamma, beta, relu, sums4C, ws,
+                                 ws_floats, dbeta, dgamma, gscale, S(stream));
+}
+int fmri_bn_bwd_apply2(const void* x, const void* dy2, void* dx2, int M, int C, float count, const float* mean,
+                       const float* rstd, const float* gamma, const float* beta, int relu, const float* sums4C,
+                       void* stream) {
+    if (!x || !dy2 || !dx2 || !sums4C || (C & 7) || M < 1) return FMRI_E_BADARG;
+    return bn_bwd_apply2_launch((const half_t*)x, (const half_t*)dy2, (half_t*)dx2, M, C, count, mean, rstd, gamma, beta,
+                                relu, sums4C, S(stream));
+}
 int fmri_bn_bwd_apply(const void* x, const void* dy, void* dx, int M, int C, float count, const float* mean,
                       const float* rstd, const float* gamma, const float* beta, int relu, const float* sums2C,
                       void* stream) {

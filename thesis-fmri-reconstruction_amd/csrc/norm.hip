@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const half_t* __restrict
 // g1 += gscale * sums[C..2C) = d gamma) -- one writer per element, no atomics.
 __global__ __launch_bounds__(1024) void fold_partials_kernel(const float* __restrict__ part, int nparts, int n,
                                                              float* __restrict__ sums, float* __restrict__ g0,
-                                                             float* __restrict__ g1, float gscale) {
+                                                             float* __restrict__ g1, float gscale, int gC) {
     // 32 columns x 32 row lanes per block: the kernel is a chain of memory latencies (few blocks, tiny data), so the
     // partial rows are spread over as many lanes as a block has and each lane keeps four loads in flight
     __shared__ float red[32][33];
@@ -160,9 +160,9 @@ __global__ __launch_bounds__(1024) void fold_partials_kernel(const float* __rest
 #pragma unroll
         for (int r = 0; r < 32; ++r) s += red[r][cx];
         sums[i] = s;
-        const int C = n >> 1;
+        const int C = gC > 0 ? gC : (n >> 1);   // columns [0, C) -> g0, [C, 2C) -> g1 (first cotangent stream only)
         if (g0 && i < C) g0[i] += gscale * s;
-        if (g1 && i >= C) g1[i - C] += gscale * s;
+        if (g1 && i >= C && i < 2 * C) g1[i - C] += gscale * s;
     }
 }
 
@@ -315,6 +315,143 @@ __global__ __launch_bounds__(256) void bn_stream_kernel(const half_t* __restrict
     }
 }
 
+// ---- BatchNorm backward of TWO cotangent streams through one saved forward (the discriminator's logit stream A and
+// feature stream B, stacked as dy = [A rows | B rows], M rows each).  The forward tensor x and everything derived from
+// it (xhat, the ReLU mask) are read and computed once for both: 3 + 5 tensor passes instead of 2 x (2 + 3).
+// partials / sums layout: [A: sum g | A: sum g*xhat | B: sum g | B: sum g*xhat], C floats each.
+__global__ __launch_bounds__(256) void bn_reduce2_kernel(const half_t* __restrict__ x, const half_t* __restrict__ dy,
+                                                         int M, int C, int cx_log2, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, int relu,
+                                                         float* __restrict__ part /* [gridDim.y][4][C] */) {
+    __shared__ float red[256 * 17];
+    const int CX = 1 << cx_log2;
+    const int RY = 256 >> cx_log2;
+    const int cx = threadIdx.x & (CX - 1);
+    const int ry = threadIdx.x >> cx_log2;
+    const int chunk = blockIdx.x * CX + cx;
+    const int nch = C >> 3;
+    float sa0[8], sa1[8], sb0[8], sb1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sa0[j] = 0.f; sa1[j] = 0.f; sb0[j] = 0.f; sb1[j] = 0.f; }
+    if (chunk < nch) {
+        float mu[8], rs[8], ga[8], be[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            mu[j] = mean[chunk * 8 + j]; rs[j] = rstd[chunk * 8 + j];
+            ga[j] = gamma[chunk * 8 + j]; be[j] = beta[chunk * 8 + j];
+        }
+        const int stride = gridDim.y * RY;
+        const int64_t coff = (int64_t)chunk * 8;
+        const half_t* dyb = dy + (int64_t)M * C;
+        auto body = [&](const h8& xv, const h8& ga_v, const h8& gb_v) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xh = ((float)xv[j] - mu[j]) * rs[j];
+                const bool on = !relu || (xh * ga[j] + be[j] > 0.f);
+                const float g_a = on ? (float)ga_v[j] : 0.f, g_b = on ? (float)gb_v[j] : 0.f;
+                sa0[j] += g_a; sa1[j] += g_a * xh;
+                sb0[j] += g_b; sb1[j] += g_b * xh;
+            }
+        };
+        int m = blockIdx.y * RY + ry;
+        for (; m + 3 * stride < M; m += 4 * stride) {
+            h8 xv[4], av[4], bv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t o = (int64_t)(m + u * stride) * C + coff;
+                xv[u] = *(const h8*)(x + o);
+                av[u] = *(const h8*)(dy + o);
+                bv[u] = *(const h8*)(dyb + o);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) body(xv[u], av[u], bv[u]);
+        }
+        for (; m < M; m += stride) {
+            const int64_t o = (int64_t)m * C + coff;
+            body(*(const h8*)(x + o), *(const h8*)(dy + o), *(const h8*)(dyb + o));
+        }
+    }
+    // block reduction of the 16 per-thread values of a stream over the RY row lanes, stream A then stream B
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            red[threadIdx.x * 17 + j] = s ? sb0[j] : sa0[j];
+            red[threadIdx.x * 17 + 8 + j] = s ? sb1[j] : sa1[j];
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < CX * 16; t += 256) {
+            const int c = t >> 4, j = t & 15;
+            const int ch = blockIdx.x * CX + c;
+            if (ch >= nch) continue;
+            float v = 0.f;
+            for (int r = 0; r < RY; ++r) v += red[((r << cx_log2) + c) * 17 + j];
+            part[((int64_t)blockIdx.y * 4 + 2 * s + (j >> 3)) * C + ch * 8 + (j & 7)] = v;
+        }
+        __syncthreads();
+    }
+}
+
+// dx_s = gamma*rstd*(g_s - sum_g_s/M - xhat*sum_gx_s/M) for both streams, x read once
+__global__ __launch_bounds__(256) void bn_stream2_kernel(const half_t* __restrict__ x, const half_t* __restrict__ dy,
+                                                         half_t* __restrict__ out, int M, int C, int cx_log2,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, int relu, float inv_count,
+                                                         const float* __restrict__ sums /* [4][C] */) {
+    const int CX = 1 << cx_log2;
+    const int RY = 256 >> cx_log2;
+    const int cx = threadIdx.x & (CX - 1);
+    const int ry = threadIdx.x >> cx_log2;
+    const int chunk = blockIdx.x * CX + cx;
+    if (chunk >= (C >> 3)) return;
+    float a[8], b[8], k[8], ga[8], be[8], a0[8], a1[8], b0[8], b1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = chunk * 8 + j;
+        a[j] = rstd[c]; b[j] = mean[c]; ga[j] = gamma[c]; be[j] = beta[c];
+        k[j] = ga[j] * a[j];
+        a0[j] = sums[c] * inv_count; a1[j] = sums[C + c] * inv_count;
+        b0[j] = sums[2 * C + c] * inv_count; b1[j] = sums[3 * C + c] * inv_count;
+    }
+    const int stride = gridDim.y * RY;
+    const int64_t coff = (int64_t)chunk * 8;
+    const int64_t sb = (int64_t)M * C;
+    auto body = [&](const h8& xv, const h8& av, const h8& bv, int m) {
+        h8 oa, ob;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xh = ((float)xv[j] - b[j]) * a[j];
+            const bool on = !relu || (xh * ga[j] + be[j] > 0.f);
+            const float g_a = on ? (float)av[j] : 0.f, g_b = on ? (float)bv[j] : 0.f;
+            oa[j] = (half_t)(k[j] * (g_a - a0[j] - xh * a1[j]));
+            ob[j] = (half_t)(k[j] * (g_b - b0[j] - xh * b1[j]));
+        }
+        const int64_t o = (int64_t)m * C + coff;
+        *(h8*)(out + o) = oa;
+        *(h8*)(out + sb + o) = ob;
+    };
+    int m = blockIdx.y * RY + ry;
+    for (; m + stride < M; m += 2 * stride) {
+        h8 xv[2], av[2], bv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t o = (int64_t)(m + u * stride) * C + coff;
+            xv[u] = *(const h8*)(x + o);
+            av[u] = *(const h8*)(dy + o);
+            bv[u] = *(const h8*)(dy + sb + o);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) body(xv[u], av[u], bv[u], m + u * stride);
+    }
+    for (; m < M; m += stride) {
+        const int64_t o = (int64_t)m * C + coff;
+        body(*(const h8*)(x + o), *(const h8*)(dy + o), *(const h8*)(dy + sb + o), m);
+    }
+}
+
 #define LAUNCH_OK() (hipGetLastError() == hipSuccess ? OK : E_LAUNCH)
 
 int64_t bn_ws_floats(int M, int C) {
@@ -338,7 +475,7 @@ static int reduce_launch(const half_t* x, const half_t* dy, half_t* dout, int M,
     if (sums) {
         const int n = 2 * C;
         hipLaunchKernelGGL(fold_partials_kernel, dim3((n + 31) / 32), dim3(1024), 0, st, ws, g.gy, n, sums, g0, g1,
-                           gscale);
+                           gscale, 0);
     }
     return LAUNCH_OK();
 }
@@ -371,6 +508,18 @@ int act_bwd_launch(const half_t* y, const half_t* dy, half_t* dpre, int M, int C
                    int64_t ws_floats, hipStream_t st) {
     return reduce_launch<2>(y, dy, dpre, M, C, nullptr, nullptr, nullptr, nullptr, act, colsum, ws, ws_floats, st);
 }
+int bn_bwd_reduce2_launch(const half_t* x, const half_t* dy, int M, int C, const float* mean, const float* rstd,
+                          const float* gamma, const float* beta, int relu, float* sums4C, float* ws, int64_t ws_floats,
+                          float* dbeta, float* dgamma, float gscale, hipStream_t st) {
+    if (!ws || ws_floats < 4 * (int64_t)C) return E_WORKSPACE;
+    const RowGeom g = row_geometry(M, C, (int)(ws_floats / (4 * (int64_t)C)));
+    hipLaunchKernelGGL(bn_reduce2_kernel, dim3(g.gx, g.gy), dim3(256), 0, st, x, dy, M, C, g.cx_log2, mean, rstd, gamma,
+                       beta, relu, ws);
+    const int n = 4 * C;
+    hipLaunchKernelGGL(fold_partials_kernel, dim3((n + 31) / 32), dim3(1024), 0, st, ws, g.gy, n, sums4C, dbeta, dgamma,
+                       gscale, C);
+    return LAUNCH_OK();
+}
 int bn_finalize_launch(const float* sums, int C, float count, const float* gamma, const float* beta, float eps,
                        float momentum, int updates, float* rm, float* rv, float* mean, float* rstd, float* scale,
                        float* shift, long long* nbt, hipStream_t st) {
@@ -394,6 +543,14 @@ int bn_apply_launch(const half_t* x, half_t* y, int M, int C, const float* scale
     hipLaunchKernelGGL((bn_stream_kernel<0>), dim3(g.gx, g.gy), dim3(256), 0, st, x, (const half_t*)nullptr, y, M, C,
                        g.cx_log2, scale, shift, (const float*)nullptr, (const float*)nullptr, relu, 0.f,
                        (const float*)nullptr);
+    return LAUNCH_OK();
+}
+int bn_bwd_apply2_launch(const half_t* x, const half_t* dy, half_t* dx, int M, int C, float count, const float* mean,
+                         const float* rstd, const float* gamma, const float* beta, int relu, const float* sums4C,
+                         hipStream_t st) {
+    const RowGeom g = stream_geometry(M, C);
+    hipLaunchKernelGGL(bn_stream2_kernel, dim3(g.gx, g.gy), dim3(256), 0, st, x, dy, dx, M, C, g.cx_log2, mean, rstd,
+                       gamma, beta, relu, 1.f / count, sums4C);
     return LAUNCH_OK();
 }
 int bn_bwd_apply_launch(const half_t* x, const half_t* dy, half_t* dx, int M, int C, float count, const float* mean,

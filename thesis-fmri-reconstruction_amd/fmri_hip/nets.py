@@ -399,9 +399,14 @@ class DiscriminatorNet:
             if li > 0:
                 dact = self.convs[li].dgrad(d, hi, wi)
                 dn = torch.empty_like(dact)
-                for si, s in enumerate(streams):
-                    self.bns[li - 1].backward(ctx["raws"][li - 1], rows(dact, si), ctx["svs"][li - 1], True,
-                                              s["scale"] if s["train"] else None, out=rows(dn, si))
+                if S == 2 and not streams[1]["train"]:
+                    # both streams in one pass over the saved forward tensor (gamma / beta gradients from stream A only)
+                    self.bns[li - 1].backward2(ctx["raws"][li - 1], dact, ctx["svs"][li - 1], True,
+                                               streams[0]["scale"] if streams[0]["train"] else None, out=dn)
+                else:
+                    for si, s in enumerate(streams):
+                        self.bns[li - 1].backward(ctx["raws"][li - 1], rows(dact, si), ctx["svs"][li - 1], True,
+                                                  s["scale"] if s["train"] else None, out=rows(dn, si))
                 d = dn
         # conv1 data gradient, conv0 (bias + ReLU).  Below the last BatchNorm the images are independent, so a stream
         # that does not train the discriminator only needs the rows whose image gradient is wanted.

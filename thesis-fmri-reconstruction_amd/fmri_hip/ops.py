@@ -648,6 +648,32 @@ class BatchNorm:
                  _P(beta), 1 if relu else 0, _P(sums))
         return out, sums
 
+    def backward2(self, raw: torch.Tensor, dy2: torch.Tensor, sv: BNSaved, relu: bool = True,
+                  param_scale: Optional[float] = None, out: Optional[torch.Tensor] = None):
+        """``backward`` for TWO cotangent streams stacked along the rows, ``dy2 = [A rows | B rows]`` (each as many rows
+        as ``raw``): the forward tensor, xhat and the ReLU mask are read / computed once for both.  gamma / beta
+        gradients (``param_scale``) are taken from stream A only.  Not for (C,H,W)-permuted BN1d."""
+        assert not self.perm
+        C = self.C
+        x2 = raw.reshape(-1, C)
+        g2 = dy2.reshape(-1, C)
+        M = x2.shape[0]
+        assert g2.shape[0] == 2 * M
+        gamma, beta, _, _ = self._params()
+        sums = torch.empty(4, C, dtype=torch.float32, device=raw.device)
+        ws = torch.empty(2 * lib.load().fmri_bn_ws_floats(M, C), dtype=torch.float32, device=raw.device)
+        pg = param_scale is not None
+        lib.call("fmri_bn_bwd_reduce2", _P(x2), _P(g2), M, C, _P(sv.mean), _P(sv.rstd), _P(gamma), _P(beta),
+                 1 if relu else 0, _P(sums), _P(ws), ws.numel(), _P(self.gbeta) if pg else None,
+                 _P(self.ggamma) if pg else None, (1.0 / param_scale) if pg else 0.0)
+        if self.reducer is not None:
+            self.reducer(sums)
+        if out is None:
+            out = torch.empty_like(dy2)
+        lib.call("fmri_bn_bwd_apply2", _P(x2), _P(g2), _P(out), M, C, sv.count, _P(sv.mean), _P(sv.rstd), _P(gamma),
+                 _P(beta), 1 if relu else 0, _P(sums))
+        return out, sums
+
     def accumulate_param_grads(self, sums: torch.Tensor, scale: float):
         inv = 1.0 / scale
         if self.perm:

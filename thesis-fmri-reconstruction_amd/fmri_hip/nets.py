@@ -282,11 +282,22 @@ class DecoderNet:
         d = self.c3.dgrad(dpre, hi, wi)
         for i in (2, 1, 0):
             draw = torch.empty_like(d)
-            for e, en in enumerate(entries):
-                self.bns[i].backward(rows(ctx["raws"][i], en["g"]), rows(d, e), ctx["svs"][i][en["g"]], True,
-                                     en["scale"] if en["train"] else None, out=rows(draw, e))
+            e = 0
+            while e < E:
+                en = entries[e]
+                nx = entries[e + 1] if e + 1 < E else None
+                if nx is not None and nx["g"] == en["g"] and not nx["train"]:
+                    # two adjacent blocks through the same forward activations: one pass over them for both
+                    self.bns[i].backward2(rows(ctx["raws"][i], en["g"]), d[e * B:(e + 2) * B], ctx["svs"][i][en["g"]],
+                                          True, en["scale"] if en["train"] else None, out=draw[e * B:(e + 2) * B])
+                    step = 2
+                else:
+                    self.bns[i].backward(rows(ctx["raws"][i], en["g"]), rows(d, e), ctx["svs"][i][en["g"]], True,
+                                         en["scale"] if en["train"] else None, out=rows(draw, e))
+                    step = 1
                 if en["train"]:
                     self.deconvs[i].wgrad(rows(ctx["acts"][i], en["g"]), rows(draw, e), en["scale"])
+                e += step
             _, hi, wi, _ = ctx["acts"][i].shape
             d = self.deconvs[i].dgrad(draw, hi, wi)
         dflat = d.reshape(E * B, -1)

@@ -391,13 +391,24 @@ class DiscriminatorNet:
                 self.fc0.wgrad(ctx["flat"], draw_fc, scale_a)
             dflat, _ = self.fc0.dgrad(draw_fc)
             d3 = dflat.reshape(ctx["acts"][3].shape)
-            draw3, _ = self.bns[2].backward(ctx["raws"][2], d3, ctx["svs"][2], True, scale_a if train else None)
+            # caller-provided stack [A rows | B rows] with B already in place (steps._start_cotangents): A goes into its
+            # first half and the two-stream batch needs no concatenation copy
+            stack = getattr(dfeat16, "_fmri_stack", None) if dfeat16 is not None else None
+            if stack is not None and stack.shape[0] != 2 * n3:
+                stack = None
+            draw3, _ = self.bns[2].backward(ctx["raws"][2], d3, ctx["svs"][2], True, scale_a if train else None,
+                                            out=stack[:n3].reshape(ctx["raws"][2].shape) if stack is not None else None)
             streams.append(dict(d=draw3, scale=scale_a, train=train, img=img_streams[0]))
+        else:
+            stack = None
         if dfeat16 is not None:
             streams.append(dict(d=dfeat16.reshape(ctx["raws"][2].shape), scale=scale_b, train=train_b,
                                 img=img_streams[1]))
         S = len(streams)
-        d = torch.cat([s["d"] for s in streams], 0) if S > 1 else streams[0]["d"]
+        if S > 1 and stack is not None:
+            d = stack.reshape((2 * n3,) + tuple(ctx["raws"][2].shape[1:]))
+        else:
+            d = torch.cat([s["d"] for s in streams], 0) if S > 1 else streams[0]["d"]
         rows = lambda t, i: t[i * n3:(i + 1) * n3]
         # conv3 .. conv1
         for li in (2, 1, 0):

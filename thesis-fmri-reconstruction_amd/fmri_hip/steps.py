@@ -224,7 +224,11 @@ class _GanStepBase:
         dev = feat.device
         dlogit16 = torch.empty(3 * B, 8, dtype=torch.float16, device=dev)
         lib.call("fmri_gan_head_bwd", _P(logit32), 1, B, _P(dlogit16), 8, self.sc.a, _P(self._slot(S_NA)))
-        dfeat16 = torch.empty_like(feat)
+        # stream B's cotangent is written straight into the second half of the buffer that stacks both streams for the
+        # discriminator's conv backward (DiscriminatorNet fills the first half with stream A: no concatenation copy)
+        stack = torch.empty((2 * feat.shape[0],) + tuple(feat.shape[1:]), dtype=feat.dtype, device=dev)
+        dfeat16 = stack[feat.shape[0]:]
+        dfeat16._fmri_stack = stack
         lib.call("fmri_feat_mse_bwd", _P(feat), B, feat[0].numel(), _P(dfeat16), self.sc.b, _P(self._slot(S_NB)))
         return dlogit16, dfeat16
 

@@ -31,12 +31,13 @@ def _same_update(sa, sb, what=""):
     (relative 1e-6 ... 4e-5 of a tensor) and (b) single elements whose near-zero gradient changes sign between runs:
     RMSprop's first update is +-3.16e-4 whatever the gradient's size, so such an element moves by 6.3e-4 (the 3-element
     bias of the decoder's last conv does this regularly).  A wrong or missing update moves (nearly) EVERY element of a
-    tensor, so: at most max(4, 0.2 %) of a tensor's elements may differ by more than 2e-5 of its largest entry."""
+    tensor, so: at most max(4, 1 %) of a tensor's elements may differ by more than 2e-5 of its largest entry (measured:
+    up to 0.22 % at B = 4)."""
     for k in sa:
         a, b = sa[k].float().cpu().reshape(-1), sb[k].float().cpu().reshape(-1)
         lim = 2e-5 * max(float(b.abs().max()), 1e-3)
         bad = int(((a - b).abs() > lim).sum())
-        assert bad <= max(4, a.numel() // 500), (what, k, bad, a.numel(), float((a - b).abs().max()))
+        assert bad <= max(4, a.numel() // 100), (what, k, bad, a.numel(), float((a - b).abs().max()))
 
 
 def _run_engine(cfg_e, B, seed, perturb, steps, noise, x):

@@ -27,15 +27,17 @@ def _tensor_err(got, ref):
 
 
 def _same_update(sa, sb, what=""):
-    """Two runs of the same step leave the same parameters, up to (a) the fp32-atomics spread of the weight gradients
-    (relative 1e-6 ... 4e-5 of a tensor) and (b) single elements whose near-zero gradient changes sign between runs:
-    RMSprop's first update is +-3.16e-4 whatever the gradient's size, so such an element moves by 6.3e-4 (the 3-element
-    bias of the decoder's last conv does this regularly).  A wrong or missing update moves (nearly) EVERY element of a
-    tensor, so: at most max(4, 1 %) of a tensor's elements may differ by more than 2e-5 of its largest entry (measured:
-    up to 0.22 % at B = 4)."""
+    """Two runs of the same step leave the same parameters, up to the run-to-run spread of the fp32 atomics in the
+    weight-gradient sums.  RMSprop's first update is lr*g/(sqrt(0.1 g^2)+1e-8): +-3.16e-4 for every element whose
+    gradient is well above 1e-8, PROPORTIONAL to g below that -- so the spread shows as (a) up to ~1e-1 of a step on
+    the elements with near-zero gradients (measured: 5 % of encoder.conv.1 moved by <= 3.6e-5 in one run of four) and
+    (b) single elements whose gradient changes sign (a full 6.3e-4; the 3-element bias of the decoder's last conv does
+    this regularly).  A wrong or missing update moves (nearly) EVERY element of a tensor by a step.  Hence: elements may
+    differ by a quarter step (8e-5; or 2e-5 of the tensor's largest entry, for the running statistics), and at most
+    max(4, 1 %) of a tensor's elements by more."""
     for k in sa:
         a, b = sa[k].float().cpu().reshape(-1), sb[k].float().cpu().reshape(-1)
-        lim = 2e-5 * max(float(b.abs().max()), 1e-3)
+        lim = max(2e-5 * float(b.abs().max()), 8e-5)
         bad = int(((a - b).abs() > lim).sum())
         assert bad <= max(4, a.numel() // 100), (what, k, bad, a.numel(), float((a - b).abs().max()))
 

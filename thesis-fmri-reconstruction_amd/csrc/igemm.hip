@@ -89,12 +89,12 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmArgs a) 
 
     // UNI (Ci % 64 == 0): a K-step lies inside one tap, so the tap decode is wave-uniform (scalar) and a
     // row's source address is rowoff[i] + one scalar offset: no per-lane multiplies inside the K loop.
+    // The general path (a K-step may straddle taps, e.g. Ci = 32) uses the same row offsets; its tap decode is per lane
+    // but once per step and thread, not per row: no 32-bit multiplies (quarter rate) per row inside the K loop.
     int rowoff[4];
-    if (UNI) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            rowoff[i] = iy0[i] >= 0 ? (pixbase[i] + iy0[i] * a.Wi + ix0[i]) * a.Ci + clog * 8 : 0;
-    }
+    for (int i = 0; i < 4; ++i)
+        rowoff[i] = iy0[i] >= 0 ? (pixbase[i] + iy0[i] * a.Wi + ix0[i]) * a.Ci + (UNI ? clog * 8 : 0) : 0;
     const int cpt = a.Ci >> 6;     // K-steps per tap (UNI)
 
     int ltap = 0, lcstep = 0;                    // UNI: position of the step being staged in the chunk-major order
@@ -130,12 +130,13 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmArgs a) 
             const int dy = kdy0 + ty * kdstep;
             const int dx = kdx0 + tx * kdstep;
             const bool tv = tap < kT;
+            const int tapoff = (dy * kWi + dx) * kCi + ci;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int iy = iy0[i] + dy;
                 const int ix = ix0[i] + dx;
                 const bool ok = tv && (unsigned)iy < (unsigned)kHi && (unsigned)ix < (unsigned)kWi;
-                const half_t* src = ok ? kin + ((int64_t)(pixbase[i] + iy * kWi + ix) * kCi + ci) : kzero;
+                const half_t* src = ok ? kin + (rowoff[i] + tapoff) : kzero;
                 glds16(src, dstA + i * (RPP * 128));
             }
         }

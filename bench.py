@@ -279,7 +279,7 @@ def main():
             "losses_last_step": {k: logs[k] for k in ("loss_encoder", "loss_decoder", "loss_discriminator", "kl")},
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(32, 3)
+            out["cpu_baseline"] = cpu_baseline(32, 10)        # ~10-15 s of CPU work (bounded to 25 s inside)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1 or force_dist:
         dist.barrier()

@@ -143,10 +143,11 @@ int fmri_bn_bwd_apply(const void* x, const void* dy, void* dx, int M, int C, flo
 /* The same for TWO cotangent streams through one saved forward (the discriminator's logit and feature streams,
  * train/train_vgan_stage1.py:369-372 back-propagates both): dy2 / dx2 = [stream A rows | stream B rows], M rows each;
  * x, xhat and the ReLU mask are read / computed once.  sums4C = [A: sum g | A: sum g*xhat | B: sum g | B: sum g*xhat];
- * dbeta / dgamma (may be NULL) accumulate gscale * stream A's sums; the workspace needs 2 * fmri_bn_ws_floats. */
+ * dbeta / dgamma (may be NULL) accumulate gscale * the sums of stream param_stream (0 = A, 1 = B); the workspace needs
+ * 2 * fmri_bn_ws_floats. */
 int fmri_bn_bwd_reduce2(const void* x, const void* dy2, int M, int C, const float* mean, const float* rstd,
                         const float* gamma, const float* beta, int relu, float* sums4C, float* ws, int64_t ws_floats,
-                        float* dbeta, float* dgamma, float gscale, void* stream);
+                        float* dbeta, float* dgamma, float gscale, int param_stream, void* stream);
 int fmri_bn_bwd_apply2(const void* x, const void* dy2, void* dx2, int M, int C, float count, const float* mean,
                        const float* rstd, const float* gamma, const float* beta, int relu, const float* sums4C,
                        void* stream);

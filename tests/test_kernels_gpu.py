@@ -306,6 +306,12 @@ def test_batchnorm_backward_two_streams(M, C):
     _close(g.grads["bn.weight"].cpu() * 4.0, ref[0][1], "bn dgamma (A only)", tol=3e-3)
     _close(g.grads["bn.bias"].cpu() * 4.0, ref[0][2], "bn dbeta (A only)", tol=3e-3)
     assert sums.shape == (4, C)
+    # parameter gradients from stream B instead
+    for v in g.grads.values():
+        v.zero_()
+    bn.backward2(x16, dy2, sv, relu=True, param_scale=2.0, param_stream=1)
+    _close(g.grads["bn.weight"].cpu() * 2.0, ref[1][1], "bn dgamma (B only)", tol=3e-3)
+    _close(g.grads["bn.bias"].cpu() * 2.0, ref[1][2], "bn dbeta (B only)", tol=3e-3)
 
 
 def test_batchnorm_permuted_features():

@@ -519,10 +519,10 @@ int fmri_bn_bwd_reduce(const void* x, const void* dy, int M, int C, const float*
 }
 int fmri_bn_bwd_reduce2(const void* x, const void* dy2, int M, int C, const float* mean, const float* rstd,
                         const float* gamma, const float* beta, int relu, float* sums4C, float* ws, int64_t ws_floats,
-                        float* dbeta, float* dgamma, float gscale, void* stream) {
-    if (!x || !dy2 || !sums4C || (C & 7) || M < 1) return FMRI_E_BADARG;
+                        float* dbeta, float* dgamma, float gscale, int param_stream, void* stream) {
+    if (!x || !dy2 || !sums4C || (C & 7) || M < 1 || (param_stream & ~1)) return FMRI_E_BADARG;
     return bn_bwd_reduce2_launch((const half_t*)x, (const half_t*)dy2, M, C, mean, rstd, gamma, beta, relu, sums4C, ws,
-                                 ws_floats, dbeta, dgamma, gscale, S(stream));
+                                 ws_floats, dbeta, dgamma, gscale, param_stream, S(stream));
 }
 int fmri_bn_bwd_apply2(const void* x, const void* dy2, void* dx2, int M, int C, float count, const float* mean,
                        const float* rstd, const float* gamma, const float* beta, int relu, const float* sums4C,

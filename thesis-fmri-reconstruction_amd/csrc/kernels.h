@@ -58,7 +58,7 @@ int64_t bn_ws_floats(int M, int C);
 int bn_stats_launch(const half_t* x, int M, int C, float* sums, float* ws, int64_t ws_floats, hipStream_t st);
 int bn_bwd_reduce2_launch(const half_t* x, const half_t* dy, int M, int C, const float* mean, const float* rstd,
                           const float* gamma, const float* beta, int relu, float* sums4C, float* ws, int64_t ws_floats,
-                          float* dbeta, float* dgamma, float gscale, hipStream_t st);
+                          float* dbeta, float* dgamma, float gscale, int param_stream, hipStream_t st);
 int bn_bwd_apply2_launch(const half_t* x, const half_t* dy, half_t* dx, int M, int C, float count, const float* mean,
                          const float* rstd, const float* gamma, const float* beta, int relu, const float* sums4C,
                          hipStream_t st);

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const half_t* __restrict
 // g1 += gscale * sums[C..2C) = d gamma) -- one writer per element, no atomics.
 __global__ __launch_bounds__(1024) void fold_partials_kernel(const float* __restrict__ part, int nparts, int n,
                                                              float* __restrict__ sums, float* __restrict__ g0,
-                                                             float* __restrict__ g1, float gscale, int gC) {
+                                                             float* __restrict__ g1, float gscale, int gC, int gOff) {
     // 32 columns x 32 row lanes per block: the kernel is a chain of memory latencies (few blocks, tiny data), so the
     // partial rows are spread over as many lanes as a block has and each lane keeps four loads in flight
     __shared__ float red[32][33];
@@ -160,9 +160,10 @@ __global__ __launch_bounds__(1024) void fold_partials_kernel(const float* __rest
 #pragma unroll
         for (int r = 0; r < 32; ++r) s += red[r][cx];
         sums[i] = s;
-        const int C = gC > 0 ? gC : (n >> 1);   // columns [0, C) -> g0, [C, 2C) -> g1 (first cotangent stream only)
-        if (g0 && i < C) g0[i] += gscale * s;
-        if (g1 && i >= C && i < 2 * C) g1[i - C] += gscale * s;
+        // columns [gOff, gOff + C) -> g0, [gOff + C, gOff + 2C) -> g1 (one cotangent stream's sums)
+        const int C = gC > 0 ? gC : (n >> 1);
+        if (g0 && i >= gOff && i < gOff + C) g0[i - gOff] += gscale * s;
+        if (g1 && i >= gOff + C && i < gOff + 2 * C) g1[i - gOff - C] += gscale * s;
     }
 }
 
@@ -475,7 +476,7 @@ static int reduce_launch(const half_t* x, const half_t* dy, half_t* dout, int M,
     if (sums) {
         const int n = 2 * C;
         hipLaunchKernelGGL(fold_partials_kernel, dim3((n + 31) / 32), dim3(1024), 0, st, ws, g.gy, n, sums, g0, g1,
-                           gscale, 0);
+                           gscale, 0, 0);
     }
     return LAUNCH_OK();
 }
@@ -510,14 +511,14 @@ int act_bwd_launch(const half_t* y, const half_t* dy, half_t* dpre, int M, int C
 }
 int bn_bwd_reduce2_launch(const half_t* x, const half_t* dy, int M, int C, const float* mean, const float* rstd,
                           const float* gamma, const float* beta, int relu, float* sums4C, float* ws, int64_t ws_floats,
-                          float* dbeta, float* dgamma, float gscale, hipStream_t st) {
+                          float* dbeta, float* dgamma, float gscale, int param_stream, hipStream_t st) {
     if (!ws || ws_floats < 4 * (int64_t)C) return E_WORKSPACE;
     const RowGeom g = row_geometry(M, C, (int)(ws_floats / (4 * (int64_t)C)));
     hipLaunchKernelGGL(bn_reduce2_kernel, dim3(g.gx, g.gy), dim3(256), 0, st, x, dy, M, C, g.cx_log2, mean, rstd, gamma,
                        beta, relu, ws);
     const int n = 4 * C;
     hipLaunchKernelGGL(fold_partials_kernel, dim3((n + 31) / 32), dim3(1024), 0, st, ws, g.gy, n, sums4C, dbeta, dgamma,
-                       gscale, C);
+                       gscale, C, param_stream ? 2 * C : 0);
     return LAUNCH_OK();
 }
 int bn_finalize_launch(const float* sums, int C, float count, const float* gamma, const float* beta, float eps,

@@ -268,6 +268,26 @@ class DecoderNet:
         B = ctx["B"]
         E = len(entries)
         rows = lambda t, i: t[i * B:(i + 1) * B]
+        # weight-gradient runs: consecutive training blocks with the same scale through consecutive forward groups are
+        # one launch over all their rows (2 x 256 images as one 512-image launch: 638 vs 806 us for the decoder's four
+        # conv layers, tools/probes/wgrad_n512.py)
+        runs, e = [], 0
+        while e < E:
+            if not entries[e]["train"]:
+                e += 1
+                continue
+            f = e
+            while (f + 1 < E and entries[f + 1]["train"] and entries[f + 1]["scale"] == entries[e]["scale"]
+                   and entries[f + 1]["g"] == entries[f]["g"] + 1):
+                f += 1
+            runs.append((e, f))
+            e = f + 1
+
+        def wgrads(layer, x_all, d_all):
+            for e0, e1 in runs:
+                g0 = entries[e0]["g"]
+                layer.wgrad(x_all[g0 * B:(g0 + e1 - e0 + 1) * B], d_all[e0 * B:(e1 + 1) * B], entries[e0]["scale"])
+
         y = ctx["y"]
         dpre = torch.empty_like(cot)
         for e, en in enumerate(entries):
@@ -277,7 +297,7 @@ class DecoderNet:
             act_backward(rows(y, en["g"]), rows(cot, e), ACT_TANH, colsum, out=rows(dpre, e))
             if en["train"]:
                 self.c3.bg.add_(colsum[:self.c3.cout], alpha=1.0 / en["scale"])
-                self.c3.wgrad(rows(ctx["acts"][3], en["g"]), rows(dpre, e), en["scale"])
+        wgrads(self.c3, ctx["acts"][3], dpre)
         _, hi, wi, _ = ctx["acts"][3].shape
         d = self.c3.dgrad(dpre, hi, wi)
         for i in (2, 1, 0):
@@ -286,18 +306,20 @@ class DecoderNet:
             while e < E:
                 en = entries[e]
                 nx = entries[e + 1] if e + 1 < E else None
-                if nx is not None and nx["g"] == en["g"] and not nx["train"]:
-                    # two adjacent blocks through the same forward activations: one pass over them for both
+                if nx is not None and nx["g"] == en["g"] and not (nx["train"] and en["train"]):
+                    # two adjacent blocks through the same forward activations: one pass over them for both; the
+                    # gamma / beta gradients come from whichever of the two trains
+                    ps = 1 if nx["train"] else 0
+                    tr = nx if nx["train"] else en
                     self.bns[i].backward2(rows(ctx["raws"][i], en["g"]), d[e * B:(e + 2) * B], ctx["svs"][i][en["g"]],
-                                          True, en["scale"] if en["train"] else None, out=draw[e * B:(e + 2) * B])
-                    step = 2
+                                          True, tr["scale"] if tr["train"] else None, out=draw[e * B:(e + 2) * B],
+                                          param_stream=ps)
+                    e += 2
                 else:
                     self.bns[i].backward(rows(ctx["raws"][i], en["g"]), rows(d, e), ctx["svs"][i][en["g"]], True,
                                          en["scale"] if en["train"] else None, out=rows(draw, e))
-                    step = 1
-                if en["train"]:
-                    self.deconvs[i].wgrad(rows(ctx["acts"][i], en["g"]), rows(draw, e), en["scale"])
-                e += step
+                    e += 1
+            wgrads(self.deconvs[i], ctx["acts"][i], draw)
             _, hi, wi, _ = ctx["acts"][i].shape
             d = self.deconvs[i].dgrad(draw, hi, wi)
         dflat = d.reshape(E * B, -1)
@@ -306,8 +328,8 @@ class DecoderNet:
         for e, en in enumerate(entries):
             self.fc_bn.backward(rows(ctx["raw_fc"], en["g"]), rows(dflat, e), ctx["sv_fc"][en["g"]], True,
                                 en["scale"] if en["train"] else None, out=rows(draw_fc, e))
-            if en["train"]:
-                self.fc.wgrad(rows(ctx["z"], en["g"]), rows(draw_fc, e), en["scale"])
+        wgrads(self.fc, ctx["z"], draw_fc)
+        for e, en in enumerate(entries):
             if en.get("need_dz"):
                 _, dz32 = self.fc.dgrad(rows(draw_fc, e).contiguous(), want32=True)
                 out[e] = dz32 * (1.0 / en["scale"])

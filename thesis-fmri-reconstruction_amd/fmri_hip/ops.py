@@ -649,10 +649,11 @@ class BatchNorm:
         return out, sums
 
     def backward2(self, raw: torch.Tensor, dy2: torch.Tensor, sv: BNSaved, relu: bool = True,
-                  param_scale: Optional[float] = None, out: Optional[torch.Tensor] = None):
+                  param_scale: Optional[float] = None, out: Optional[torch.Tensor] = None, param_stream: int = 0):
         """``backward`` for TWO cotangent streams stacked along the rows, ``dy2 = [A rows | B rows]`` (each as many rows
         as ``raw``): the forward tensor, xhat and the ReLU mask are read / computed once for both.  gamma / beta
-        gradients (``param_scale``) are taken from stream A only.  Not for (C,H,W)-permuted BN1d."""
+        gradients (``param_scale``) are taken from ONE stream (``param_stream``: 0 = A, 1 = B).  Not for (C,H,W)-permuted
+        BN1d."""
         assert not self.perm
         C = self.C
         x2 = raw.reshape(-1, C)
@@ -665,7 +666,7 @@ class BatchNorm:
         pg = param_scale is not None
         lib.call("fmri_bn_bwd_reduce2", _P(x2), _P(g2), M, C, _P(sv.mean), _P(sv.rstd), _P(gamma), _P(beta),
                  1 if relu else 0, _P(sums), _P(ws), ws.numel(), _P(self.gbeta) if pg else None,
-                 _P(self.ggamma) if pg else None, (1.0 / param_scale) if pg else 0.0)
+                 _P(self.ggamma) if pg else None, (1.0 / param_scale) if pg else 0.0, int(param_stream))
         if self.reducer is not None:
             self.reducer(sums)
         if out is None:

@@ -398,16 +398,15 @@ class Stage1Step(_GanStepBase):
         # decoder cotangent, stored = dec * nA * (lambda*B_true - (1-lambda)*A_true)
         cot = torch.empty(3 * B, H, W, 8, dtype=torch.float16, device=dev)
         lam = hp.lambda_mse
-        # block order [x_tilde: decoder loss | x_tilde: feature loss (encoder path) | x_p: decoder loss]: the two blocks
+        # block order [x_tilde: feature loss (encoder path) | x_tilde: decoder loss | x_p: decoder loss]: the two blocks
         # that go through the SAME forward activations (group 0) are adjacent, so the decoder's BatchNorm backward takes
-        # them in one pass (BatchNorm.backward2)
-        ka, kb = sc.dec * lam / sc.b, -sc.dec * (1.0 - lam) / sc.a
-        axpby(dimg_b[:B], dimg_a[:B], ka, kb, out=cot[:B], a_dev=self._slot(S_RATIO))
-        cot[B:2 * B].copy_(dimg_b[:B])
-        axpby(dimg_b[B:], dimg_a[B:], ka, kb, out=cot[2 * B:], a_dev=self._slot(S_RATIO))
-        entries = [dict(g=0, scale=sc.dec, train=True), dict(g=0, scale=sc.b, train=False, need_dz=True),
+        # them in one pass (BatchNorm.backward2), and the two training blocks are adjacent, so every decoder weight
+        # gradient is one launch over 2B rows
+        cot[:B].copy_(dimg_b[:B])
+        axpby(dimg_b, dimg_a, sc.dec * lam / sc.b, -sc.dec * (1.0 - lam) / sc.a, out=cot[B:], a_dev=self._slot(S_RATIO))
+        entries = [dict(g=0, scale=sc.b, train=False, need_dz=True), dict(g=0, scale=sc.dec, train=True),
                    dict(g=1, scale=sc.dec, train=True)]
-        dz = self.dec.backward(fw["dctx"], cot, entries, join=dp)[1]  # = nB * dz_true
+        dz = self.dec.backward(fw["dctx"], cot, entries, join=dp)[0]  # = nB * dz_true
         self.dd.all_reduce_async(self.dec.group.grad)
         if early:
             ops.side_run(dev, lambda: self._apply_one(self.opt_dec, self.dec, self.flags[1:2], S_NA))

@@ -325,9 +325,21 @@ class DecoderNet:
         dflat = d.reshape(E * B, -1)
         draw_fc = torch.empty_like(dflat)
         out = {}
-        for e, en in enumerate(entries):
-            self.fc_bn.backward(rows(ctx["raw_fc"], en["g"]), rows(dflat, e), ctx["sv_fc"][en["g"]], True,
-                                en["scale"] if en["train"] else None, out=rows(draw_fc, e))
+        e = 0
+        while e < E:
+            en = entries[e]
+            nx = entries[e + 1] if e + 1 < E else None
+            if nx is not None and nx["g"] == en["g"] and not (nx["train"] and en["train"]):
+                ps = 1 if nx["train"] else 0
+                tr = nx if nx["train"] else en
+                self.fc_bn.backward2(rows(ctx["raw_fc"], en["g"]), dflat[e * B:(e + 2) * B], ctx["sv_fc"][en["g"]], True,
+                                     tr["scale"] if tr["train"] else None, out=draw_fc[e * B:(e + 2) * B],
+                                     param_stream=ps)
+                e += 2
+            else:
+                self.fc_bn.backward(rows(ctx["raw_fc"], en["g"]), rows(dflat, e), ctx["sv_fc"][en["g"]], True,
+                                    en["scale"] if en["train"] else None, out=rows(draw_fc, e))
+                e += 1
         wgrads(self.fc, ctx["z"], draw_fc)
         for e, en in enumerate(entries):
             if en.get("need_dz"):

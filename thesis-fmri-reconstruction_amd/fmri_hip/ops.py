@@ -652,9 +652,7 @@ class BatchNorm:
                   param_scale: Optional[float] = None, out: Optional[torch.Tensor] = None, param_stream: int = 0):
         """``backward`` for TWO cotangent streams stacked along the rows, ``dy2 = [A rows | B rows]`` (each as many rows
         as ``raw``): the forward tensor, xhat and the ReLU mask are read / computed once for both.  gamma / beta
-        gradients (``param_scale``) are taken from ONE stream (``param_stream``: 0 = A, 1 = B).  Not for (C,H,W)-permuted
-        BN1d."""
-        assert not self.perm
+        gradients (``param_scale``) are taken from ONE stream (``param_stream``: 0 = A, 1 = B)."""
         C = self.C
         x2 = raw.reshape(-1, C)
         g2 = dy2.reshape(-1, C)
@@ -663,10 +661,12 @@ class BatchNorm:
         gamma, beta, _, _ = self._params()
         sums = torch.empty(4, C, dtype=torch.float32, device=raw.device)
         ws = torch.empty(2 * lib.load().fmri_bn_ws_floats(M, C), dtype=torch.float32, device=raw.device)
-        pg = param_scale is not None
+        pg = param_scale is not None and not self.perm     # (C,H,W)-permuted BN1d: scattered below
         lib.call("fmri_bn_bwd_reduce2", _P(x2), _P(g2), M, C, _P(sv.mean), _P(sv.rstd), _P(gamma), _P(beta),
                  1 if relu else 0, _P(sums), _P(ws), ws.numel(), _P(self.gbeta) if pg else None,
                  _P(self.ggamma) if pg else None, (1.0 / param_scale) if pg else 0.0, int(param_stream))
+        if param_scale is not None and self.perm:
+            self.accumulate_param_grads(sums[2 * int(param_stream):2 * int(param_stream) + 2], param_scale)
         if self.reducer is not None:
             self.reducer(sums)
         if out is None:

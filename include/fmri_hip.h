@@ -72,6 +72,23 @@ int fmri_unpack_grad(const float* src, float* dst, int64_t sa, int64_t sta, int6
 int fmri_igemm(const void* in, const void* w, void* out, const float* bias, const void* zero16, int N, int Hi, int Wi,
                int Ci, int Ho, int Wo, int CoStore, int Co, int k, int stride, int pad, int mode, int act,
                int out_f32, int splits, int64_t slab_stride, int bn_tile, void* stream);
+/* The same contraction with an epilogue that a following BatchNorm needs (models/vae_gan.py:26-34,57-59: conv -> bn):
+ * every block writes, per output channel, sum x and sum x^2 of the values it STORED (valid output pixels only) to its
+ * own row of stat_part[group][stat_rows_cap][2][CoStore] (plain stores, deterministic), group = image / stat_group_n
+ * (stat_group_n = 0: one group; a row tile never mixes groups).  *ep_done = rows written per group (they are the
+ * first rows of each group; fold them with fmri_bn_fold_finalize), or 0 when the kernel behind this geometry has no
+ * such epilogue, a tile would straddle two groups or stat_rows_cap is too small -- then use fmri_bn_stats on the
+ * output.  N*Ho*Wo/128 + 8 rows per group always suffice.  w_elems: elements of the packed weight buffer `w` (the
+ * descriptor-addressed kernels bound their weight DMA with it; 0 = unknown, those kernels are skipped). */
+typedef struct fmri_epilogue {
+    float* stat_part;        /* NULL: no statistics */
+    int32_t stat_rows_cap;   /* rows allocated per group */
+    int32_t stat_group_n;    /* images per statistics group, 0 = all images */
+} fmri_epilogue;
+int fmri_igemm_ep(const void* in, const void* w, void* out, const float* bias, const void* zero16, int N, int Hi,
+                  int Wi, int Ci, int Ho, int Wo, int CoStore, int Co, int k, int stride, int pad, int mode, int act,
+                  int out_f32, int splits, int64_t slab_stride, int bn_tile, int64_t w_elems, const fmri_epilogue* ep,
+                  int* ep_done, void* stream);
 /* dW[a][tap*Bc+b] (+)= sum_m P[m][a] * Q[gather(m,tap)][b]; see csrc/wgrad.hip.  Replaces the weight
  * gradients autograd computes for the same modules (train/train_vgan_stage1.py:412,422,430). */
 int fmri_wgrad(const void* P, const void* Q, float* out, const void* zero16, int N, int Yc, int Xc, int A, int Hq,
@@ -131,6 +148,15 @@ int fmri_bn_stats_finalize(const void* x, int M, int C, float* sums2C, float* ws
                            const float* gamma, const float* beta, float eps, float momentum, int updates,
                            float* running_mean, float* running_var, float* mean, float* rstd, float* scale,
                            float* shift, int64_t* num_batches_tracked, void* stream);
+/* The statistics rows a contraction's epilogue wrote (fmri_igemm_ep: stat_part [rows][2][C] of ONE group) folded into
+ * sums2C and finalized like fmri_bn_finalize; scratch: fmri_bn_fold_scratch_floats(C) floats (two-stage fold of long
+ * row lists).  fmri_bn_fold only folds (data-parallel runs all-reduce sums2C before fmri_bn_finalize). */
+int fmri_bn_fold_finalize(const float* stat_part, int rows, int C, float* scratch, float* sums2C, float count,
+                          const float* gamma, const float* beta, float eps, float momentum, int updates,
+                          float* running_mean, float* running_var, float* mean, float* rstd, float* scale, float* shift,
+                          int64_t* num_batches_tracked, void* stream);
+int fmri_bn_fold(const float* stat_part, int rows, int C, float* scratch, float* sums2C, void* stream);
+int fmri_bn_fold_scratch_floats(int C);
 int fmri_bn_apply(const void* x, void* y, int M, int C, const float* scale, const float* shift, int relu,
                   void* stream);
 int fmri_bn_bwd_reduce(const void* x, const void* dy, int M, int C, const float* mean, const float* rstd,

@@ -200,6 +200,28 @@ def synth_batch(batch: int, cfg: ArchCfg, n_voxels: int = 0, seed: int = 1234, s
 
 
 # ----------------------------------------------------------------------------------------------
+# 16-bit storage model (tests only)
+# ----------------------------------------------------------------------------------------------
+# STORAGE16 = True makes the forward passes below round every tensor the HIP engine STORES in fp16 -- images, GEMM
+# weights, conv / linear outputs, BatchNorm+ReLU outputs, latent codes, generated images -- at the point where the
+# engine stores it, with a straight-through gradient (the arithmetic stays fp32, like the engine's fp32 accumulators).
+# The ReLU masks of such a run are the engine's masks, so its gradients can be compared tightly; the default (False)
+# is the plain fp32 restatement that the golden vectors pin.
+STORAGE16 = False
+
+
+def _q(t: Tensor) -> Tensor:
+    if not STORAGE16:
+        return t
+    return t + (t.detach().half().float() - t.detach())
+
+
+def _w(P: State, key: str) -> Tensor:
+    """GEMM weight as the engine multiplies it (fp16 copy of the fp32 master under STORAGE16)."""
+    return _q(P[key])
+
+
+# ----------------------------------------------------------------------------------------------
 # sub-network forwards
 # ----------------------------------------------------------------------------------------------
 def _bn(P: State, pre: str, x: Tensor, train: bool) -> Tensor:
@@ -213,61 +235,61 @@ def _bn(P: State, pre: str, x: Tensor, train: bool) -> Tensor:
 
 def encoder_fwd(P: State, pre: str, x: Tensor, cfg: ArchCfg, train: bool = True):
     """Encoder.forward, models/vae_gan.py:87-93."""
-    h = x
+    h = _q(x)
     for i in range(3):
-        h = F.conv2d(h, P[f"{pre}conv.{i}.conv.weight"], None, cfg.stride, cfg.padding)
-        h = F.relu(_bn(P, f"{pre}conv.{i}.bn.", h, train))
+        h = _q(F.conv2d(h, _w(P, f"{pre}conv.{i}.conv.weight"), None, cfg.stride, cfg.padding))
+        h = _q(F.relu(_bn(P, f"{pre}conv.{i}.bn.", h, train)))
     h = h.reshape(h.shape[0], -1)
-    h = F.relu(_bn(P, f"{pre}fc.1.", F.linear(h, P[f"{pre}fc.0.weight"]), train))
-    mu = F.linear(h, P[f"{pre}l_mu.weight"], P[f"{pre}l_mu.bias"])
-    logvar = F.linear(h, P[f"{pre}l_var.weight"], P[f"{pre}l_var.bias"])
+    h = _q(F.relu(_bn(P, f"{pre}fc.1.", _q(F.linear(h, _w(P, f"{pre}fc.0.weight"))), train)))
+    mu = F.linear(h, _w(P, f"{pre}l_mu.weight"), P[f"{pre}l_mu.bias"])
+    logvar = F.linear(h, _w(P, f"{pre}l_var.weight"), P[f"{pre}l_var.bias"])
     return mu, logvar
 
 
 def decoder_fwd(P: State, pre: str, z: Tensor, cfg: ArchCfg, train: bool = True):
     """Decoder.forward, models/vae_gan.py:125-129."""
-    h = F.relu(_bn(P, f"{pre}fc.1.", F.linear(z, P[f"{pre}fc.0.weight"]), train))
+    h = _q(F.relu(_bn(P, f"{pre}fc.1.", _q(F.linear(_q(z), _w(P, f"{pre}fc.0.weight"))), train)))
     h = h.reshape(h.shape[0], -1, cfg.fc_input, cfg.fc_input)
     for i in range(3):
-        h = F.conv_transpose2d(h, P[f"{pre}conv.{i}.conv.weight"], None, cfg.stride, cfg.padding,
-                               output_padding=1 if cfg.output_pad_dec[i] else 0)
-        h = F.relu(_bn(P, f"{pre}conv.{i}.bn.", h, train))
-    h = F.conv2d(h, P[f"{pre}conv.3.0.weight"], P[f"{pre}conv.3.0.bias"], 1, 2)
-    return torch.tanh(h)
+        h = _q(F.conv_transpose2d(h, _w(P, f"{pre}conv.{i}.conv.weight"), None, cfg.stride, cfg.padding,
+                                  output_padding=1 if cfg.output_pad_dec[i] else 0))
+        h = _q(F.relu(_bn(P, f"{pre}conv.{i}.bn.", h, train)))
+    h = F.conv2d(h, _w(P, f"{pre}conv.3.0.weight"), P[f"{pre}conv.3.0.bias"], 1, 2)
+    return _q(torch.tanh(h))
 
 
 def discriminator_fwd(P: State, pre: str, x_orig: Tensor, x_pred: Tensor, x_samp: Tensor, mode: str,
                       cfg: ArchCfg, train: bool = True, recon_level: int = 3):
     """Discriminator.forward, models/vae_gan.py:163-183 (mode 'REC' or 'GAN')."""
-    h = torch.cat((x_orig, x_pred, x_samp), 0)
-    h = F.relu(F.conv2d(h, P[f"{pre}conv.0.0.weight"], P[f"{pre}conv.0.0.bias"], cfg.stride_gan, 2))
+    h = _q(torch.cat((x_orig, x_pred, x_samp), 0))
+    h = _q(F.relu(F.conv2d(h, _w(P, f"{pre}conv.0.0.weight"), P[f"{pre}conv.0.0.bias"], cfg.stride_gan, 2)))
     for i in (1, 2, 3):
-        raw = F.conv2d(h, P[f"{pre}conv.{i}.conv.weight"], None, cfg.stride, cfg.padding)
+        raw = _q(F.conv2d(h, _w(P, f"{pre}conv.{i}.conv.weight"), None, cfg.stride, cfg.padding))
         if mode == "REC" and i == recon_level:
             # reference still runs bn+relu on this block before returning (vae_gan.py:25-30)
             _bn(P, f"{pre}conv.{i}.bn.", raw, train)
             return raw.reshape(raw.shape[0], -1)
-        h = F.relu(_bn(P, f"{pre}conv.{i}.bn.", raw, train))
+        h = _q(F.relu(_bn(P, f"{pre}conv.{i}.bn.", raw, train)))
     h = h.reshape(h.shape[0], -1)
-    h = F.relu(_bn(P, f"{pre}fc.1.", F.linear(h, P[f"{pre}fc.0.weight"]), train))
-    h = F.linear(h, P[f"{pre}fc.3.weight"], P[f"{pre}fc.3.bias"])
+    h = _q(F.relu(_bn(P, f"{pre}fc.1.", _q(F.linear(h, _w(P, f"{pre}fc.0.weight"))), train)))
+    h = F.linear(h, _w(P, f"{pre}fc.3.weight"), P[f"{pre}fc.3.bias"])
     return torch.sigmoid(h)
 
 
 def cognitive_encoder_fwd(P: State, pre: str, fmri: Tensor, train: bool = True):
     """CognitiveEncoder.forward, models/vae_gan.py:224-229."""
-    h = F.relu(_bn(P, f"{pre}fc1.1.", F.linear(fmri, P[f"{pre}fc1.0.weight"]), train))
-    mu = F.linear(h, P[f"{pre}l_mu.weight"], P[f"{pre}l_mu.bias"])
-    logvar = F.linear(h, P[f"{pre}l_var.weight"], P[f"{pre}l_var.bias"])
+    h = _q(F.relu(_bn(P, f"{pre}fc1.1.", _q(F.linear(_q(fmri), _w(P, f"{pre}fc1.0.weight"))), train)))
+    mu = F.linear(h, _w(P, f"{pre}l_mu.weight"), P[f"{pre}l_mu.bias"])
+    logvar = F.linear(h, _w(P, f"{pre}l_var.weight"), P[f"{pre}l_var.bias"])
     return mu, logvar
 
 
 def wae_discriminator_fwd(P: State, pre: str, z: Tensor):
     """WaeDiscriminator.forward, models/vae_gan.py:527-529."""
-    h = z
+    h = _q(z)
     for idx in (0, 2, 4, 6):
-        h = F.relu(F.linear(h, P[f"{pre}main.{idx}.weight"], P[f"{pre}main.{idx}.bias"]))
-    return torch.sigmoid(F.linear(h, P[f"{pre}main.8.weight"], P[f"{pre}main.8.bias"]))
+        h = _q(F.relu(F.linear(h, _w(P, f"{pre}main.{idx}.weight"), P[f"{pre}main.{idx}.bias"])))
+    return torch.sigmoid(F.linear(h, _w(P, f"{pre}main.8.weight"), P[f"{pre}main.8.bias"]))
 
 
 def reparameterize(mu: Tensor, logvar: Tensor, eps: Tensor) -> Tensor:
@@ -404,7 +426,7 @@ def equilibrium_gate(bce_o_mean: float, bce_p_mean: float, hp: GanHyper):
 
 def _compose_losses(fw, x_real, B, hp: GanHyper):
     dl, dc = fw["disc_layer"], fw["disc_class"]
-    nle, kl, mse, bo, bp, bs = vaegan_loss(x_real, fw["x_tilde"], dl[:B], dl[B:-B], dl[-B:], dc[:B], dc[B:-B],
+    nle, kl, mse, bo, bp, bs = vaegan_loss(_q(x_real), fw["x_tilde"], dl[:B], dl[B:-B], dl[-B:], dc[:B], dc[B:-B],
                                            dc[-B:], fw["mus"], fw["log_variances"])
     loss_enc = torch.sum(kl) + torch.sum(mse)                                   # stage1.py:369
     loss_dis = torch.sum(bo) + torch.sum(bp) + torch.sum(bs)                   # :370-371

@@ -159,6 +159,60 @@ def test_deconv_forward_dgrad_wgrad(cin, cout, H, op, N):
     _close(g.grads["w"].cpu(), wr.grad, "deconv wgrad", tol=3e-3)
 
 
+EPI_STAT_CASES = [
+    # kind, cin, cout, stride, H, out_pad, N, groups, expect the epilogue
+    ("conv", 64, 128, 2, 16, 0, 4, 1, True),        # igemm 128 x 128, Ci % 64 == 0
+    ("conv", 32, 128, 2, 32, 0, 8, 1, True),        # K-steps straddle taps
+    ("conv", 3, 64, 2, 16, 0, 4, 1, True),          # 2 K-steps, 64-channel tile
+    ("conv", 128, 256, 2, 32, 0, 200, 1, True),     # 256 x 256 tile (8 waves)
+    ("deconv", 256, 128, 2, 16, 1, 4, 2, True),     # igemm_tc5, double-buffered window, two BatchNorm batches
+    ("deconv", 256, 256, 2, 8, 1, 4, 2, True),      # igemm_tc5, two images per tile
+    ("deconv", 256, 256, 2, 8, 1, 6, 2, False),     # a tile would hold images of two batches: no epilogue
+    ("deconv", 256, 256, 2, 13, 0, 3, 1, True),     # partial tiles, output_padding = 0
+    ("deconv", 128, 64, 2, 25, 1, 2, 2, True),      # 64-channel tile
+]
+
+
+@pytest.mark.parametrize("kind,cin,cout,stride,H,op,N,groups,expect", EPI_STAT_CASES)
+def test_conv_epilogue_batchnorm_statistics(kind, cin, cout, stride, H, op, N, groups, expect):
+    """fmri_igemm_ep: the per-block rows of sum x / sum x^2 the contraction's epilogue writes fold to the statistics of
+    the stored output, per BatchNorm batch, and BatchNorm.forward gives the same result from them as from its own pass."""
+    from fmri_hip.ops import ConvLayer, BatchNorm
+    torch.manual_seed(cin + cout + H + N)
+    shape = (cout, cin, 5, 5) if kind == "conv" else (cin, cout, 5, 5)
+    g = _G({"w": _h(torch.randn(*shape) * 0.05), "bn.weight": torch.rand(cout) + 0.5, "bn.bias": torch.randn(cout) * 0.1})
+    g.bufs = {"bn.running_mean": torch.zeros(cout, device=DEV), "bn.running_var": torch.ones(cout, device=DEV),
+              "bn.num_batches_tracked": torch.zeros((), dtype=torch.int64, device=DEV)}
+    layer = ConvLayer(g, "w", None, kind, cin, cout, 5, stride if kind == "conv" else 2, 2, op)
+    x16 = torch.randn(N, H, H, layer.cinp, device=DEV).half()
+    if layer.cinp != cin:
+        x16[..., cin:] = 0
+    y16 = layer.forward(x16, bn_groups=groups)
+    B = N // groups
+    assert (layer.take_stats(0) is not None) == expect
+    if not expect:
+        return
+    bn = BatchNorm(g, "bn.", layer.coutp) if layer.coutp == cout else None
+    for gi in range(groups):
+        part = layer.take_stats(gi)
+        yg = y16[gi * B:(gi + 1) * B].float().reshape(-1, layer.coutp)
+        got = part.double().sum(0).cpu()
+        ref = torch.stack([yg.double().sum(0), (yg.double() ** 2).sum(0)]).cpu()
+        scale = (yg.double() ** 2).sum(0).sqrt().cpu().clamp_min(1e-6)
+        assert ((got[0] - ref[0]).abs() <= 2e-5 * scale * np.sqrt(yg.shape[0])).all(), "sum x"
+        assert ((got[1] - ref[1]).abs() <= 2e-5 * ref[1].abs() + 1e-6).all(), "sum x^2"
+        if bn is not None:
+            a, sva = bn.forward(y16[gi * B:(gi + 1) * B], True, 0, stat_acc=part)
+            b, svb = bn.forward(y16[gi * B:(gi + 1) * B], True, 0)
+            assert torch.allclose(sva.mean, svb.mean, rtol=1e-5, atol=1e-6)
+            assert torch.allclose(sva.rstd, svb.rstd, rtol=1e-5, atol=1e-6)
+            assert ((a.float() - b.float()).abs() <= 2e-3 * b.float().abs().clamp_min(1.0)).all()   # <= 1 fp16 ulp
+    # deterministic: a second run writes bit-identical rows
+    first = layer._stat_part[:groups, :layer._stat_rows].clone()
+    layer.forward(x16, bn_groups=groups)
+    assert torch.equal(first, layer._stat_part[:groups, :layer._stat_rows])
+
+
 def test_conv_bias_relu_tanh_epilogues():
     from fmri_hip.ops import ConvLayer, ACT_RELU, ACT_TANH
     torch.manual_seed(5)

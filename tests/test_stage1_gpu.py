@@ -11,6 +11,8 @@ import numpy as np
 import pytest
 import torch
 
+import gradcheck
+
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 LOSS_RTOL = 1e-3
@@ -72,7 +74,7 @@ def test_stage1_step_matches_oracle(arch, B, seed, perturb):
     P = O.fill_state(O.vaegan_spec(cfg_o), seed, perturb)
     opts = {n: O.OptState(kind="rmsprop", lr=1e-4) for n in ("encoder", "decoder", "discriminator")}
     report = []
-    fw_fail, grad_worst = False, 0.0
+    fw_fail = False
     for s in range(steps):
         ref = O.stage1_step(P, opts, data["x"], data["noise"][s, 0], data["noise"][s, 1], cfg_o, keep_grads=True)
         e = eng[s]
@@ -86,21 +88,17 @@ def test_stage1_step_matches_oracle(arch, B, seed, perturb):
             report.append((s, "fw:" + k, err, 0, err))
             fw_fail = fw_fail or (s == 0 and err > FW_TOL)
         if s == 0:
-            worst = []
-            for k, g in ref["grads"].items():
-                if g is None:
-                    continue
-                err = _tensor_err(e["grads"][k], g)
-                worst.append((err, k))
-            worst.sort(reverse=True)
-            report.append((s, "grad worst", worst[:6], 0, worst[0][0]))
-            grad_worst = worst[0][0]
+            # gradients: tight against the oracle under its 16-bit storage model (same ReLU masks as the engine),
+            # direction / length against the plain fp32 oracle (tests/gradcheck.py)
+            P16 = O.fill_state(O.vaegan_spec(cfg_o), seed, perturb)
+            o16 = {n: O.OptState(kind="rmsprop", lr=1e-4) for n in ("encoder", "decoder", "discriminator")}
+            with gradcheck.storage16(O):
+                ref16 = O.stage1_step(P16, o16, data["x"], data["noise"][s, 0], data["noise"][s, 1], cfg_o,
+                                      keep_grads=True)
+            gradcheck.check(e["grads"], ref["grads"], ref16["grads"], f"stage1 {arch}")
     for row in report:
         print(row)
     assert not fw_fail, "forward tensors off"
-    # ReLU-mask flips caused by fp16 activations add ~3% (relative L2) of unbiased noise per ReLU layer to
-    # back-propagated gradients (measured: 2% at disc conv3 ... 11% at encoder conv0, projection 1.00+-0.02)
-    assert grad_worst < 0.25, grad_worst
     for s, k, got, want, r in report:
         if isinstance(k, str) and not k.startswith(("fw:", "grad")) and s == 0:
             assert r < LOSS_RTOL, (s, k, got, want, r)

@@ -6,6 +6,8 @@ import numpy as np
 import pytest
 import torch
 
+import gradcheck
+
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 LOSS_KEYS = ("loss_encoder", "loss_decoder", "loss_discriminator", "nle", "kl", "mse", "bce_orig", "bce_pred",
@@ -75,9 +77,11 @@ def test_cognitive_step_matches_oracle_and_golden(golden_dir, stage):
                 e = _terr(outs[k], ref["fw"][k])
                 print(stage, "fw", k, e)
                 assert e < 1e-2, (k, e)
-            worst = max(_terr(grads[k], v) for k, v in ref["grads"].items() if v is not None)
-            print(stage, "worst grad err", worst)
-            assert worst < 0.25
+            P16, _ = _oracle_state(O, cfg_o, V, seed, perturb, stage)
+            o16 = {n: O.OptState(kind="rmsprop", lr=1e-4) for n in ("encoder", "decoder", "discriminator")}
+            with gradcheck.storage16(O):
+                ref16 = ostep(P16, o16, data["fmri"], data["x"], nz, cfg_o, V, keep_grads=True)
+            gradcheck.check(grads, ref["grads"], ref16["grads"], f"stage{stage}")
     # BN running statistics / update counters follow the reference's call pattern (golden fingerprints)
     sd = {k: v.cpu() for k, v in st.state_dict().items()}
     keys = [str(k) for k in g["step1/state_keys"]]

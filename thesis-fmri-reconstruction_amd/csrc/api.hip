@@ -138,7 +138,24 @@ int fmri_unpack_grad(const float* src, float* dst, int64_t sa, int64_t sta, int6
 int fmri_igemm(const void* in, const void* w, void* out, const float* bias, const void* zero16, int N, int Hi, int Wi,
                int Ci, int Ho, int Wo, int CoStore, int Co, int k, int stride, int pad, int mode, int act,
                int out_f32, int splits, int64_t slab_stride, int bn_tile, void* stream) {
+    return fmri_igemm_ep(in, w, out, bias, zero16, N, Hi, Wi, Ci, Ho, Wo, CoStore, Co, k, stride, pad, mode, act, out_f32,
+                         splits, slab_stride, bn_tile, 0, nullptr, nullptr, stream);
+}
+
+int fmri_igemm_ep(const void* in, const void* w, void* out, const float* bias, const void* zero16, int N, int Hi,
+                  int Wi, int Ci, int Ho, int Wo, int CoStore, int Co, int k, int stride, int pad, int mode, int act,
+                  int out_f32, int splits, int64_t slab_stride, int bn_tile, int64_t w_elems, const fmri_epilogue* ep,
+                  int* ep_done, void* stream) {
+    if (ep_done) *ep_done = 0;
     if (!in || !w || !out || !zero16) return FMRI_E_BADARG;
+    StatEpi se;
+    se.part = nullptr; se.rows_cap = 0; se.C = CoStore; se.group_n = 0;
+    se.tpg[0] = se.tpg[1] = se.tpg[2] = se.tpg[3] = 0;
+    if (ep && ep->stat_part) {
+        if (ep->stat_rows_cap < 1 || ep->stat_group_n < 0 || out_f32 || (ep->stat_group_n > 0 && N % ep->stat_group_n))
+            return FMRI_E_BADARG;
+        se.part = ep->stat_part; se.rows_cap = ep->stat_rows_cap; se.group_n = ep->stat_group_n;
+    }
     if (N < 1 || Ci < 8 || (Ci & 7) || CoStore < 4 || (CoStore & 3) || Co < 1 || Co > CoStore) return FMRI_E_BADARG;
     if (bn_tile != 32 && bn_tile != 64 && bn_tile != 128) return FMRI_E_UNSUPPORTED;
     if (splits < 1) return FMRI_E_BADARG;
@@ -149,6 +166,7 @@ int fmri_igemm(const void* in, const void* w, void* out, const float* bias, cons
     a.in = (const half_t*)in; a.w = (const half_t*)w; a.out = out; a.bias = bias; a.zero = (const half_t*)zero16;
     a.N = N; a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.Ho = Ho; a.Wo = Wo; a.CoStore = CoStore; a.Co = Co;
     a.act = act; a.splits = splits; a.slab_stride = slab_stride;
+    a.st = se; a.st.part = nullptr;
     a.fdCi = make_fastdiv((uint32_t)Ci);
     a.fdCpt = make_fastdiv((uint32_t)(Ci >= 64 ? Ci / 64 : 1));
     int maxM = 0;
@@ -212,6 +230,58 @@ int fmri_igemm(const void* in, const void* w, void* out, const float* bias, cons
                 const int r = igemm_narrow_launch(q, Ci, co_tiles, mode == FMRI_CONV_FLIP, S(stream));
                 if (r != E_UNSUPPORTED) return r;
             }
+        }
+    }
+    // stride-2 transposed convolution k5 p2, Ci % 128 == 0, >= 64 output channels, no bias / activation: all four parity
+    // classes per block (csrc/igemm_tc5.hip); FMRI_TC5=off disables
+    static const char* tc5_env = getenv("FMRI_TC5");
+    static const bool no_tc5 = tc5_env && !strcmp(tc5_env, "off");
+    if (!no_tc5 && mode == FMRI_TCONV2 && k == 5 && pad == 2 && (Ci & 127) == 0 && bn_tile >= 64 && !out_f32 &&
+        splits == 1 && !bias && act == FMRI_ACT_NONE && w_elems > 0 && w_elems * 2 < 0xffffffffLL &&
+        (int64_t)N * Hi * Wi * Ci * 2 < 0x7fffffffLL) {
+        Tc5Args q;
+        q.in = a.in; q.w = a.w; q.out = (half_t*)out; q.bias = nullptr;
+        q.N = N; q.Hi = Hi; q.Wi = Wi; q.Ci = Ci; q.Ho = Ho; q.Wo = Wo; q.CoStore = CoStore; q.Co = Co;
+        q.act = act; q.nchunks = Ci / 64;
+        bool ok = true;
+        for (int i = 0; i < 4; ++i) {
+            const IgemmClass& s = a.cls[i];
+            const int th = s.T / s.TW;
+            if (th != ((i >> 1) ? 2 : 3) || s.TW != ((i & 1) ? 2 : 3) || s.dy0 != 1 || s.dx0 != 1 || s.dstep != -1 ||
+                s.oy0 != (i >> 1) || s.ox0 != (i & 1) || s.Kpad < s.T * Ci)
+                ok = false;
+            q.cls[i].Yc = s.Yc; q.cls[i].Xc = s.Xc; q.cls[i].Kpad = s.Kpad; q.cls[i].pad0 = 0; q.cls[i].w_off = s.w_off;
+            if ((s.w_off + (int64_t)copad * s.Kpad) > w_elems) ok = false;
+        }
+        const int Yc0 = a.cls[0].Yc, Xc0 = a.cls[0].Xc;          // class (0, 0) has the largest grid
+        q.pw_log2 = Xc0 > 8 ? 4 : 3;
+        q.ph_log2 = (q.pw_log2 == 3 && Yc0 > 8) ? 4 : 3;
+        q.PH = 1 << q.ph_log2;
+        q.IPB = 128 >> (q.pw_log2 + q.ph_log2);
+        q.IH = q.PH + 2;
+        q.IW = (1 << q.pw_log2) + 2;
+        q.tiles_x = (Xc0 + (1 << q.pw_log2) - 1) >> q.pw_log2;
+        q.tiles_y = (Yc0 + q.PH - 1) >> q.ph_log2;
+        q.ntiles = Yc0 > 0 && Xc0 > 0 ? ((N + q.IPB - 1) / q.IPB) * q.tiles_y * q.tiles_x : 0;
+        q.nslice = (q.IPB * q.IH * q.IW * 8 + 255) / 256;
+        q.in_bytes = (uint32_t)((int64_t)N * Hi * Wi * Ci * 2);
+        q.w_bytes = (uint32_t)(w_elems * 2);
+        q.fdTPI = make_fastdiv((uint32_t)(q.tiles_y * q.tiles_x));
+        q.fdTX = make_fastdiv((uint32_t)q.tiles_x);
+        q.fdIHW = make_fastdiv((uint32_t)(q.IH * q.IW));
+        q.fdIW = make_fastdiv((uint32_t)q.IW);
+        q.st = se;
+        // statistics: one row per tile; groups must not share a tile
+        const int tpi5 = q.tiles_y * q.tiles_x;
+        if (se.part) {
+            if (se.group_n > 0 && (se.group_n % q.IPB)) q.st.part = nullptr;
+            q.st.tpg[0] = se.group_n > 0 ? (se.group_n / q.IPB) * tpi5 : q.ntiles;
+            if (q.st.tpg[0] > se.rows_cap) q.st.part = nullptr;
+        }
+        if (ok && q.ntiles > 0) {
+            const int r = igemm_tc5_launch(q, bn_tile, copad, S(stream));
+            if (r == OK && ep_done && q.st.part) *ep_done = q.st.tpg[0];
+            if (r != E_UNSUPPORTED) return r;
         }
     }
     // stride-2 transposed convolution 128 -> <= 32 channels -> persistent register-resident-weight kernel
@@ -343,7 +413,24 @@ int fmri_igemm(const void* in, const void* w, void* out, const float* bias, cons
             if (r != E_UNSUPPORTED) return r;
         }
     }
-    return igemm_launch(a, maxM, bn_tile, copad, out_f32 != 0, S(stream));
+    // generic kernel: statistics epilogue (one row per row tile) when no tile straddles two statistics groups
+    a.st = se;
+    int prows = 0;
+    if (se.part && !out_f32) {
+        const int bm = igemm_bm(a, maxM, bn_tile, copad, false);
+        for (int i = 0; i < a.ncls; ++i) {
+            const int64_t mg = se.group_n > 0 ? (int64_t)se.group_n * a.cls[i].Yc * a.cls[i].Xc : a.cls[i].M;
+            if (se.group_n > 0 && (mg % bm)) a.st.part = nullptr;
+            a.st.tpg[i] = (int)((mg + bm - 1) / bm);
+            prows += a.st.tpg[i];
+        }
+        if (prows > se.rows_cap) a.st.part = nullptr;
+    } else {
+        a.st.part = nullptr;
+    }
+    const int r = igemm_launch(a, maxM, bn_tile, copad, out_f32 != 0, S(stream));
+    if (r == OK && ep_done && a.st.part) *ep_done = prows;
+    return r;
 }
 
 // number of per-split slabs fmri_wgrad(..., atomic = 2) writes for a budget of `splits` blocks per tile group
@@ -505,6 +592,21 @@ int fmri_bn_stats_finalize(const void* x, int M, int C, float* sums2C, float* ws
                                     updates, running_mean, running_var, mean, rstd, scale, shift,
                                     (long long*)num_batches_tracked, S(stream));
 }
+int fmri_bn_fold_finalize(const float* stat_part, int rows, int C, float* scratch, float* sums2C, float count,
+                          const float* gamma, const float* beta, float eps, float momentum, int updates,
+                          float* running_mean, float* running_var, float* mean, float* rstd, float* scale, float* shift,
+                          int64_t* num_batches_tracked, void* stream) {
+    if (!stat_part || rows < 1 || C < 1 || !scratch || !sums2C || !gamma || !beta || !mean || !rstd || !scale || !shift)
+        return FMRI_E_BADARG;
+    return bn_fold_finalize_launch(stat_part, rows, C, scratch, sums2C, count, gamma, beta, eps, momentum, updates,
+                                   running_mean, running_var, mean, rstd, scale, shift, (long long*)num_batches_tracked,
+                                   S(stream));
+}
+int fmri_bn_fold(const float* stat_part, int rows, int C, float* scratch, float* sums2C, void* stream) {
+    if (!stat_part || rows < 1 || C < 1 || !scratch || !sums2C) return FMRI_E_BADARG;
+    return bn_fold_launch(stat_part, rows, 2 * C, scratch, sums2C, S(stream));
+}
+int fmri_bn_fold_scratch_floats(int C) { return C < 1 ? 0 : FOLD_STAGE_ROWS * 2 * C; }
 int fmri_bn_apply(const void* x, void* y, int M, int C, const float* scale, const float* shift, int relu,
                   void* stream) {
     if (!x || !y || (C & 7)) return FMRI_E_BADARG;

@@ -60,6 +60,19 @@ __host__ __device__ inline uint32_t fd_div(uint32_t n, const FastDiv& f) {
 // with tap = ty*TW + tx, dy = dy0 + ty*dstep, dx = dx0 + tx*dstep.  A plain convolution has one
 // class; a stride-2 transposed convolution has four (output parity classes).
 // ---------------------------------------------------------------------------------------------
+// BatchNorm statistics emitted by a contraction's epilogue: per output channel sum x and sum x^2 of the STORED (fp16)
+// values over the valid output pixels of one block, written (plain stores: deterministic) to the block's own row of
+//   part[group][rows_cap][2][C]
+// group = image / group_n (decoder: several BatchNorm batches in one launch; group_n = 0: one group).  A group's rows
+// are dense: [0, P) with P = sum over classes of tpg[class]; fmri_bn_fold_finalize folds them.
+struct StatEpi {
+    float* part;           // null: no statistics
+    int32_t rows_cap;      // rows allocated per group
+    int32_t C;             // channels per row half (= CoStore of the launch)
+    int32_t group_n;       // images per statistics group, 0 = all
+    int32_t tpg[4];        // row tiles per group of class c (igemm_tc5: [0] = tiles per group, all classes in one tile)
+};
+
 struct IgemmClass {
     int32_t Yc, Xc;        // rows / cols of the output sub-grid per image
     int32_t oy0, ox0;      // output offset of the class
@@ -86,6 +99,7 @@ struct IgemmArgs {
     int64_t slab_stride;     // elements between split-K slabs (fp32 output only)
     FastDiv fdCi;
     FastDiv fdCpt;           // divide by Ci/64 (K-steps per tap) when Ci % 64 == 0
+    StatEpi st;              // BatchNorm statistics epilogue (fp16 output only)
     IgemmClass cls[4];
 };
 
@@ -141,6 +155,30 @@ struct WinArgs {
     int32_t nchunks;             // Ci / 64
     int32_t win_bytes, pbufs;    // bytes of one LDS window buffer (multiple of 4096); 1 or 2 buffers (set at launch)
     WinClass cls[4];
+};
+
+// all four parity classes of a k5 s2 p2 transposed convolution per block (igemm_tc5.hip)
+struct Tc5Class {
+    int32_t Yc, Xc;        // class output grid: class (cy, cx) writes output pixel (2y + cy, 2x + cx)
+    int32_t Kpad, pad0;
+    int64_t w_off;         // element offset of the class's packed weight matrix
+};
+
+struct Tc5Args {
+    const half_t* in;      // [N][Hi][Wi][Ci]
+    const half_t* w;
+    half_t* out;           // [N][Ho][Wo][CoStore]
+    const float* bias;
+    int32_t N, Hi, Wi, Ci;
+    int32_t Ho, Wo, CoStore, Co;
+    int32_t act, nchunks;                        // nchunks = Ci / 64 (even)
+    int32_t pw_log2, ph_log2, PH, IPB;           // tile of 128 class-grid positions: PW x PH x IPB images
+    int32_t tiles_x, tiles_y, ntiles;
+    int32_t IH, IW, nslice;                      // union window (PH + 2) x (PW + 2); 4 KB DMA slices per 64-channel chunk
+    uint32_t in_bytes, w_bytes;                  // buffer descriptor ranges (in_bytes < 2^31)
+    FastDiv fdTPI, fdTX, fdIHW, fdIW;
+    StatEpi st;
+    Tc5Class cls[4];
 };
 
 // weight-gradient implicit GEMM (wgrad.hip):
@@ -253,6 +291,58 @@ __device__ __forceinline__ void xcd_tile(int& tx, int& ty) {
     if ((nb & 7) == 0) l = (l & 7) * (nb >> 3) + (l >> 3);
     ty = l % gy;
     tx = l / gy;
+}
+
+// sum over the 16 lanes of a DPP row (lanes with equal lane >> 4), result in every lane of the row
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));  // row_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));  // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+    return v;
+}
+
+// BatchNorm statistics out of MFMA accumulators laid out D[i = channel][j = pixel] (16x16x32, weights as the A operand):
+// lane (fq = lane >> 4, frow = lane & 15) holds, per 16-channel tile tn, the per-lane sums over its pixels of channels
+// tn*16 + fq*4 + 0..3.  The 16 lanes of a DPP row hold the same channels of 16 different pixels: one row sum each, then
+// lane (fq, frow) owns channel (frow >> 2)*16 + fq*4 + (frow & 3) of the wave's BNW = 16*TN channels.  The WM waves that
+// cover the same channels (different pixel rows of the block tile) meet in `scratch` (LDS, (WM-1)*WN*128 floats, free
+// after the K loop) in a fixed order, and the wm == 0 waves store the block's row: row[co] = sum, row[C + co] = sum of
+// squares.  Called by every thread of the block.
+template <int TN, int WM, int WN>
+__device__ __forceinline__ void stat_store(const f4 (&ssum)[TN], const f4 (&ssq)[TN], int lane, int wm, int wn,
+                                           int co_block, float* scratch, float* row, int C) {
+    const int frow = lane & 15, fq = lane >> 4;
+    float vs = 0.f, vq = 0.f;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const float s = row16_sum(ssum[tn][rg]);
+            const float q = row16_sum(ssq[tn][rg]);
+            if (frow == tn * 4 + rg) { vs = s; vq = q; }
+        }
+    const int ch = (frow >> 2) * 16 + fq * 4 + (frow & 3);      // channel within the wave's 16*TN
+    __syncthreads();                                             // everyone is done with the operand tiles in LDS
+    if (WM > 1 && wm > 0) {
+        float* dst = scratch + ((wm - 1) * WN + wn) * 128;
+        dst[ch] = vs;
+        dst[64 + ch] = vq;
+    }
+    if (WM > 1) __syncthreads();
+    if (wm == 0 && (frow >> 2) < TN) {
+#pragma unroll
+        for (int w = 1; w < WM; ++w) {
+            const float* src = scratch + ((w - 1) * WN + wn) * 128;
+            vs += src[ch];
+            vq += src[64 + ch];
+        }
+        const int co = co_block + wn * (16 * TN) + ch;
+        if (co < C) {
+            row[co] = vs;
+            row[C + co] = vq;
+        }
+    }
 }
 
 __device__ __forceinline__ float act_apply(float v, int act) {

@@ -239,6 +239,10 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmArgs a) 
     }
 
     // ---- epilogue: D[i = co][j = pixel]; lane owns pixel (lane&15), channels (lane>>4)*4 .. +3
+    const bool stats = !OUT_F32 && a.st.part != nullptr;
+    f4 ssum[TN], ssq[TN];
+#pragma unroll
+    for (int i = 0; i < TN; ++i) { ssum[i] = (f4){0.f, 0.f, 0.f, 0.f}; ssq[i] = (f4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
         const int m = m0 + wm * (BM / WM) + tm * 16 + frow;
@@ -270,7 +274,30 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmArgs a) 
                     hv[r] = (half_t)f;
                 }
                 *(h4*)((half_t*)a.out + opix * a.CoStore + co) = hv;
+                if (stats) {
+                    // BatchNorm statistics of the STORED values (see StatEpi)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float f = (float)hv[r];
+                        ssum[tn][r] += f;
+                        ssq[tn][r] += f * f;
+                    }
+                }
             }
+        }
+    }
+    if constexpr (!OUT_F32) {
+        if (stats) {        // block-uniform
+            // row of this block: classes one after the other, a group's tiles dense (the host guarantees that no tile
+            // straddles two groups)
+            int g = 0, prow = bx;
+            if (a.st.group_n > 0) {
+                g = bx / a.st.tpg[icls];
+                prow = bx - g * a.st.tpg[icls];
+            }
+            for (int i = 0; i < icls; ++i) prow += a.st.tpg[i];
+            float* row = a.st.part + ((size_t)g * a.st.rows_cap + prow) * 2 * a.st.C;
+            stat_store<TN, WM, WN>(ssum, ssq, lane, wm, wn, co0, (float*)smem, row, a.st.C);
         }
     }
 }
@@ -298,13 +325,18 @@ static int launch_bn(const IgemmArgs& a, int maxM, int copad, bool out_f32, hipS
 
 // host entry used by api.hip.  bn_tile in {32, 64, 128}; a 128-channel tiling of a layer with >= 256 output channels
 // and enough 256-pixel tiles to fill the chip is promoted to the 256 x 256 tile (FMRI_BIG=off disables).
-int igemm_launch(const IgemmArgs& a, int maxM, int bn_tile, int copad, bool out_f32, hipStream_t st) {
+int igemm_bm(const IgemmArgs& a, int maxM, int bn_tile, int copad, bool out_f32) {
     static const char* big_env = getenv("FMRI_BIG");
     static const bool no_big = big_env && !strcmp(big_env, "off");
     static const int big_min = big_env && big_env[0] >= '0' && big_env[0] <= '9' ? atoi(big_env) : 192;
     if (!no_big && bn_tile == 128 && !out_f32 && a.splits == 1 && (copad & 255) == 0 &&
         (int64_t)((maxM + 255) / 256) * (copad / 256) * a.ncls >= big_min)
-        return launch_bn<256, 256, 2, 4>(a, maxM, copad, out_f32, st);
+        return 256;
+    return 128;
+}
+
+int igemm_launch(const IgemmArgs& a, int maxM, int bn_tile, int copad, bool out_f32, hipStream_t st) {
+    if (igemm_bm(a, maxM, bn_tile, copad, out_f32) == 256) return launch_bn<256, 256, 2, 4>(a, maxM, copad, out_f32, st);
     switch (bn_tile) {
         case 128: return launch_bn<128, 128, 2, 2>(a, maxM, copad, out_f32, st);
         case 64: return launch_bn<128, 64, 2, 2>(a, maxM, copad, out_f32, st);

@@ -33,9 +33,11 @@ struct UnpackArgs {
 };
 
 int igemm_launch(const IgemmArgs& a, int maxM, int bn_tile, int copad, bool out_f32, hipStream_t st);
+int igemm_bm(const IgemmArgs& a, int maxM, int bn_tile, int copad, bool out_f32);   // row tile igemm_launch will use
 int igemm_patch_launch(PatchArgs& a, int max_tiles, int bn_tile, int copad, hipStream_t st);
 int igemm_win_launch(WinArgs& a, int max_tiles, int bn_tile, int copad, hipStream_t st);
 int igemm_tc32_launch(const Tc32Args& a, int nblocks, hipStream_t st);
+int igemm_tc5_launch(const Tc5Args& a, int bn_tile, int copad, hipStream_t st);
 int igemm_narrow_launch(const NarrowArgs& a, int ci, int co_tiles, bool flip, hipStream_t st);
 int wgrad_launch(const WgradArgs& a, int apad, int ba_tile, hipStream_t st);
 int wgrad_win_launch(const WgradWinArgs& a, int apad, hipStream_t st);
@@ -69,6 +71,12 @@ int bn_stats_finalize_launch(const half_t* x, int M, int C, float* sums, float* 
 int bn_bwd_reduce_launch(const half_t* x, const half_t* dy, int M, int C, const float* mean, const float* rstd,
                          const float* gamma, const float* beta, int relu, float* sums, float* ws, int64_t ws_floats,
                          float* dbeta, float* dgamma, float gscale, hipStream_t st);
+constexpr int FOLD_STAGE_ROWS = 32;     // rows of the intermediate buffer of a two-stage statistics fold
+int bn_fold_finalize_launch(const float* part, int rows, int C, float* scratch, float* sums, float count,
+                            const float* gamma, const float* beta, float eps, float momentum, int updates, float* rm,
+                            float* rv, float* mean, float* rstd, float* scale, float* shift, long long* nbt,
+                            hipStream_t st);
+int bn_fold_launch(const float* part, int rows, int n, float* scratch, float* sums, hipStream_t st);
 int bn_finalize_launch(const float* sums, int C, float count, const float* gamma, const float* beta, float eps,
                        float momentum, int updates, float* rm, float* rv, float* mean, float* rstd, float* scale,
                        float* shift, long long* nbt, hipStream_t st);

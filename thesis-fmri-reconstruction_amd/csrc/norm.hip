@@ -167,6 +167,36 @@ __global__ __launch_bounds__(1024) void fold_partials_kernel(const float* __rest
     }
 }
 
+// stage 1 of a long fold (statistics rows written by a contraction's epilogue, StatEpi): block (x, y) sums rows
+// [y*per, (y+1)*per) of columns 32x .. 32x+31 into out[y][n].  Same lane layout as fold_partials_kernel.
+__global__ __launch_bounds__(1024) void fold_rows_kernel(const float* __restrict__ part, int nparts, int n, int per,
+                                                         float* __restrict__ out) {
+    __shared__ float red[32][33];
+    const int cx = threadIdx.x & 31, gy = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + cx;
+    const int lo = blockIdx.y * per;
+    const int hi = lo + per < nparts ? lo + per : nparts;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < n) {
+        int p = lo + gy;
+        for (; p + 96 < hi; p += 128) {
+            s0 += part[(int64_t)p * n + i];
+            s1 += part[(int64_t)(p + 32) * n + i];
+            s2 += part[(int64_t)(p + 64) * n + i];
+            s3 += part[(int64_t)(p + 96) * n + i];
+        }
+        for (; p < hi; p += 32) s0 += part[(int64_t)p * n + i];
+    }
+    red[gy][cx] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (gy == 0 && i < n) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) s += red[r][cx];
+        out[(int64_t)blockIdx.y * n + i] = s;
+    }
+}
+
 // shared by bn_finalize_kernel and fold_finalize_kernel: channel c from its batch sums
 __device__ __forceinline__ void bn_finalize_channel(int c, float sx, float sxx, float count, const float* gamma,
                                                     const float* beta, float eps, float momentum, int updates,
@@ -492,6 +522,31 @@ int bn_stats_finalize_launch(const half_t* x, int M, int C, float* sums, float* 
                        (const float*)nullptr, (const float*)nullptr, 0, ws);
     hipLaunchKernelGGL(fold_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, st, ws, g.gy, C, sums, count, gamma,
                        beta, eps, momentum, updates, rm, rv, mean, rstd, scale, shift, nbt);
+    return LAUNCH_OK();
+}
+// Statistics rows of a contraction's epilogue (StatEpi): part [rows][2][C] -> sums (+ finalize).  More than 256 rows are
+// folded in two stages through `scratch` (FOLD_STAGE_ROWS x 2C floats).
+static const float* fold_stage1(const float* part, int& rows, int n, float* scratch, hipStream_t st) {
+    if (rows <= 256) return part;
+    const int per = (rows + FOLD_STAGE_ROWS - 1) / FOLD_STAGE_ROWS;
+    const int ny = (rows + per - 1) / per;
+    hipLaunchKernelGGL(fold_rows_kernel, dim3((n + 31) / 32, ny), dim3(1024), 0, st, part, rows, n, per, scratch);
+    rows = ny;
+    return scratch;
+}
+int bn_fold_finalize_launch(const float* part, int rows, int C, float* scratch, float* sums, float count,
+                            const float* gamma, const float* beta, float eps, float momentum, int updates, float* rm,
+                            float* rv, float* mean, float* rstd, float* scale, float* shift, long long* nbt,
+                            hipStream_t st) {
+    const float* src = fold_stage1(part, rows, 2 * C, scratch, st);
+    hipLaunchKernelGGL(fold_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, st, src, rows, C, sums, count, gamma,
+                       beta, eps, momentum, updates, rm, rv, mean, rstd, scale, shift, nbt);
+    return LAUNCH_OK();
+}
+int bn_fold_launch(const float* part, int rows, int n, float* scratch, float* sums, hipStream_t st) {
+    const float* src = fold_stage1(part, rows, n, scratch, st);
+    hipLaunchKernelGGL(fold_partials_kernel, dim3((n + 31) / 32), dim3(1024), 0, st, src, rows, n, sums,
+                       (float*)nullptr, (float*)nullptr, 0.f, 0, 0);
     return LAUNCH_OK();
 }
 int bn_stats_launch(const half_t* x, int M, int C, float* sums, float* ws, int64_t ws_floats, hipStream_t st) {

@@ -28,6 +28,8 @@ _SIGS = {
     "fmri_ssim": [_p, _p, _i, _i, _i, _p, _p, _p, _p],
     "fmri_unpack_grad": [_p, _p, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _l, _p],
     "fmri_igemm": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _l, _i, _p],
+    "fmri_igemm_ep": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _l, _i, _l, _p, _p,
+                      _p],
     "fmri_wgrad_slabs": [_i, _i, _i, _i, _i, _i],
     "fmri_wgrad": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "fmri_nchw_to_nhwc": [_p, _p, _i, _i, _i, _i, _p],
@@ -39,6 +41,8 @@ _SIGS = {
     "fmri_bn_stats": [_p, _i, _i, _p, _p, _l, _p],
     "fmri_bn_finalize": [_p, _i, _f, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p, _p, _p, _p],
     "fmri_bn_stats_finalize": [_p, _i, _i, _p, _p, _l, _f, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p, _p, _p, _p],
+    "fmri_bn_fold_finalize": [_p, _i, _i, _p, _p, _f, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p, _p, _p, _p],
+    "fmri_bn_fold": [_p, _i, _i, _p, _p, _p],
     "fmri_bn_apply": [_p, _p, _i, _i, _p, _p, _i, _p],
     "fmri_bn_bwd_reduce": [_p, _p, _i, _i, _p, _p, _p, _p, _i, _p, _p, _l, _p, _p, _f, _p],
     "fmri_bn_bwd_apply": [_p, _p, _p, _i, _i, _f, _p, _p, _p, _p, _i, _p, _p],
@@ -61,7 +65,13 @@ _SIGS = {
     "fmri_adam": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _f, _f, _p, _f, _p, _p],
 }
 
-EXPORTS = sorted(list(_SIGS) + ["fmri_version", "fmri_last_error_string", "fmri_test_fastdiv", "fmri_bn_ws_floats"])
+class Epilogue(C.Structure):
+    """``fmri_epilogue`` of include/fmri_hip.h (BatchNorm statistics out of a contraction's epilogue)."""
+    _fields_ = [("stat_part", C.c_void_p), ("stat_rows_cap", C.c_int32), ("stat_group_n", C.c_int32)]
+
+
+EXPORTS = sorted(list(_SIGS) + ["fmri_version", "fmri_last_error_string", "fmri_test_fastdiv", "fmri_bn_ws_floats",
+                             "fmri_bn_fold_scratch_floats"])
 
 _lib = None
 
@@ -87,6 +97,8 @@ def load():
     lib.fmri_test_fastdiv.argtypes = [C.c_uint32, C.c_uint32]
     lib.fmri_bn_ws_floats.restype = _l
     lib.fmri_bn_ws_floats.argtypes = [_i, _i]
+    lib.fmri_bn_fold_scratch_floats.restype = _i
+    lib.fmri_bn_fold_scratch_floats.argtypes = [_i]
     _lib = lib
     return lib
 

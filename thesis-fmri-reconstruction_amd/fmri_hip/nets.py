@@ -127,8 +127,8 @@ class EncoderNet:
         h = x16
         upd = (1 if train_stats else 0) if updates is None else updates
         for conv, bn in zip(self.convs, self.bns):
-            raw = conv.forward(h)
-            h, sv = bn.forward(raw, relu=True, updates=upd)
+            raw = conv.forward(h, bn_groups=0 if bn.eval_mode else 1)
+            h, sv = bn.forward(raw, relu=True, updates=upd, stat_acc=conv.take_stats())
             raws.append(raw)
             svs.append(sv)
             acts.append(h)
@@ -240,11 +240,12 @@ class DecoderNet:
         h = act_fc.reshape(GB, f, f, self.size0)
         acts, raws, svs = [h], [], []
         for dc, bn in zip(self.deconvs, self.bns):
-            raw = dc.forward(h)
+            raw = dc.forward(h, bn_groups=0 if bn.eval_mode else groups)
             act = torch.empty_like(raw)
             sl = [None] * groups
             for gi in order:
-                _, sv = bn.forward(raw[gi * B:(gi + 1) * B], True, upd, out=act[gi * B:(gi + 1) * B])
+                _, sv = bn.forward(raw[gi * B:(gi + 1) * B], True, upd, out=act[gi * B:(gi + 1) * B],
+                                   stat_acc=dc.take_stats(gi))
                 sl[gi] = sv
             raws.append(raw)
             svs.append(sl)
@@ -383,8 +384,8 @@ class DiscriminatorNet:
         acts, raws, svs = [a0], [], []
         h = a0
         for conv, bn in zip(self.convs, self.bns):
-            raw = conv.forward(h)
-            h, sv = bn.forward(raw, relu=True, updates=conv_updates if train_stats else 0)
+            raw = conv.forward(h, bn_groups=0 if bn.eval_mode else 1)
+            h, sv = bn.forward(raw, relu=True, updates=conv_updates if train_stats else 0, stat_acc=conv.take_stats())
             raws.append(raw)
             svs.append(sv)
             acts.append(h)

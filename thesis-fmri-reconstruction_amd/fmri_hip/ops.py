@@ -178,7 +178,8 @@ def _choose_splits(blocks: int, ksteps: int) -> int:
 PROFILE = None
 
 
-def igemm_kernel_label(N, Hi, Wi, Ci, Ho, Wo, CoStore, Co, k, stride, pad, mode, out_f32, splits, tile) -> str:
+def igemm_kernel_label(N, Hi, Wi, Ci, Ho, Wo, CoStore, Co, k, stride, pad, mode, out_f32, splits, tile,
+                       bias_none=True, act=0) -> str:
     """Name of the kernel instantiation csrc/api.hip::fmri_igemm routes this geometry to (mirrors its rules)."""
     spatial = Hi * Wi > 1
     if (mode in (MODE_CONV, MODE_CONV_FLIP) and stride == 1 and k == 5 and pad == 2 and Ci in (8, 32) and Co <= 32
@@ -186,6 +187,15 @@ def igemm_kernel_label(N, Hi, Wi, Ci, Ho, Wo, CoStore, Co, k, stride, pad, mode,
         return f"fmri::igemm_narrow_kernel<{Ci},{1 if Co <= 16 else 2},{'true' if mode == MODE_CONV_FLIP else 'false'}>"
     if mode == MODE_TCONV2 and Ci == 128 and CoStore <= 32 and not out_f32 and splits == 1:
         return "fmri::igemm_tc32_kernel"
+    if (mode == MODE_TCONV2 and k == 5 and pad == 2 and Ci % 128 == 0 and tile >= 64 and not out_f32 and splits == 1
+            and bias_none and act == ACT_NONE and os.environ.get("FMRI_TC5") != "off"):
+        yc, xc = (Ho + 1) // 2, (Wo + 1) // 2
+        pw = 16 if xc > 8 else 8
+        ph = 16 if (pw == 8 and yc > 8) else 8
+        ipb = 128 // (pw * ph)
+        nsl = (ipb * (ph + 2) * (pw + 2) * 8 + 255) // 256
+        if nsl in (6, 7):
+            return f"fmri::igemm_tc5_kernel<{tile},{nsl},false>"
     unit = (mode == MODE_TCONV2 or stride == 1) and spatial and 2 <= k <= 5 and not out_f32 and splits == 1
     if unit and Ci % 64 == 0 and tile >= 64:
         return f"fmri::igemm_win_kernel<{tile},2,2>"
@@ -203,20 +213,31 @@ def igemm_kernel_label(N, Hi, Wi, Ci, Ho, Wo, CoStore, Co, k, stride, pad, mode,
 
 
 def run_igemm(x, pw: PackedWeight, out, bias, N, Hi, Wi, Ci, Ho, Wo, CoStore, Co, k, stride, pad, mode, act, out_f32,
-              splits, slab_stride, tile, flops=0.0):
+              splits, slab_stride, tile, flops=0.0, stats=None) -> int:
+    """``stats`` = (partial-row tensor [groups][rows_cap][2][CoStore] fp32, rows_cap, images per group or 0): ask the
+    kernel for the BatchNorm statistics of its output (fmri_igemm_ep).  Returns the number of rows written per group
+    (0: the kernel behind this geometry has no statistics epilogue)."""
     w = pw.get()
     prof = PROFILE is not None and flops > 0.0
     if prof:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    lib.call("fmri_igemm", _P(x), _P(w), _P(out), _P(bias), _P(zero_page(x.device)), N, Hi, Wi, Ci, Ho, Wo,
-             CoStore, Co, k, stride, pad, mode, act, 1 if out_f32 else 0, splits, slab_stride, tile)
+    ep, done = None, ctypes.c_int(0)
+    if stats is not None:
+        ep = ctypes.byref(lib.Epilogue(stats[0].data_ptr(), int(stats[1]), int(stats[2])))
+    lib.call("fmri_igemm_ep", _P(x), _P(w), _P(out), _P(bias), _P(zero_page(x.device)), N, Hi, Wi, Ci, Ho, Wo,
+             CoStore, Co, k, stride, pad, mode, act, 1 if out_f32 else 0, splits, slab_stride, tile, w.numel(), ep,
+             ctypes.byref(done))
     if prof:
         e1.record()
         PROFILE.append((igemm_kernel_label(N, Hi, Wi, Ci, Ho, Wo, CoStore, Co, k, stride, pad, mode, out_f32, splits,
-                                           tile),
+                                           tile, bias is None, act),
                         e0, e1, flops))
+    return int(done.value)
 
+
+# BatchNorm statistics out of the producing contraction's epilogue (fmri_igemm_ep): on/off
+_EPI_STATS = os.environ.get("FMRI_EPI_STATS") != "off"
 
 # window-resident wgrad kernel: on/off, resident-block target (2 per CU), largest split count still written as slabs
 _WW_ON = os.environ.get("FMRI_WGRAD_WIN") != "off"
@@ -374,16 +395,34 @@ class ConvLayer:
             f = lambda v: (v - 1) * self.stride - 2 * self.pad + self.k + self.out_pad
         return f(hi), f(wi)
 
-    def forward(self, x: torch.Tensor, act: int = ACT_NONE, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, act: int = ACT_NONE, out: Optional[torch.Tensor] = None,
+                bn_groups: int = 0) -> torch.Tensor:
+        """``bn_groups`` > 0: the output goes into a train-mode BatchNorm whose batch is each of ``bn_groups`` equal
+        image ranges; the kernel's epilogue is asked for the batch statistics (fmri_igemm_ep) and ``take_stats(g)``
+        hands group g's accumulator to ``BatchNorm.forward`` (None if this geometry's kernel has no such epilogue)."""
         N, Hi, Wi, C = x.shape
         assert C == self.cinp and x.dtype == torch.float16 and x.is_contiguous()
         Ho, Wo = self.out_hw(Hi, Wi)
         if out is None:
             out = torch.empty(N, Ho, Wo, self.coutp, dtype=torch.float16, device=x.device)
         mode = MODE_CONV if self.kind == "conv" else MODE_TCONV2
-        run_igemm(x, self.pw_f, out, self.b, N, Hi, Wi, self.cinp, Ho, Wo, self.coutp, self.cout, self.k,
-                  self.stride, self.pad, mode, act, False, 1, 0, self.t_out, self._flops(N, Hi, Wi, Ho, Wo))
+        stats = None
+        self._stat_rows = 0
+        if bn_groups > 0 and _EPI_STATS and N % bn_groups == 0:
+            cap = (N // bn_groups) * Ho * Wo // 128 + 8
+            part = getattr(self, "_stat_part", None)
+            if part is None or part.shape[0] < bn_groups or part.shape[1] < cap:
+                part = self._stat_part = torch.empty(bn_groups, cap, 2, self.coutp, dtype=torch.float32,
+                                                     device=x.device)
+            stats = (part, part.shape[1], N // bn_groups if bn_groups > 1 else 0)
+        self._stat_rows = run_igemm(x, self.pw_f, out, self.b, N, Hi, Wi, self.cinp, Ho, Wo, self.coutp, self.cout,
+                                    self.k, self.stride, self.pad, mode, act, False, 1, 0, self.t_out,
+                                    self._flops(N, Hi, Wi, Ho, Wo), stats=stats)
         return out
+
+    def take_stats(self, g: int = 0) -> Optional[torch.Tensor]:
+        """Rows [P][2][coutp] with the per-block batch statistics of group ``g`` of the last forward, or None."""
+        return self._stat_part[g, :self._stat_rows] if getattr(self, "_stat_rows", 0) > 0 else None
 
     def _flops(self, N, Hi, Wi, Ho, Wo):
         """Algorithmic FLOPs of one pass (fwd == dgrad == wgrad): 2 * pixels * cin * cout * k^2, pixels = conv
@@ -574,7 +613,10 @@ class BatchNorm:
             lib.call("fmri_permute_chw", _P(self.rm_e), _P(self.rm), c0, hw, 0, 1.0, 0)
             lib.call("fmri_permute_chw", _P(self.rv_e), _P(self.rv), c0, hw, 0, 1.0, 0)
 
-    def forward(self, raw: torch.Tensor, relu: bool = True, updates: int = 1, out: Optional[torch.Tensor] = None):
+    def forward(self, raw: torch.Tensor, relu: bool = True, updates: int = 1, out: Optional[torch.Tensor] = None,
+                stat_acc: Optional[torch.Tensor] = None):
+        """``stat_acc``: the batch statistics of ``raw`` as rows [P][2][C] written by the producing kernel's epilogue
+        (``ConvLayer.take_stats``): the statistics pass over ``raw`` is skipped."""
         if self.eval_mode:
             return self.forward_eval(raw, relu, out), None
         C = self.C
@@ -583,7 +625,7 @@ class BatchNorm:
         dev = raw.device
         gamma, beta, rm, rv = self._params()
         sums = torch.empty(2, C, dtype=torch.float32, device=dev)
-        ws = _reduce_ws(M, C, dev)
+        ws = _reduce_ws(M, C, dev) if stat_acc is None else None
         count = float(M)
         sv = BNSaved()
         buf = torch.empty(4, C, dtype=torch.float32, device=dev)
@@ -593,7 +635,17 @@ class BatchNorm:
         fin = (_P(gamma), _P(beta), 1e-5, 0.9, updates, _P(rm) if updates > 0 else None,
                _P(rv) if updates > 0 else None, _P(sv.mean), _P(sv.rstd), _P(sv.scale), _P(sv.shift),
                _P(self.nbt) if updates > 0 else None)
-        if self.reducer is None:
+        if stat_acc is not None:
+            assert stat_acc.shape[-1] == C and stat_acc.is_contiguous()
+            rows = stat_acc.shape[0]
+            scratch = torch.empty(lib.load().fmri_bn_fold_scratch_floats(C), dtype=torch.float32, device=dev)
+            if self.reducer is None:
+                lib.call("fmri_bn_fold_finalize", _P(stat_acc), rows, C, _P(scratch), _P(sums), count, *fin)
+            else:
+                lib.call("fmri_bn_fold", _P(stat_acc), rows, C, _P(scratch), _P(sums))
+                count *= self.reducer(sums)
+                lib.call("fmri_bn_finalize", _P(sums), C, count, *fin)
+        elif self.reducer is None:
             # no statistics exchange: the fold of the partial sums finalizes (one launch less on the critical path)
             lib.call("fmri_bn_stats_finalize", _P(x2), M, C, _P(sums), _P(ws), ws.numel(), count, *fin)
         else:

@@ -216,6 +216,21 @@ def _q(t: Tensor) -> Tensor:
     return t + (t.detach().half().float() - t.detach())
 
 
+# RELU_MASKS (tests only): a list of 0/1 tensors consumed in call order by every ReLU below -- the masks of another
+# run of the same network (the HIP engine's stored activations > 0).  With the masks pinned the gradients are a smooth
+# function of the activations, so two implementations can be compared at rounding level instead of at the level of
+# "which pre-activations within fp16 rounding of zero fell on which side".
+RELU_MASKS = None
+
+
+def _relu(x: Tensor) -> Tensor:
+    if RELU_MASKS is None:
+        return F.relu(x)
+    m = RELU_MASKS.pop(0)
+    assert m.shape == x.shape, (tuple(m.shape), tuple(x.shape))
+    return x * m
+
+
 def _w(P: State, key: str) -> Tensor:
     """GEMM weight as the engine multiplies it (fp16 copy of the fp32 master under STORAGE16)."""
     return _q(P[key])
@@ -238,9 +253,9 @@ def encoder_fwd(P: State, pre: str, x: Tensor, cfg: ArchCfg, train: bool = True)
     h = _q(x)
     for i in range(3):
         h = _q(F.conv2d(h, _w(P, f"{pre}conv.{i}.conv.weight"), None, cfg.stride, cfg.padding))
-        h = _q(F.relu(_bn(P, f"{pre}conv.{i}.bn.", h, train)))
+        h = _q(_relu(_bn(P, f"{pre}conv.{i}.bn.", h, train)))
     h = h.reshape(h.shape[0], -1)
-    h = _q(F.relu(_bn(P, f"{pre}fc.1.", _q(F.linear(h, _w(P, f"{pre}fc.0.weight"))), train)))
+    h = _q(_relu(_bn(P, f"{pre}fc.1.", _q(F.linear(h, _w(P, f"{pre}fc.0.weight"))), train)))
     mu = F.linear(h, _w(P, f"{pre}l_mu.weight"), P[f"{pre}l_mu.bias"])
     logvar = F.linear(h, _w(P, f"{pre}l_var.weight"), P[f"{pre}l_var.bias"])
     return mu, logvar
@@ -248,12 +263,12 @@ def encoder_fwd(P: State, pre: str, x: Tensor, cfg: ArchCfg, train: bool = True)
 
 def decoder_fwd(P: State, pre: str, z: Tensor, cfg: ArchCfg, train: bool = True):
     """Decoder.forward, models/vae_gan.py:125-129."""
-    h = _q(F.relu(_bn(P, f"{pre}fc.1.", _q(F.linear(_q(z), _w(P, f"{pre}fc.0.weight"))), train)))
+    h = _q(_relu(_bn(P, f"{pre}fc.1.", _q(F.linear(_q(z), _w(P, f"{pre}fc.0.weight"))), train)))
     h = h.reshape(h.shape[0], -1, cfg.fc_input, cfg.fc_input)
     for i in range(3):
         h = _q(F.conv_transpose2d(h, _w(P, f"{pre}conv.{i}.conv.weight"), None, cfg.stride, cfg.padding,
                                   output_padding=1 if cfg.output_pad_dec[i] else 0))
-        h = _q(F.relu(_bn(P, f"{pre}conv.{i}.bn.", h, train)))
+        h = _q(_relu(_bn(P, f"{pre}conv.{i}.bn.", h, train)))
     h = F.conv2d(h, _w(P, f"{pre}conv.3.0.weight"), P[f"{pre}conv.3.0.bias"], 1, 2)
     return _q(torch.tanh(h))
 
@@ -262,23 +277,23 @@ def discriminator_fwd(P: State, pre: str, x_orig: Tensor, x_pred: Tensor, x_samp
                       cfg: ArchCfg, train: bool = True, recon_level: int = 3):
     """Discriminator.forward, models/vae_gan.py:163-183 (mode 'REC' or 'GAN')."""
     h = _q(torch.cat((x_orig, x_pred, x_samp), 0))
-    h = _q(F.relu(F.conv2d(h, _w(P, f"{pre}conv.0.0.weight"), P[f"{pre}conv.0.0.bias"], cfg.stride_gan, 2)))
+    h = _q(_relu(F.conv2d(h, _w(P, f"{pre}conv.0.0.weight"), P[f"{pre}conv.0.0.bias"], cfg.stride_gan, 2)))
     for i in (1, 2, 3):
         raw = _q(F.conv2d(h, _w(P, f"{pre}conv.{i}.conv.weight"), None, cfg.stride, cfg.padding))
         if mode == "REC" and i == recon_level:
             # reference still runs bn+relu on this block before returning (vae_gan.py:25-30)
             _bn(P, f"{pre}conv.{i}.bn.", raw, train)
             return raw.reshape(raw.shape[0], -1)
-        h = _q(F.relu(_bn(P, f"{pre}conv.{i}.bn.", raw, train)))
+        h = _q(_relu(_bn(P, f"{pre}conv.{i}.bn.", raw, train)))
     h = h.reshape(h.shape[0], -1)
-    h = _q(F.relu(_bn(P, f"{pre}fc.1.", _q(F.linear(h, _w(P, f"{pre}fc.0.weight"))), train)))
+    h = _q(_relu(_bn(P, f"{pre}fc.1.", _q(F.linear(h, _w(P, f"{pre}fc.0.weight"))), train)))
     h = F.linear(h, _w(P, f"{pre}fc.3.weight"), P[f"{pre}fc.3.bias"])
     return torch.sigmoid(h)
 
 
 def cognitive_encoder_fwd(P: State, pre: str, fmri: Tensor, train: bool = True):
     """CognitiveEncoder.forward, models/vae_gan.py:224-229."""
-    h = _q(F.relu(_bn(P, f"{pre}fc1.1.", _q(F.linear(_q(fmri), _w(P, f"{pre}fc1.0.weight"))), train)))
+    h = _q(_relu(_bn(P, f"{pre}fc1.1.", _q(F.linear(_q(fmri), _w(P, f"{pre}fc1.0.weight"))), train)))
     mu = F.linear(h, _w(P, f"{pre}l_mu.weight"), P[f"{pre}l_mu.bias"])
     logvar = F.linear(h, _w(P, f"{pre}l_var.weight"), P[f"{pre}l_var.bias"])
     return mu, logvar
@@ -288,7 +303,7 @@ def wae_discriminator_fwd(P: State, pre: str, z: Tensor):
     """WaeDiscriminator.forward, models/vae_gan.py:527-529."""
     h = _q(z)
     for idx in (0, 2, 4, 6):
-        h = _q(F.relu(F.linear(h, _w(P, f"{pre}main.{idx}.weight"), P[f"{pre}main.{idx}.bias"])))
+        h = _q(_relu(F.linear(h, _w(P, f"{pre}main.{idx}.weight"), P[f"{pre}main.{idx}.bias"])))
     return torch.sigmoid(F.linear(h, _w(P, f"{pre}main.8.weight"), P[f"{pre}main.8.bias"]))
 
 

@@ -9,10 +9,11 @@ Two references per tensor:
     engine's gradient must keep the direction (cosine) and the length along the reference (projection).
 """
 import contextlib
+import os
 
 import torch
 
-TOL16 = 2e-2        # relative L2 error against the 16-bit-storage oracle, per tensor
+TOL16 = 1e-2        # relative L2 error against the 16-bit-storage oracle, per tensor
 COS32 = 0.95        # cosine against the fp32 oracle
 PROJ32 = 0.03       # |<g, r> / <r, r> - 1| against the fp32 oracle
 
@@ -41,12 +42,24 @@ def report(got, ref32, ref16, skip=()):
     return rows
 
 
-def check(got, ref32, ref16, what="", skip=(), tol16=TOL16, cos32=COS32, proj32=PROJ32, small=64):
-    """Assert the two criteria for every tensor; tensors with fewer than ``small`` elements (the 3-element bias of the
-    decoder's last convolution, scalar biases: sums that cancel over the batch) are held to the 16-bit-storage
-    comparison with a 5x bound only."""
+def check(got, ref32, ref16, what="", skip=(), tol16=TOL16, cos32=COS32, proj32=PROJ32, small=64, loose16=0.15):
+    """Assert the criteria for every tensor.  ``ref16`` comes from an oracle run with the engine's ReLU masks pinned
+    (``oracle.RELU_MASKS``) -> bound ``tol16``; without pinned masks (pass ``tol16=None``) the 16-bit-storage run only has
+    masks as far from the engine's as the fp32 run's and is held to ``loose16``.  Tensors with fewer than ``small``
+    elements (the 3-element bias of the decoder's last convolution, scalar biases: sums that cancel over the batch) are
+    held to 5x the 16-bit bound only."""
+    if tol16 is None:
+        tol16 = loose16
     rows = report(got, ref32, ref16, skip)
     rows.sort(key=lambda r: -r[1])
+    log = os.environ.get("FMRI_GRADLOG")
+    if log:
+        with open(log, "a") as f:
+            f.write(f"# {what}: worst err16 {max(r[1] for r in rows):.3e}, min cos32 "
+                    f"{min(r[2] for r in rows if r[4] >= small):.4f}, max |proj32-1| "
+                    f"{max(abs(r[3] - 1) for r in rows if r[4] >= small):.4f} (bounds {tol16} / {cos32} / {proj32})\n")
+            for k, e16, cos, proj, n in rows[:5]:
+                f.write(f"{what} {k} err16 {e16:.3e} cos32 {cos:.4f} proj32 {proj:.4f} n {n}\n")
     for k, e16, cos, proj, n in rows[:8]:
         print(f"{what} grad {k}: err16 {e16:.2e} cos32 {cos:.4f} proj32 {proj:.4f} n {n}")
     print(f"{what} worst err16 {max(r[1] for r in rows):.2e}  min cos32 {min(r[2] for r in rows if r[4] >= small):.4f}")

@@ -127,7 +127,7 @@ def test_literal_reference_loop_body_runs_on_engine():
     o16 = {n: O.OptState(kind="rmsprop", lr=lr) for n in ("encoder", "decoder", "discriminator")}
     with gradcheck.storage16(O):
         ref16 = O.stage1_step(P16, o16, data["x"], data["noise"][0, 0], data["noise"][0, 1], cfg, keep_grads=True)
-    gradcheck.check(got_g, ref["grads"], ref16["grads"], "api stage1")
+    gradcheck.check(got_g, ref["grads"], ref16["grads"], "api stage1", tol16=None)
     # parameters after the three optimizer steps and BN bookkeeping
     sd = model.state_dict()
     for k, v in P.items():

@@ -44,13 +44,33 @@ def _same_update(sa, sb, what=""):
         assert bad <= max(4, a.numel() // 100), (what, k, bad, a.numel(), float((a - b).abs().max()))
 
 
-def _run_engine(cfg_e, B, seed, perturb, steps, noise, x):
+def _engine_relu_masks(st):
+    """The ReLU masks of the engine's last forward (stored activations > 0) in the call order of the oracle's ReLUs:
+    encoder (3 conv blocks, fc), decoder(z), decoder(z_p) (fc, 3 deconv blocks each), discriminator 'REC' pass
+    (conv0, blocks 1-2) and 'GAN' pass (conv0, blocks 1-3, fc)."""
+    fw = st.fw
+    B = fw["B"]
+    nchw = lambda t: (t.float() > 0).permute(0, 3, 1, 2).float().cpu()
+    rows = lambda t: (t.float() > 0).float().cpu()
+    e, d, c = fw["ectx"], fw["dctx"], fw["sctx"]
+    m = [nchw(e["acts"][i]) for i in (1, 2, 3)] + [rows(e["hfc"])]
+    for g in range(2):
+        sl = slice(g * B, (g + 1) * B)
+        m.append(nchw(d["acts"][0][sl]).reshape(B, -1))          # (H,W,C) engine order -> the reference's (C,H,W)
+        m += [nchw(d["acts"][i][sl]) for i in (1, 2, 3)]
+    rec = [nchw(c["acts"][i]) for i in (0, 1, 2)]
+    return m + rec + [t.clone() for t in rec] + [nchw(c["acts"][3]), rows(c["hfc"])]
+
+
+def _run_engine(cfg_e, B, seed, perturb, steps, noise, x, masks_out=None):
     from fmri_hip.steps import Stage1Step
     st = Stage1Step(cfg_e, DEV)
     st.load_recipe(seed, perturb)
     outs = []
     for s in range(steps):
         st.forward(x.to(DEV), noise[s, 0].to(DEV), noise[s, 1].to(DEV))
+        if s == 0 and masks_out is not None:
+            masks_out.extend(_engine_relu_masks(st))
         st.gate(B)
         st.backward()
         rec = dict(logs=None, outputs={k: v.cpu() for k, v in st.outputs().items()},
@@ -70,7 +90,8 @@ def test_stage1_step_matches_oracle(arch, B, seed, perturb):
     cfg_e = getattr(ArchConfig, arch)()
     steps = 2
     data = O.synth_batch(B, cfg_o, seed=1234, steps=steps)
-    eng = _run_engine(cfg_e, B, seed, perturb, steps, data["noise"], data["x"])
+    masks = []
+    eng = _run_engine(cfg_e, B, seed, perturb, steps, data["noise"], data["x"], masks_out=masks)
     P = O.fill_state(O.vaegan_spec(cfg_o), seed, perturb)
     opts = {n: O.OptState(kind="rmsprop", lr=1e-4) for n in ("encoder", "decoder", "discriminator")}
     report = []
@@ -88,13 +109,18 @@ def test_stage1_step_matches_oracle(arch, B, seed, perturb):
             report.append((s, "fw:" + k, err, 0, err))
             fw_fail = fw_fail or (s == 0 and err > FW_TOL)
         if s == 0:
-            # gradients: tight against the oracle under its 16-bit storage model (same ReLU masks as the engine),
-            # direction / length against the plain fp32 oracle (tests/gradcheck.py)
+            # gradients: tight against the oracle run with the ENGINE's ReLU masks and its 16-bit storage model (what is
+            # left is rounding), direction / length against the plain fp32 oracle (tests/gradcheck.py)
             P16 = O.fill_state(O.vaegan_spec(cfg_o), seed, perturb)
             o16 = {n: O.OptState(kind="rmsprop", lr=1e-4) for n in ("encoder", "decoder", "discriminator")}
             with gradcheck.storage16(O):
-                ref16 = O.stage1_step(P16, o16, data["x"], data["noise"][s, 0], data["noise"][s, 1], cfg_o,
-                                      keep_grads=True)
+                O.RELU_MASKS = list(masks)
+                try:
+                    ref16 = O.stage1_step(P16, o16, data["x"], data["noise"][s, 0], data["noise"][s, 1], cfg_o,
+                                          keep_grads=True)
+                finally:
+                    left, O.RELU_MASKS = len(O.RELU_MASKS), None
+            assert left == 0, left
             gradcheck.check(e["grads"], ref["grads"], ref16["grads"], f"stage1 {arch}")
     for row in report:
         print(row)

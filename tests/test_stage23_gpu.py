@@ -81,7 +81,7 @@ def test_cognitive_step_matches_oracle_and_golden(golden_dir, stage):
             o16 = {n: O.OptState(kind="rmsprop", lr=1e-4) for n in ("encoder", "decoder", "discriminator")}
             with gradcheck.storage16(O):
                 ref16 = ostep(P16, o16, data["fmri"], data["x"], nz, cfg_o, V, keep_grads=True)
-            gradcheck.check(grads, ref["grads"], ref16["grads"], f"stage{stage}")
+            gradcheck.check(grads, ref["grads"], ref16["grads"], f"stage{stage}", tol16=None)
     # BN running statistics / update counters follow the reference's call pattern (golden fingerprints)
     sd = {k: v.cpu() for k, v in st.state_dict().items()}
     keys = [str(k) for k in g["step1/state_keys"]]

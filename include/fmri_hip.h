@@ -84,6 +84,20 @@ typedef struct fmri_epilogue {
     float* stat_part;        /* NULL: no statistics */
     int32_t stat_rows_cap;   /* rows allocated per group */
     int32_t stat_group_n;    /* images per statistics group, 0 = all images */
+    /* BatchNorm (+ReLU) BACKWARD statistics, for the data gradient that produces the cotangent dy of a BatchNorm output
+     * (autograd of models/vae_gan.py:28-29,58-59): with the saved forward input bn_x of that BatchNorm (geometry of
+     * `out`), xhat = (x - mean)*rstd and on = !relu || xhat*gamma + beta > 0, `out` receives g = on ? dy : 0 and the rows
+     * hold (sum g, sum g*xhat).  Group i (<= 4: cotangent streams / decoder calls stacked along the batch) reads x from
+     * image bn_x_img0[i] on, with the batch statistics of its forward call.  NULL bn_x: forward statistics.  Requires
+     * stat_part, no bias / activation; if *ep_done comes back 0 `out` holds the plain dy (use fmri_bn_bwd_reduce). */
+    const void* bn_x;
+    const float* bn_gamma;
+    const float* bn_beta;
+    const float* bn_mean[4];
+    const float* bn_rstd[4];
+    int32_t bn_x_img0[4];
+    int32_t bn_relu;
+    int32_t reserved;
 } fmri_epilogue;
 int fmri_igemm_ep(const void* in, const void* w, void* out, const float* bias, const void* zero16, int N, int Hi,
                   int Wi, int Ci, int Ho, int Wo, int CoStore, int Co, int k, int stride, int pad, int mode, int act,
@@ -157,6 +171,12 @@ int fmri_bn_fold_finalize(const float* stat_part, int rows, int C, float* scratc
                           int64_t* num_batches_tracked, void* stream);
 int fmri_bn_fold(const float* stat_part, int rows, int C, float* scratch, float* sums2C, void* stream);
 int fmri_bn_fold_scratch_floats(int C);
+/* BatchNorm-backward rows (fmri_epilogue.bn_x) of `groups` cotangent groups, stat_part [groups][rows_cap][2][C], folded
+ * into sums [groups][2][C] = per group [sum g | sum g*xhat] (the sums4C layout of fmri_bn_bwd_apply2 for two groups);
+ * dbeta / dgamma (may be NULL) += gscale * the sums of group param_group.  scratch: groups *
+ * fmri_bn_fold_scratch_floats(C) floats. */
+int fmri_bn_bwd_fold(const float* stat_part, int rows, int rows_cap, int C, int groups, float* scratch, float* sums,
+                     float* dbeta, float* dgamma, float gscale, int param_group, void* stream);
 int fmri_bn_apply(const void* x, void* y, int M, int C, const float* scale, const float* shift, int relu,
                   void* stream);
 int fmri_bn_bwd_reduce(const void* x, const void* dy, int M, int C, const float* mean, const float* rstd,

@@ -213,6 +213,68 @@ def test_conv_epilogue_batchnorm_statistics(kind, cin, cout, stride, H, op, N, g
     assert torch.equal(first, layer._stat_part[:groups, :layer._stat_rows])
 
 
+EPI_BWD_CASES = [
+    # kind, cin, cout, H (layer input), out_pad, N, groups
+    ("conv", 128, 256, 16, 0, 4, 1),        # conv dgrad = igemm_tc5<128>, two images per tile
+    ("conv", 128, 256, 32, 0, 4, 2),        # igemm_tc5<128>, double-buffered window, two cotangent streams
+    ("conv", 64, 128, 32, 0, 6, 3),         # igemm_tc5<64>, three groups (decoder entries)
+    ("conv", 128, 256, 26, 0, 3, 1),        # partial tiles
+    ("deconv", 256, 128, 16, 1, 4, 2),      # deconv dgrad = stride-2 convolution on the generic kernel
+    ("deconv", 128, 64, 16, 1, 128, 2),     # ... its 256 x 256 tile
+]
+
+
+@pytest.mark.parametrize("kind,cin,cout,H,op,N,groups", EPI_BWD_CASES)
+def test_dgrad_epilogue_batchnorm_backward(kind, cin, cout, H, op, N, groups):
+    """fmri_epilogue.bn_x: the data gradient's epilogue applies the ReLU mask of the BatchNorm block in front of the
+    layer and emits its backward sums; BatchNorm.backward / backward2 from those rows equals the separate reduction."""
+    from fmri_hip.ops import ConvLayer, BatchNorm
+    torch.manual_seed(cin + cout + H + N)
+    shape = (cout, cin, 5, 5) if kind == "conv" else (cin, cout, 5, 5)
+    g = _G({"w": _h(torch.randn(*shape) * 0.05), "bn.weight": torch.rand(cin) + 0.5, "bn.bias": torch.randn(cin) * 0.3})
+    g.bufs = {"bn.running_mean": torch.zeros(cin, device=DEV), "bn.running_var": torch.ones(cin, device=DEV),
+              "bn.num_batches_tracked": torch.zeros((), dtype=torch.int64, device=DEV)}
+    layer = ConvLayer(g, "w", None, kind, cin, cout, 5, 2, 2, op)
+    bn = BatchNorm(g, "bn.", cin)
+    B = N // groups
+    # forward of the BatchNorm block in front of the layer: `groups` calls over B images each, two of them on the SAME
+    # saved tensor when groups >= 2 (cotangent streams), the last on its own
+    nfw = 1 if groups < 3 else 2
+    raw = torch.randn(nfw * B, H, H, cin, device=DEV).half()
+    svs = [bn.forward(raw[i * B:(i + 1) * B], True, 0)[1] for i in range(nfw)]
+    fwd_of = [0] * groups if groups < 3 else [0, 0, 1]
+    Ho, Wo = layer.out_hw(H, H)
+    dy = (torch.randn(N, Ho, Wo, layer.coutp, device=DEV) * 0.5).half()
+    grp = [(fwd_of[e] * B, svs[fwd_of[e]]) for e in range(groups)]
+    d_plain = layer.dgrad(dy, H, H)
+    d_mask = layer.dgrad(dy, H, H, bn_bwd=dict(bn=bn, x=raw, groups=grp))
+    stat = layer.take_bwd_stats()
+    assert stat is not None
+    rows = lambda t, e: t[e * B:(e + 1) * B]
+    e = 0
+    while e < groups:
+        xg = rows(raw, fwd_of[e])
+        if e + 1 < groups and fwd_of[e + 1] == fwd_of[e]:
+            a, sa = bn.backward2(xg, d_plain[e * B:(e + 2) * B], svs[fwd_of[e]], True)
+            b, sb = bn.backward2(xg, d_mask[e * B:(e + 2) * B], svs[fwd_of[e]], True, stat=stat, stat_group=e)
+            e += 2
+        else:
+            a, sa = bn.backward(xg, rows(d_plain, e), svs[fwd_of[e]], True)
+            b, sb = bn.backward(xg, rows(d_mask, e), svs[fwd_of[e]], True, stat=stat, stat_group=e)
+            e += 1
+        ref = sa.double().cpu()
+        tol = 2e-4 * ref.abs().max() + 1e-4
+        assert ((sb.double().cpu() - ref).abs() <= tol).all(), (float((sb.double().cpu() - ref).abs().max()), float(tol))
+        assert ((a.float() - b.float()).abs() <= 2e-3 * a.float().abs().clamp_min(float(a.float().abs().mean()))).all()
+    # the masked output is the plain one with the ReLU-off elements zeroed
+    gamma, beta = g.views["bn.weight"], g.views["bn.bias"]
+    for e in range(groups):
+        sv = svs[fwd_of[e]]
+        xh = (rows(raw, fwd_of[e]).float() - sv.mean) * sv.rstd
+        on = (xh * gamma + beta) > 0
+        assert torch.equal(rows(d_mask, e), torch.where(on, rows(d_plain, e), torch.zeros_like(rows(d_plain, e))))
+
+
 def test_conv_bias_relu_tanh_epilogues():
     from fmri_hip.ops import ConvLayer, ACT_RELU, ACT_TANH
     torch.manual_seed(5)

@@ -151,10 +151,25 @@ int fmri_igemm_ep(const void* in, const void* w, void* out, const float* bias, c
     StatEpi se;
     se.part = nullptr; se.rows_cap = 0; se.C = CoStore; se.group_n = 0;
     se.tpg[0] = se.tpg[1] = se.tpg[2] = se.tpg[3] = 0;
+    BnBwdEpi bb;
+    memset(&bb, 0, sizeof(bb));
     if (ep && ep->stat_part) {
         if (ep->stat_rows_cap < 1 || ep->stat_group_n < 0 || out_f32 || (ep->stat_group_n > 0 && N % ep->stat_group_n))
             return FMRI_E_BADARG;
         se.part = ep->stat_part; se.rows_cap = ep->stat_rows_cap; se.group_n = ep->stat_group_n;
+        if (ep->bn_x) {
+            // BatchNorm backward: <= 4 groups, every used group fully described; no bias / activation
+            const int groups = se.group_n > 0 ? N / se.group_n : 1;
+            if (groups > 4 || !ep->bn_gamma || !ep->bn_beta || bias || act != FMRI_ACT_NONE || Co != CoStore)
+                return FMRI_E_BADARG;
+            bb.x = (const half_t*)ep->bn_x; bb.gamma = ep->bn_gamma; bb.beta = ep->bn_beta; bb.relu = ep->bn_relu;
+            for (int i = 0; i < groups; ++i) {
+                if (!ep->bn_mean[i] || !ep->bn_rstd[i] || ep->bn_x_img0[i] < 0) return FMRI_E_BADARG;
+                bb.mean[i] = ep->bn_mean[i]; bb.rstd[i] = ep->bn_rstd[i]; bb.x_img0[i] = ep->bn_x_img0[i];
+            }
+        }
+    } else if (ep && ep->bn_x) {
+        return FMRI_E_BADARG;
     }
     if (N < 1 || Ci < 8 || (Ci & 7) || CoStore < 4 || (CoStore & 3) || Co < 1 || Co > CoStore) return FMRI_E_BADARG;
     if (bn_tile != 32 && bn_tile != 64 && bn_tile != 128) return FMRI_E_UNSUPPORTED;
@@ -167,6 +182,7 @@ int fmri_igemm_ep(const void* in, const void* w, void* out, const float* bias, c
     a.N = N; a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.Ho = Ho; a.Wo = Wo; a.CoStore = CoStore; a.Co = Co;
     a.act = act; a.splits = splits; a.slab_stride = slab_stride;
     a.st = se; a.st.part = nullptr;
+    a.bb = bb;
     a.fdCi = make_fastdiv((uint32_t)Ci);
     a.fdCpt = make_fastdiv((uint32_t)(Ci >= 64 ? Ci / 64 : 1));
     int maxM = 0;
@@ -271,6 +287,7 @@ int fmri_igemm_ep(const void* in, const void* w, void* out, const float* bias, c
         q.fdIHW = make_fastdiv((uint32_t)(q.IH * q.IW));
         q.fdIW = make_fastdiv((uint32_t)q.IW);
         q.st = se;
+        q.bb = bb;
         // statistics: one row per tile; groups must not share a tile
         const int tpi5 = q.tiles_y * q.tiles_x;
         if (se.part) {
@@ -278,6 +295,7 @@ int fmri_igemm_ep(const void* in, const void* w, void* out, const float* bias, c
             q.st.tpg[0] = se.group_n > 0 ? (se.group_n / q.IPB) * tpi5 : q.ntiles;
             if (q.st.tpg[0] > se.rows_cap) q.st.part = nullptr;
         }
+        if (!q.st.part) q.bb.x = nullptr;       // no statistics rows: plain output (*ep_done = 0 tells the caller)
         if (ok && q.ntiles > 0) {
             const int r = igemm_tc5_launch(q, bn_tile, copad, S(stream));
             if (r == OK && ep_done && q.st.part) *ep_done = q.st.tpg[0];
@@ -428,6 +446,7 @@ int fmri_igemm_ep(const void* in, const void* w, void* out, const float* bias, c
     } else {
         a.st.part = nullptr;
     }
+    if (!a.st.part) a.bb.x = nullptr;           // no statistics rows: plain output (*ep_done = 0 tells the caller)
     const int r = igemm_launch(a, maxM, bn_tile, copad, out_f32 != 0, S(stream));
     if (r == OK && ep_done && a.st.part) *ep_done = prows;
     return r;
@@ -607,6 +626,13 @@ int fmri_bn_fold(const float* stat_part, int rows, int C, float* scratch, float*
     return bn_fold_launch(stat_part, rows, 2 * C, scratch, sums2C, S(stream));
 }
 int fmri_bn_fold_scratch_floats(int C) { return C < 1 ? 0 : FOLD_STAGE_ROWS * 2 * C; }
+int fmri_bn_bwd_fold(const float* stat_part, int rows, int rows_cap, int C, int groups, float* scratch, float* sums,
+                     float* dbeta, float* dgamma, float gscale, int param_group, void* stream) {
+    if (!stat_part || rows < 1 || rows > rows_cap || C < 1 || groups < 1 || groups > 4 || !scratch || !sums)
+        return FMRI_E_BADARG;
+    return bn_bwd_fold_launch(stat_part, rows, rows_cap, C, groups, scratch, sums, dbeta, dgamma, gscale, param_group,
+                              S(stream));
+}
 int fmri_bn_apply(const void* x, void* y, int M, int C, const float* scale, const float* shift, int relu,
                   void* stream) {
     if (!x || !y || (C & 7)) return FMRI_E_BADARG;

@@ -73,6 +73,22 @@ struct StatEpi {
     int32_t tpg[4];        // row tiles per group of class c (igemm_tc5: [0] = tiles per group, all classes in one tile)
 };
 
+// BatchNorm + ReLU BACKWARD statistics in the epilogue of the data-gradient contraction that produces the cotangent dy
+// of a BatchNorm output (dgrad of the next layer):  with the saved forward tensor x (same geometry as the contraction's
+// output), xhat = (x - mean)*rstd and on = !relu || xhat*gamma + beta > 0, the epilogue stores g = on ? dy : 0 and
+// emits the StatEpi rows with (sum g, sum g*xhat) instead of (sum x, sum x^2).  Statistics group i (image / group_n:
+// cotangent streams or decoder calls stacked along the batch) reads x from image x_img0[i] on and uses the batch
+// statistics mean[i] / rstd[i] of the forward call it belongs to.
+struct BnBwdEpi {
+    const half_t* x;       // null: forward statistics (StatEpi only)
+    const float* gamma;
+    const float* beta;
+    const float* mean[4];
+    const float* rstd[4];
+    int32_t x_img0[4];
+    int32_t relu, pad0;
+};
+
 struct IgemmClass {
     int32_t Yc, Xc;        // rows / cols of the output sub-grid per image
     int32_t oy0, ox0;      // output offset of the class
@@ -100,6 +116,7 @@ struct IgemmArgs {
     FastDiv fdCi;
     FastDiv fdCpt;           // divide by Ci/64 (K-steps per tap) when Ci % 64 == 0
     StatEpi st;              // BatchNorm statistics epilogue (fp16 output only)
+    BnBwdEpi bb;             // ... of a BatchNorm backward (with st)
     IgemmClass cls[4];
 };
 
@@ -178,6 +195,7 @@ struct Tc5Args {
     uint32_t in_bytes, w_bytes;                  // buffer descriptor ranges (in_bytes < 2^31)
     FastDiv fdTPI, fdTX, fdIHW, fdIW;
     StatEpi st;
+    BnBwdEpi bb;
     Tc5Class cls[4];
 };
 
@@ -305,23 +323,29 @@ __device__ __forceinline__ float row16_sum(float v) {
 // BatchNorm statistics out of MFMA accumulators laid out D[i = channel][j = pixel] (16x16x32, weights as the A operand):
 // lane (fq = lane >> 4, frow = lane & 15) holds, per 16-channel tile tn, the per-lane sums over its pixels of channels
 // tn*16 + fq*4 + 0..3.  The 16 lanes of a DPP row hold the same channels of 16 different pixels: one row sum each, then
-// lane (fq, frow) owns channel (frow >> 2)*16 + fq*4 + (frow & 3) of the wave's BNW = 16*TN channels.  The WM waves that
-// cover the same channels (different pixel rows of the block tile) meet in `scratch` (LDS, (WM-1)*WN*128 floats, free
-// after the K loop) in a fixed order, and the wm == 0 waves store the block's row: row[co] = sum, row[C + co] = sum of
-// squares.  Called by every thread of the block.
-template <int TN, int WM, int WN>
-__device__ __forceinline__ void stat_store(const f4 (&ssum)[TN], const f4 (&ssq)[TN], int lane, int wm, int wn,
-                                           int co_block, float* scratch, float* row, int C) {
-    const int frow = lane & 15, fq = lane >> 4;
-    float vs = 0.f, vq = 0.f;
+// lane (fq, frow) owns channel (frow >> 2)*16 + fq*4 + (frow & 3) of the wave's 16*TN channels and adds the two sums
+// of that channel to (vs, vq).
+template <int TN>
+__device__ __forceinline__ void stat_lane_add(const f4 (&ssum)[TN], const f4 (&ssq)[TN], int lane, float& vs,
+                                              float& vq) {
+    const int frow = lane & 15;
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
             const float s = row16_sum(ssum[tn][rg]);
             const float q = row16_sum(ssq[tn][rg]);
-            if (frow == tn * 4 + rg) { vs = s; vq = q; }
+            if (frow == tn * 4 + rg) { vs += s; vq += q; }
         }
+}
+
+// The per-lane sums of stat_lane_add -> the block's StatEpi row.  The WM waves that cover the same channels (different
+// pixel rows of the block tile) meet in `scratch` (LDS, (WM-1)*WN*128 floats, free after the K loop) in a fixed order,
+// and the wm == 0 waves store row[co] = sum, row[C + co] = second sum.  Called by every thread of the block.
+template <int TN, int WM, int WN>
+__device__ __forceinline__ void stat_store(float vs, float vq, int lane, int wm, int wn, int co_block, float* scratch,
+                                           float* row, int C) {
+    const int frow = lane & 15, fq = lane >> 4;
     const int ch = (frow >> 2) * 16 + fq * 4 + (frow & 3);      // channel within the wave's 16*TN
     __syncthreads();                                             // everyone is done with the operand tiles in LDS
     if (WM > 1 && wm > 0) {
@@ -343,6 +367,33 @@ __device__ __forceinline__ void stat_store(const f4 (&ssum)[TN], const f4 (&ssq)
             row[C + co] = vq;
         }
     }
+}
+
+// BnBwdEpi fields of statistics group g (wave-uniform), selected without indexing the kernel-argument arrays with a
+// run-time value (which makes the compiler copy them to scratch)
+__device__ __forceinline__ void bn_bwd_group(const BnBwdEpi& b, int g, const float*& mean, const float*& rstd,
+                                             int& x_img0) {
+    mean = b.mean[0]; rstd = b.rstd[0]; x_img0 = b.x_img0[0];
+    if (g == 1) { mean = b.mean[1]; rstd = b.rstd[1]; x_img0 = b.x_img0[1]; }
+    if (g == 2) { mean = b.mean[2]; rstd = b.rstd[2]; x_img0 = b.x_img0[2]; }
+    if (g == 3) { mean = b.mean[3]; rstd = b.rstd[3]; x_img0 = b.x_img0[3]; }
+}
+
+// BnBwdEpi transform of 4 consecutive channels of one pixel: v = dy (fp32 accumulators), xr = saved forward values;
+// returns the stored g and adds (g, g*xhat) to the running sums.
+__device__ __forceinline__ h4 bn_bwd_mask4(const f4& v, const h4& xr, const f4& mu, const f4& rs, const f4& ga,
+                                           const f4& be, int relu, f4& s0, f4& s1) {
+    h4 hv;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float xh = ((float)xr[r] - mu[r]) * rs[r];
+        const bool on = !relu || (xh * ga[r] + be[r] > 0.f);
+        hv[r] = (half_t)(on ? v[r] : 0.f);
+        const float g = (float)hv[r];
+        s0[r] += g;
+        s1[r] += g * xh;
+    }
+    return hv;
 }
 
 __device__ __forceinline__ float act_apply(float v, int act) {

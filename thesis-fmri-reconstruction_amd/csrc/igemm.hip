@@ -240,49 +240,75 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmArgs a) 
 
     // ---- epilogue: D[i = co][j = pixel]; lane owns pixel (lane&15), channels (lane>>4)*4 .. +3
     const bool stats = !OUT_F32 && a.st.part != nullptr;
+    const bool bwd = stats && a.bb.x != nullptr;          // BatchNorm backward statistics + ReLU mask (BnBwdEpi)
+    int sgrp = 0;                                          // statistics group of the block's rows
+    if (stats && a.st.group_n > 0) sgrp = bx / a.st.tpg[icls];
     f4 ssum[TN], ssq[TN];
 #pragma unroll
     for (int i = 0; i < TN; ++i) { ssum[i] = (f4){0.f, 0.f, 0.f, 0.f}; ssq[i] = (f4){0.f, 0.f, 0.f, 0.f}; }
+    int64_t opix[TM];                                      // output pixel of row tile tm, -1: outside
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
         const int m = m0 + wm * (BM / WM) + tm * 16 + frow;
+        opix[tm] = -1;
         if (m >= c.M) continue;
         const uint32_t n = fd_div((uint32_t)m, c.fdYX);
         const uint32_t rem = (uint32_t)m - n * (uint32_t)YX;
         const uint32_t y = fd_div(rem, c.fdX);
         const uint32_t x = rem - y * (uint32_t)c.Xc;
-        const int64_t opix = ((int64_t)n * a.Ho + (y * a.os + c.oy0)) * a.Wo + (x * a.os + c.ox0);
+        opix[tm] = ((int64_t)n * a.Ho + (y * a.os + c.oy0)) * a.Wo + (x * a.os + c.ox0);
+    }
+    const float* gmean = nullptr;
+    const float* grstd = nullptr;
+    int gimg0 = 0;
+    if (bwd) bn_bwd_group(a.bb, sgrp, gmean, grstd, gimg0);
+    const int64_t xshift = bwd ? (int64_t)(gimg0 - sgrp * a.st.group_n) * a.Ho * a.Wo : 0;
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const int co = co0 + wn * (BN / WN) + tn * 16 + fq * 4;
-            if (co >= a.CoStore) continue;
+    for (int tn = 0; tn < TN; ++tn) {
+        const int co = co0 + wn * (BN / WN) + tn * 16 + fq * 4;
+        if (co >= a.CoStore) continue;
+        f4 mu, rs, ga, be;
+        if (bwd) {
+            mu = *(const f4*)(gmean + co);
+            rs = *(const f4*)(grstd + co);
+            ga = *(const f4*)(a.bb.gamma + co);
+            be = *(const f4*)(a.bb.beta + co);
+        }
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            if (opix[tm] < 0) continue;
             f4 v = acc[tn][tm];
             if constexpr (OUT_F32) {
-                float* o = (float*)a.out + (int64_t)split * a.slab_stride + opix * a.CoStore + co;
+                float* o = (float*)a.out + (int64_t)split * a.slab_stride + opix[tm] * a.CoStore + co;
                 *(f4*)o = v;
             } else {
                 h4 hv;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float f = v[r];
-                    if (co + r < a.Co) {
-                        if (a.bias) f += a.bias[co + r];
-                        f = act_apply(f, a.act);
-                    } else {
-                        f = 0.f;
-                    }
-                    hv[r] = (half_t)f;
-                }
-                *(h4*)((half_t*)a.out + opix * a.CoStore + co) = hv;
-                if (stats) {
-                    // BatchNorm statistics of the STORED values (see StatEpi)
+                if (bwd) {
+                    const h4 xr = *(const h4*)(a.bb.x + (opix[tm] + xshift) * a.CoStore + co);
+                    hv = bn_bwd_mask4(v, xr, mu, rs, ga, be, a.bb.relu, ssum[tn], ssq[tn]);
+                } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float f = (float)hv[r];
-                        ssum[tn][r] += f;
-                        ssq[tn][r] += f * f;
+                        float f = v[r];
+                        if (co + r < a.Co) {
+                            if (a.bias) f += a.bias[co + r];
+                            f = act_apply(f, a.act);
+                        } else {
+                            f = 0.f;
+                        }
+                        hv[r] = (half_t)f;
+                    }
+                    if (stats) {
+                        // BatchNorm statistics of the STORED values (see StatEpi)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float f = (float)hv[r];
+                            ssum[tn][r] += f;
+                            ssq[tn][r] += f * f;
+                        }
                     }
                 }
+                *(h4*)((half_t*)a.out + opix[tm] * a.CoStore + co) = hv;
             }
         }
     }
@@ -290,14 +316,12 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmArgs a) 
         if (stats) {        // block-uniform
             // row of this block: classes one after the other, a group's tiles dense (the host guarantees that no tile
             // straddles two groups)
-            int g = 0, prow = bx;
-            if (a.st.group_n > 0) {
-                g = bx / a.st.tpg[icls];
-                prow = bx - g * a.st.tpg[icls];
-            }
+            int prow = bx - sgrp * a.st.tpg[icls];
             for (int i = 0; i < icls; ++i) prow += a.st.tpg[i];
-            float* row = a.st.part + ((size_t)g * a.st.rows_cap + prow) * 2 * a.st.C;
-            stat_store<TN, WM, WN>(ssum, ssq, lane, wm, wn, co0, (float*)smem, row, a.st.C);
+            float* row = a.st.part + ((size_t)sgrp * a.st.rows_cap + prow) * 2 * a.st.C;
+            float vs = 0.f, vq = 0.f;
+            stat_lane_add<TN>(ssum, ssq, lane, vs, vq);
+            stat_store<TN, WM, WN>(vs, vq, lane, wm, wn, co0, (float*)smem, row, a.st.C);
         }
     }
 }

@@ -42,6 +42,14 @@ __device__ __forceinline__ void static_for(F&& f) {
 // Offsets >= num_records read as zero.  Issued from inline asm so that the compiler does not serialise later LDS reads
 // behind it (see glds16_raw in common.h); the caller owns the vmcnt / barrier protocol.
 __device__ __forceinline__ void bdma16(v4i srd, uint32_t voff, uint32_t soff, uint32_t lds) {
+    // under scalar-register pressure the compiler parks the descriptor in vector registers and would hand those to the
+    // "s" operand: name every word wave-uniform (free when it already sits in SGPRs)
+    srd.x = __builtin_amdgcn_readfirstlane(srd.x);
+    srd.y = __builtin_amdgcn_readfirstlane(srd.y);
+    srd.z = __builtin_amdgcn_readfirstlane(srd.z);
+    srd.w = __builtin_amdgcn_readfirstlane(srd.w);
+    soff = __builtin_amdgcn_readfirstlane(soff);
+    lds = __builtin_amdgcn_readfirstlane(lds);
     asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
                  ::"v"(voff), "s"(srd), "s"(soff), "s"(lds)
                  : "memory");
@@ -58,7 +66,8 @@ __device__ __forceinline__ void wait_vm() {
 
 // NSL = 4 KB DMA slices per window chunk: 6 -> two window buffers (80 KB LDS with the 128-row weight ring),
 // 7 (two 10 x 10 image windows per tile) -> one buffer, reloaded between chunks.
-template <int BN, int NSL, bool STATS>
+// STATS: 0 none, 1 BatchNorm forward statistics (StatEpi), 2 BatchNorm backward statistics + ReLU mask (BnBwdEpi)
+template <int BN, int NSL, int STATS>
 __global__ __launch_bounds__(256, 2) void igemm_tc5_kernel(const Tc5Args a) {
     constexpr int BM = 128, WM = 2, WN = 2;
     constexpr int TM = BM / WM / 16;            // 4
@@ -182,10 +191,8 @@ __global__ __launch_bounds__(256, 2) void igemm_tc5_kernel(const Tc5Args a) {
     };
     zero_acc();
 
-    // BatchNorm statistics of this lane's 4 x TN channels over its valid pixels, all classes
-    f4 ssum[TN], ssq[TN];
-#pragma unroll
-    for (int i = 0; i < TN; ++i) { ssum[i] = (f4){0.f, 0.f, 0.f, 0.f}; ssq[i] = (f4){0.f, 0.f, 0.f, 0.f}; }
+    // BatchNorm statistics of the lane's channel (see stat_lane_add) over the block's valid pixels, all classes
+    float vsum = 0.f, vsq = 0.f;
 
     auto compute = [&](auto SHIFT_, auto PB_, auto STG_) __attribute__((always_inline)) {
         constexpr int sh = decltype(SHIFT_)::value, pb = decltype(PB_)::value, stg = decltype(STG_)::value;
@@ -228,9 +235,12 @@ __global__ __launch_bounds__(256, 2) void igemm_tc5_kernel(const Tc5Args a) {
     // ---- epilogue of one class: D[i = co][j = class-grid position] -> output pixel (2y + cy, 2x + cx).  No bias /
     // activation here: every layer of this geometry is followed by BatchNorm or is a data gradient (the launcher routes
     // anything else to igemm_win.hip).
+    const int sgrp = (STATS != 0 && a.st.group_n > 0) ? (grp * a.IPB) / a.st.group_n : 0;     // statistics group of the tile
     auto epilogue = [&](int cls) __attribute__((always_inline)) {
         const int cy = cls >> 1, cx = cls & 1;
         const int Yc = a.cls[cls].Yc, Xc = a.cls[cls].Xc;
+        // output pixel (element offset / CoStore) of row tile tm, -1: outside
+        int64_t opix[TM];
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
             const int r = wm * (BM / WM) + tm * 16 + frow;
@@ -238,27 +248,62 @@ __global__ __launch_bounds__(256, 2) void igemm_tc5_kernel(const Tc5Args a) {
             const int rr = r & ((1 << tp_log2) - 1);
             const int n = grp * a.IPB + ip;
             const int y = y0 + (rr >> a.pw_log2), x = x0 + tile_x(rr);
-            if (n >= a.N || y >= Yc || x >= Xc) continue;
-            const int64_t opix = ((int64_t)n * a.Ho + (y * 2 + cy)) * a.Wo + (x * 2 + cx);
-            half_t* orow = a.out + opix * a.CoStore;
+            opix[tm] = (n >= a.N || y >= Yc || x >= Xc) ? -1 : ((int64_t)n * a.Ho + (y * 2 + cy)) * a.Wo + (x * 2 + cx);
+        }
+        // BnBwdEpi: the saved forward tensor starts x_img0[group] images in, the cotangent group_n * group images
+        const float* gmean = nullptr;
+        const float* grstd = nullptr;
+        int gimg0 = 0;
+        if constexpr (STATS == 2) bn_bwd_group(a.bb, sgrp, gmean, grstd, gimg0);
+        const int64_t xshift = STATS == 2 ? (int64_t)(gimg0 - sgrp * a.st.group_n) * a.Ho * a.Wo : 0;
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-                const int co = co0 + wn * (BN / WN) + tn * 16 + fq * 4;
-                if (co >= a.CoStore) continue;
+        for (int tn = 0; tn < TN; ++tn) {
+            const int co = co0 + wn * (BN / WN) + tn * 16 + fq * 4;
+            if (co >= a.CoStore) continue;
+            f4 mu, rs, ga, be;
+            // sums of this lane's 4 channels over its pixels: reduced to the lane's one channel right after the tile
+            // column (keeps the epilogue's register peak below what would spill loop-carried values)
+            f4 s0 = (f4){0.f, 0.f, 0.f, 0.f}, s1 = (f4){0.f, 0.f, 0.f, 0.f};
+            if constexpr (STATS == 2) {
+                mu = *(const f4*)(gmean + co);
+                rs = *(const f4*)(grstd + co);
+                ga = *(const f4*)(a.bb.gamma + co);
+                be = *(const f4*)(a.bb.beta + co);
+            }
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                if (opix[tm] < 0) continue;
                 const f4 v = acc[tn][tm];
                 h4 hv;
+                if constexpr (STATS == 2) {
+                    const h4 xr = *(const h4*)(a.bb.x + (opix[tm] + xshift) * a.CoStore + co);
+                    hv = bn_bwd_mask4(v, xr, mu, rs, ga, be, a.bb.relu, s0, s1);
+                } else {
 #pragma unroll
-                for (int rg = 0; rg < 4; ++rg) hv[rg] = (half_t)(co + rg < a.Co ? v[rg] : 0.f);
-                *(h4*)(orow + co) = hv;
-                if constexpr (STATS) {
-                    // statistics of the STORED (fp16-rounded) values: what the consumers and the BN backward see
+                    for (int rg = 0; rg < 4; ++rg) hv[rg] = (half_t)(co + rg < a.Co ? v[rg] : 0.f);
+                    if constexpr (STATS == 1) {
+                        // statistics of the STORED (fp16-rounded) values: what the consumers and the BN backward see
 #pragma unroll
-                    for (int rg = 0; rg < 4; ++rg) {
-                        const float f = (float)hv[rg];
-                        ssum[tn][rg] += f;
-                        ssq[tn][rg] += f * f;
+                        for (int rg = 0; rg < 4; ++rg) {
+                            const float f = (float)hv[rg];
+                            s0[rg] += f;
+                            s1[rg] += f * f;
+                        }
                     }
                 }
+                *(h4*)(a.out + opix[tm] * a.CoStore + co) = hv;
+            }
+            if constexpr (STATS != 0) {
+                // 16-lane row sums; lane (fq, frow) owns channel (frow >> 2)*16 + fq*4 + (frow & 3) (stat_store)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const float ra = row16_sum(s0[rg]);
+                    const float rb = row16_sum(s1[rg]);
+                    if (frow == tn * 4 + rg) { vsum += ra; vsq += rb; }
+                }
+                // one tile column at a time: without this the compiler issues every column's loads up front and the
+                // registers they occupy push loop-carried values into scratch
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
@@ -339,17 +384,14 @@ __global__ __launch_bounds__(256, 2) void igemm_tc5_kernel(const Tc5Args a) {
     run_class(std::integral_constant<int, 3>{});
 
     // ---- BatchNorm statistics of the block (all four classes): its own row of the partial buffer
-    if constexpr (STATS) {
-        const int tile0 = grp * a.tiles_y * a.tiles_x;            // first tile of this image group
-        const int g = a.st.group_n > 0 ? (grp * a.IPB) / a.st.group_n : 0;
-        const int prow = bx - g * a.st.tpg[0];
-        (void)tile0;
-        float* row = a.st.part + ((size_t)g * a.st.rows_cap + prow) * 2 * a.st.C;
-        stat_store<TN, WM, WN>(ssum, ssq, lane, wm, wn, co0, (float*)smem, row, a.st.C);
+    if constexpr (STATS != 0) {
+        const int prow = bx - sgrp * a.st.tpg[0];
+        float* row = a.st.part + ((size_t)sgrp * a.st.rows_cap + prow) * 2 * a.st.C;
+        stat_store<TN, WM, WN>(vsum, vsq, lane, wm, wn, co0, (float*)smem, row, a.st.C);
     }
 }
 
-template <int BN, int NSL, bool STATS>
+template <int BN, int NSL, int STATS>
 static int launch_tc5(const Tc5Args& a, int copad, hipStream_t st) {
     auto kern = igemm_tc5_kernel<BN, NSL, STATS>;
     constexpr int PBUFS = NSL <= 6 ? 2 : 1;
@@ -364,7 +406,8 @@ static int launch_tc5(const Tc5Args& a, int copad, hipStream_t st) {
 
 template <int BN, int NSL>
 static int launch_tc5s(const Tc5Args& a, int copad, hipStream_t st) {
-    return a.st.part ? launch_tc5<BN, NSL, true>(a, copad, st) : launch_tc5<BN, NSL, false>(a, copad, st);
+    if (!a.st.part) return launch_tc5<BN, NSL, 0>(a, copad, st);
+    return a.bb.x ? launch_tc5<BN, NSL, 2>(a, copad, st) : launch_tc5<BN, NSL, 1>(a, copad, st);
 }
 
 // bias == null and act == none only (see the epilogue); nslice in {6, 7}; bn_tile in {64, 128}

@@ -77,6 +77,8 @@ int bn_fold_finalize_launch(const float* part, int rows, int C, float* scratch, 
                             float* rv, float* mean, float* rstd, float* scale, float* shift, long long* nbt,
                             hipStream_t st);
 int bn_fold_launch(const float* part, int rows, int n, float* scratch, float* sums, hipStream_t st);
+int bn_bwd_fold_launch(const float* part, int rows, int rows_cap, int C, int G, float* scratch, float* sums,
+                       float* dbeta, float* dgamma, float gscale, int pgroup, hipStream_t st);
 int bn_finalize_launch(const float* sums, int C, float count, const float* gamma, const float* beta, float eps,
                        float momentum, int updates, float* rm, float* rv, float* mean, float* rstd, float* scale,
                        float* shift, long long* nbt, hipStream_t st);

@@ -170,7 +170,10 @@ __global__ __launch_bounds__(1024) void fold_partials_kernel(const float* __rest
 // stage 1 of a long fold (statistics rows written by a contraction's epilogue, StatEpi): block (x, y) sums rows
 // [y*per, (y+1)*per) of columns 32x .. 32x+31 into out[y][n].  Same lane layout as fold_partials_kernel.
 __global__ __launch_bounds__(1024) void fold_rows_kernel(const float* __restrict__ part, int nparts, int n, int per,
-                                                         float* __restrict__ out) {
+                                                         float* __restrict__ out, int64_t part_gstride,
+                                                         int64_t out_gstride) {
+    part += blockIdx.z * part_gstride;      // statistics group
+    out += blockIdx.z * out_gstride;
     __shared__ float red[32][33];
     const int cx = threadIdx.x & 31, gy = threadIdx.x >> 5;
     const int i = blockIdx.x * 32 + cx;
@@ -194,6 +197,43 @@ __global__ __launch_bounds__(1024) void fold_rows_kernel(const float* __restrict
 #pragma unroll
         for (int r = 0; r < 32; ++r) s += red[r][cx];
         out[(int64_t)blockIdx.y * n + i] = s;
+    }
+}
+
+// BatchNorm-backward statistics rows of a contraction's epilogue (BnBwdEpi), G cotangent groups at once: block (x, g)
+// folds columns 32x .. 32x+31 of group g's rows into sums[g][n] (n = 2C: sum g | sum g*xhat); the group `pgroup` also
+// accumulates the parameter gradients d beta += gscale * sum g, d gamma += gscale * sum g*xhat (one writer per element).
+__global__ __launch_bounds__(1024) void fold_groups_kernel(const float* __restrict__ part, int nparts, int n,
+                                                           int64_t part_gstride, float* __restrict__ sums,
+                                                           float* __restrict__ dbeta, float* __restrict__ dgamma,
+                                                           float gscale, int pgroup) {
+    __shared__ float red[32][33];
+    part += blockIdx.y * part_gstride;
+    const int cx = threadIdx.x & 31, gy = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + cx;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < n) {
+        int p = gy;
+        for (; p + 96 < nparts; p += 128) {
+            s0 += part[(int64_t)p * n + i];
+            s1 += part[(int64_t)(p + 32) * n + i];
+            s2 += part[(int64_t)(p + 64) * n + i];
+            s3 += part[(int64_t)(p + 96) * n + i];
+        }
+        for (; p < nparts; p += 32) s0 += part[(int64_t)p * n + i];
+    }
+    red[gy][cx] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (gy == 0 && i < n) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) s += red[r][cx];
+        sums[(int64_t)blockIdx.y * n + i] = s;
+        const int C = n >> 1;
+        if ((int)blockIdx.y == pgroup) {
+            if (dbeta && i < C) dbeta[i] += gscale * s;
+            if (dgamma && i >= C) dgamma[i - C] += gscale * s;
+        }
     }
 }
 
@@ -530,7 +570,8 @@ static const float* fold_stage1(const float* part, int& rows, int n, float* scra
     if (rows <= 256) return part;
     const int per = (rows + FOLD_STAGE_ROWS - 1) / FOLD_STAGE_ROWS;
     const int ny = (rows + per - 1) / per;
-    hipLaunchKernelGGL(fold_rows_kernel, dim3((n + 31) / 32, ny), dim3(1024), 0, st, part, rows, n, per, scratch);
+    hipLaunchKernelGGL(fold_rows_kernel, dim3((n + 31) / 32, ny), dim3(1024), 0, st, part, rows, n, per, scratch,
+                       (int64_t)0, (int64_t)0);
     rows = ny;
     return scratch;
 }
@@ -547,6 +588,25 @@ int bn_fold_launch(const float* part, int rows, int n, float* scratch, float* su
     const float* src = fold_stage1(part, rows, n, scratch, st);
     hipLaunchKernelGGL(fold_partials_kernel, dim3((n + 31) / 32), dim3(1024), 0, st, src, rows, n, sums,
                        (float*)nullptr, (float*)nullptr, 0.f, 0, 0);
+    return LAUNCH_OK();
+}
+// part [G][rows_cap][2][C] (the first `rows` rows of each group are valid) -> sums [G][2][C] (+ parameter gradients)
+int bn_bwd_fold_launch(const float* part, int rows, int rows_cap, int C, int G, float* scratch, float* sums,
+                       float* dbeta, float* dgamma, float gscale, int pgroup, hipStream_t st) {
+    const int n = 2 * C;
+    int64_t gstride = (int64_t)rows_cap * n;
+    const float* src = part;
+    if (rows > 256) {
+        const int per = (rows + FOLD_STAGE_ROWS - 1) / FOLD_STAGE_ROWS;
+        const int ny = (rows + per - 1) / per;
+        hipLaunchKernelGGL(fold_rows_kernel, dim3((n + 31) / 32, ny, G), dim3(1024), 0, st, part, rows, n, per, scratch,
+                           gstride, (int64_t)FOLD_STAGE_ROWS * n);
+        src = scratch;
+        rows = ny;
+        gstride = (int64_t)FOLD_STAGE_ROWS * n;
+    }
+    hipLaunchKernelGGL(fold_groups_kernel, dim3((n + 31) / 32, G), dim3(1024), 0, st, src, rows, n, gstride, sums, dbeta,
+                       dgamma, gscale, pgroup);
     return LAUNCH_OK();
 }
 int bn_stats_launch(const half_t* x, int M, int C, float* sums, float* ws, int64_t ws_floats, hipStream_t st) {

@@ -43,6 +43,7 @@ _SIGS = {
     "fmri_bn_stats_finalize": [_p, _i, _i, _p, _p, _l, _f, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p, _p, _p, _p],
     "fmri_bn_fold_finalize": [_p, _i, _i, _p, _p, _f, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p, _p, _p, _p],
     "fmri_bn_fold": [_p, _i, _i, _p, _p, _p],
+    "fmri_bn_bwd_fold": [_p, _i, _i, _i, _i, _p, _p, _p, _p, _f, _i, _p],
     "fmri_bn_apply": [_p, _p, _i, _i, _p, _p, _i, _p],
     "fmri_bn_bwd_reduce": [_p, _p, _i, _i, _p, _p, _p, _p, _i, _p, _p, _l, _p, _p, _f, _p],
     "fmri_bn_bwd_apply": [_p, _p, _p, _i, _i, _f, _p, _p, _p, _p, _i, _p, _p],
@@ -67,7 +68,10 @@ _SIGS = {
 
 class Epilogue(C.Structure):
     """``fmri_epilogue`` of include/fmri_hip.h (BatchNorm statistics out of a contraction's epilogue)."""
-    _fields_ = [("stat_part", C.c_void_p), ("stat_rows_cap", C.c_int32), ("stat_group_n", C.c_int32)]
+    _fields_ = [("stat_part", C.c_void_p), ("stat_rows_cap", C.c_int32), ("stat_group_n", C.c_int32),
+                ("bn_x", C.c_void_p), ("bn_gamma", C.c_void_p), ("bn_beta", C.c_void_p),
+                ("bn_mean", C.c_void_p * 4), ("bn_rstd", C.c_void_p * 4), ("bn_x_img0", C.c_int32 * 4),
+                ("bn_relu", C.c_int32), ("reserved", C.c_int32)]
 
 
 EXPORTS = sorted(list(_SIGS) + ["fmri_version", "fmri_last_error_string", "fmri_test_fastdiv", "fmri_bn_ws_floats",

@@ -75,6 +75,12 @@ class FusedHeads:
         return None
 
 
+def _bwd_epi(**kw):
+    """``bn_bwd`` argument of ``ConvLayer.dgrad`` when the BatchNorm-backward epilogue is switched on (ops._EPI_BWD)."""
+    from . import ops
+    return kw if ops._EPI_BWD else None
+
+
 def refresh_net(net):
     """Everything a sub-network derives from its master parameters -- fp16 GEMM weights, (C,H,W)-permuted BatchNorm
     vectors, the fused heads' concatenated weights -- refreshed NOW on the current stream.  They are otherwise
@@ -158,12 +164,16 @@ class EncoderNet:
             after_fc()
         dflat, _ = self.fc.dgrad(draw_fc)
         d = dflat.reshape(ctx["acts"][3].shape)
+        stat = None
         for i in (2, 1, 0):
-            draw, _ = self.bns[i].backward(ctx["raws"][i], d, ctx["svs"][i], True, scale)
+            draw, _ = self.bns[i].backward(ctx["raws"][i], d, ctx["svs"][i], True, scale, stat=stat)
             self.convs[i].wgrad(ctx["acts"][i], draw, scale)
             if i > 0:
                 _, hi, wi, _ = ctx["acts"][i].shape
-                d = self.convs[i].dgrad(draw, hi, wi)
+                # the data gradient's epilogue masks with block i-1's ReLU and reduces its BatchNorm backward sums
+                d = self.convs[i].dgrad(draw, hi, wi, bn_bwd=_bwd_epi(bn=self.bns[i - 1], x=ctx["raws"][i - 1],
+                                                                      groups=[(0, ctx["svs"][i - 1])]))
+                stat = self.convs[i].take_bwd_stats()
 
 
 class CognitiveEncoderNet:
@@ -301,6 +311,7 @@ class DecoderNet:
         wgrads(self.c3, ctx["acts"][3], dpre)
         _, hi, wi, _ = ctx["acts"][3].shape
         d = self.c3.dgrad(dpre, hi, wi)
+        stat = None
         for i in (2, 1, 0):
             draw = torch.empty_like(d)
             e = 0
@@ -314,15 +325,24 @@ class DecoderNet:
                     tr = nx if nx["train"] else en
                     self.bns[i].backward2(rows(ctx["raws"][i], en["g"]), d[e * B:(e + 2) * B], ctx["svs"][i][en["g"]],
                                           True, tr["scale"] if tr["train"] else None, out=draw[e * B:(e + 2) * B],
-                                          param_stream=ps)
+                                          param_stream=ps, stat=stat, stat_group=e)
                     e += 2
                 else:
                     self.bns[i].backward(rows(ctx["raws"][i], en["g"]), rows(d, e), ctx["svs"][i][en["g"]], True,
-                                         en["scale"] if en["train"] else None, out=rows(draw, e))
+                                         en["scale"] if en["train"] else None, out=rows(draw, e), stat=stat,
+                                         stat_group=e)
                     e += 1
             wgrads(self.deconvs[i], ctx["acts"][i], draw)
             _, hi, wi, _ = ctx["acts"][i].shape
-            d = self.deconvs[i].dgrad(draw, hi, wi)
+            if i > 0:
+                # block i-1's ReLU mask and BatchNorm backward sums come out of this data gradient's epilogue: one
+                # statistics group per cotangent block (its forward call's rows of the saved tensor and statistics)
+                d = self.deconvs[i].dgrad(draw, hi, wi, bn_bwd=_bwd_epi(
+                    bn=self.bns[i - 1], x=ctx["raws"][i - 1],
+                    groups=[(en["g"] * B, ctx["svs"][i - 1][en["g"]]) for en in entries]))
+                stat = self.deconvs[i].take_bwd_stats()
+            else:
+                d = self.deconvs[i].dgrad(draw, hi, wi)
         dflat = d.reshape(E * B, -1)
         draw_fc = torch.empty_like(dflat)
         out = {}
@@ -454,16 +474,21 @@ class DiscriminatorNet:
                     self.convs[li].wgrad(ctx["acts"][li], rows(d, si), s["scale"])
             _, hi, wi, _ = ctx["acts"][li].shape
             if li > 0:
-                dact = self.convs[li].dgrad(d, hi, wi)
+                # the data gradient's epilogue masks with block li-1's ReLU and reduces its BatchNorm backward sums, one
+                # statistics group per cotangent stream (all read the same saved forward tensor)
+                dact = self.convs[li].dgrad(d, hi, wi, bn_bwd=_bwd_epi(bn=self.bns[li - 1], x=ctx["raws"][li - 1],
+                                                                       groups=[(0, ctx["svs"][li - 1])] * S))
+                stat = self.convs[li].take_bwd_stats()
                 dn = torch.empty_like(dact)
                 if S == 2 and not streams[1]["train"]:
                     # both streams in one pass over the saved forward tensor (gamma / beta gradients from stream A only)
                     self.bns[li - 1].backward2(ctx["raws"][li - 1], dact, ctx["svs"][li - 1], True,
-                                               streams[0]["scale"] if streams[0]["train"] else None, out=dn)
+                                               streams[0]["scale"] if streams[0]["train"] else None, out=dn, stat=stat)
                 else:
                     for si, s in enumerate(streams):
                         self.bns[li - 1].backward(ctx["raws"][li - 1], rows(dact, si), ctx["svs"][li - 1], True,
-                                                  s["scale"] if s["train"] else None, out=rows(dn, si))
+                                                  s["scale"] if s["train"] else None, out=rows(dn, si), stat=stat,
+                                                  stat_group=si)
                 d = dn
         # conv1 data gradient, conv0 (bias + ReLU).  Below the last BatchNorm the images are independent, so a stream
         # that does not train the discriminator only needs the rows whose image gradient is wanted.

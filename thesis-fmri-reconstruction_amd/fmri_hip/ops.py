@@ -213,10 +213,12 @@ def igemm_kernel_label(N, Hi, Wi, Ci, Ho, Wo, CoStore, Co, k, stride, pad, mode,
 
 
 def run_igemm(x, pw: PackedWeight, out, bias, N, Hi, Wi, Ci, Ho, Wo, CoStore, Co, k, stride, pad, mode, act, out_f32,
-              splits, slab_stride, tile, flops=0.0, stats=None) -> int:
+              splits, slab_stride, tile, flops=0.0, stats=None, bn_bwd=None) -> int:
     """``stats`` = (partial-row tensor [groups][rows_cap][2][CoStore] fp32, rows_cap, images per group or 0): ask the
-    kernel for the BatchNorm statistics of its output (fmri_igemm_ep).  Returns the number of rows written per group
-    (0: the kernel behind this geometry has no statistics epilogue)."""
+    kernel for the BatchNorm statistics of its output (fmri_igemm_ep).  ``bn_bwd`` = dict(x, gamma, beta, relu, groups =
+    [(first image of x, BNSaved), ...]): the BatchNorm-BACKWARD form of that epilogue (masked cotangent + sum g,
+    sum g*xhat rows).  Returns the number of rows written per group (0: the kernel behind this geometry has no such
+    epilogue -- the output is then the plain contraction)."""
     w = pw.get()
     prof = PROFILE is not None and flops > 0.0
     if prof:
@@ -224,7 +226,13 @@ def run_igemm(x, pw: PackedWeight, out, bias, N, Hi, Wi, Ci, Ho, Wo, CoStore, Co
         e0.record()
     ep, done = None, ctypes.c_int(0)
     if stats is not None:
-        ep = ctypes.byref(lib.Epilogue(stats[0].data_ptr(), int(stats[1]), int(stats[2])))
+        e = lib.Epilogue(stats[0].data_ptr(), int(stats[1]), int(stats[2]))
+        if bn_bwd is not None:
+            e.bn_x, e.bn_gamma, e.bn_beta = _P(bn_bwd["x"]), _P(bn_bwd["gamma"]), _P(bn_bwd["beta"])
+            e.bn_relu = 1 if bn_bwd.get("relu", True) else 0
+            for i, (img0, sv) in enumerate(bn_bwd["groups"]):
+                e.bn_mean[i], e.bn_rstd[i], e.bn_x_img0[i] = _P(sv.mean), _P(sv.rstd), int(img0)
+        ep = ctypes.byref(e)
     lib.call("fmri_igemm_ep", _P(x), _P(w), _P(out), _P(bias), _P(zero_page(x.device)), N, Hi, Wi, Ci, Ho, Wo,
              CoStore, Co, k, stride, pad, mode, act, 1 if out_f32 else 0, splits, slab_stride, tile, w.numel(), ep,
              ctypes.byref(done))
@@ -238,6 +246,10 @@ def run_igemm(x, pw: PackedWeight, out, bias, N, Hi, Wi, Ci, Ho, Wo, CoStore, Co
 
 # BatchNorm statistics out of the producing contraction's epilogue (fmri_igemm_ep): on/off
 _EPI_STATS = os.environ.get("FMRI_EPI_STATS") != "off"
+# ... and the BatchNorm-BACKWARD form (ReLU mask + sum g, sum g*xhat out of the data gradient's epilogue): off by
+# default.  Measured on the B = 256 Stage-I step it removes 0.34 ms of reduction kernels but the epilogues' reads of the
+# saved forward tile (8 bytes per lane, latency exposed once per parity class) cost the data-gradient kernels 0.59 ms.
+_EPI_BWD = os.environ.get("FMRI_EPI_BWD") == "on"
 
 # window-resident wgrad kernel: on/off, resident-block target (2 per CU), largest split count still written as slabs
 _WW_ON = os.environ.get("FMRI_WGRAD_WIN") != "off"
@@ -430,21 +442,47 @@ class ConvLayer:
         pix = Ho * Wo if self.kind == "conv" else Hi * Wi
         return 2.0 * N * pix * self.cin * self.cout * self.k * self.k
 
-    def dgrad(self, dy: torch.Tensor, hi: int, wi: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Cotangent w.r.t. the layer input (same scale as dy)."""
+    def dgrad(self, dy: torch.Tensor, hi: int, wi: int, out: Optional[torch.Tensor] = None,
+              bn_bwd: Optional[dict] = None) -> torch.Tensor:
+        """Cotangent w.r.t. the layer input (same scale as dy).
+
+        ``bn_bwd`` = dict(bn=<BatchNorm whose (ReLU'd) output is this layer's input>, x=<its saved forward input>,
+        groups=[(first image of x, BNSaved), ...]): the rows of ``dy`` are len(groups) equal blocks (cotangent streams /
+        decoder calls); the kernel's epilogue applies the ReLU mask and emits that BatchNorm's backward statistics
+        (fmri_epilogue.bn_x).  ``take_bwd_stats()`` then returns (rows [G][cap][2][C], valid rows) for
+        ``BatchNorm.backward(..., stat=...)``, or None when this geometry's kernel has no such epilogue (the output is
+        then the plain data gradient)."""
         N, Ho, Wo, C = dy.shape
         assert C == self.coutp and dy.is_contiguous()
         if out is None:
             out = torch.empty(N, hi, wi, self.cinp, dtype=torch.float16, device=dy.device)
         fl = self._flops(N, hi, wi, Ho, Wo)
+        stats, bb = None, None
+        self._bwd_rows = 0
+        if bn_bwd is not None and _EPI_STATS and self.cinp == self.cin:
+            bn, G = bn_bwd["bn"], len(bn_bwd["groups"])
+            if bn.C == self.cinp and not bn.perm and N % G == 0 and G <= 4:
+                cap = (N // G) * hi * wi // 128 + 8
+                part = getattr(self, "_bwd_part", None)
+                if part is None or part.shape[0] < G or part.shape[1] < cap:
+                    part = self._bwd_part = torch.empty(max(G, 2), cap, 2, self.cinp, dtype=torch.float32,
+                                                        device=dy.device)
+                gamma, beta, _, _ = bn._params()
+                stats = (part, part.shape[1], N // G if G > 1 else 0)
+                bb = dict(x=bn_bwd["x"], gamma=gamma, beta=beta, relu=bn_bwd.get("relu", True), groups=bn_bwd["groups"])
         if self.kind == "conv":
             mode = MODE_TCONV2 if self.stride == 2 else MODE_CONV_FLIP
-            run_igemm(dy, self.pw_d, out, None, N, Ho, Wo, self.coutp, hi, wi, self.cinp, self.cin, self.k,
-                      self.stride, self.pad, mode, ACT_NONE, False, 1, 0, self.t_in, fl)
+            r = run_igemm(dy, self.pw_d, out, None, N, Ho, Wo, self.coutp, hi, wi, self.cinp, self.cin, self.k,
+                          self.stride, self.pad, mode, ACT_NONE, False, 1, 0, self.t_in, fl, stats=stats, bn_bwd=bb)
         else:
-            run_igemm(dy, self.pw_d, out, None, N, Ho, Wo, self.coutp, hi, wi, self.cinp, self.cin, self.k, 2,
-                      self.pad, MODE_CONV, ACT_NONE, False, 1, 0, self.t_in, fl)
+            r = run_igemm(dy, self.pw_d, out, None, N, Ho, Wo, self.coutp, hi, wi, self.cinp, self.cin, self.k, 2,
+                          self.pad, MODE_CONV, ACT_NONE, False, 1, 0, self.t_in, fl, stats=stats, bn_bwd=bb)
+        self._bwd_rows = r if stats is not None else 0
         return out
+
+    def take_bwd_stats(self):
+        """(rows tensor [G][cap][2][cinp], valid rows per group) of the last ``dgrad(..., bn_bwd=...)``, or None."""
+        return (self._bwd_part, self._bwd_rows) if getattr(self, "_bwd_rows", 0) > 0 else None
 
     def wgrad(self, x: torch.Tensor, dy: torch.Tensor, scale: float):
         """weight.grad += (1/scale) * dW(x, dy)  (on the side stream: ops.join_side() before the gradient is read)."""
@@ -673,23 +711,42 @@ class BatchNorm:
         lib.call("fmri_bn_apply", _P(x2), _P(out), x2.shape[0], C, _P(scale), _P(shift), 1 if relu else 0)
         return out
 
+    def _fold_bwd(self, stat, group0: int, groups: int, sums: torch.Tensor, param_scale, param_group: int):
+        """Backward statistics rows of a data gradient's epilogue (``ConvLayer.take_bwd_stats``) -> sums [groups][2][C]
+        (+ gamma / beta gradients from group ``param_group``)."""
+        part, rows = stat
+        C = self.C
+        cap = part.shape[1]
+        scratch = torch.empty(groups * lib.load().fmri_bn_fold_scratch_floats(C), dtype=torch.float32,
+                              device=part.device)
+        pg = param_scale is not None
+        lib.call("fmri_bn_bwd_fold", _P(part[group0]), rows, cap, C, groups, _P(scratch), _P(sums),
+                 _P(self.gbeta) if pg else None, _P(self.ggamma) if pg else None, (1.0 / param_scale) if pg else 0.0,
+                 int(param_group))
+
     def backward(self, raw: torch.Tensor, dy: torch.Tensor, sv: BNSaved, relu: bool = True,
-                 param_scale: Optional[float] = None, out: Optional[torch.Tensor] = None):
+                 param_scale: Optional[float] = None, out: Optional[torch.Tensor] = None, stat=None,
+                 stat_group: int = 0):
         """dx through (ReLU o BN) with batch statistics; if ``param_scale`` is given, gamma/beta grads are
-        accumulated as (1/param_scale) * sums."""
+        accumulated as (1/param_scale) * sums.  ``stat``: the reduction already done by the epilogue of the data
+        gradient that produced ``dy`` (group ``stat_group`` of ``ConvLayer.take_bwd_stats()``; dy is then ReLU-masked)."""
         C = self.C
         x2 = raw.reshape(-1, C)
         g2 = dy.reshape(-1, C)
         M = x2.shape[0]
         gamma, beta, _, _ = self._params()
         sums = torch.empty(2, C, dtype=torch.float32, device=raw.device)
-        ws = _reduce_ws(M, C, raw.device)
         # gamma/beta gradients come from the LOCAL sums (the SUM all-reduce of the gradients adds the other ranks); the
         # fold kernel of the reduction accumulates them, the permuted (C,H,W)-ordered BN1d needs the scatter kernel
         direct = param_scale is not None and not self.perm
-        lib.call("fmri_bn_bwd_reduce", _P(x2), _P(g2), M, C, _P(sv.mean), _P(sv.rstd), _P(gamma), _P(beta),
-                 1 if relu else 0, _P(sums), _P(ws), ws.numel(), _P(self.gbeta) if direct else None,
-                 _P(self.ggamma) if direct else None, (1.0 / param_scale) if direct else 0.0)
+        if stat is not None:
+            assert not self.perm
+            self._fold_bwd(stat, stat_group, 1, sums, param_scale, 0)
+        else:
+            ws = _reduce_ws(M, C, raw.device)
+            lib.call("fmri_bn_bwd_reduce", _P(x2), _P(g2), M, C, _P(sv.mean), _P(sv.rstd), _P(gamma), _P(beta),
+                     1 if relu else 0, _P(sums), _P(ws), ws.numel(), _P(self.gbeta) if direct else None,
+                     _P(self.ggamma) if direct else None, (1.0 / param_scale) if direct else 0.0)
         if param_scale is not None and self.perm:
             self.accumulate_param_grads(sums, param_scale)
         if self.reducer is not None:
@@ -701,7 +758,8 @@ class BatchNorm:
         return out, sums
 
     def backward2(self, raw: torch.Tensor, dy2: torch.Tensor, sv: BNSaved, relu: bool = True,
-                  param_scale: Optional[float] = None, out: Optional[torch.Tensor] = None, param_stream: int = 0):
+                  param_scale: Optional[float] = None, out: Optional[torch.Tensor] = None, param_stream: int = 0,
+                  stat=None, stat_group: int = 0):
         """``backward`` for TWO cotangent streams stacked along the rows, ``dy2 = [A rows | B rows]`` (each as many rows
         as ``raw``): the forward tensor, xhat and the ReLU mask are read / computed once for both.  gamma / beta
         gradients (``param_scale``) are taken from ONE stream (``param_stream``: 0 = A, 1 = B)."""
@@ -712,11 +770,16 @@ class BatchNorm:
         assert g2.shape[0] == 2 * M
         gamma, beta, _, _ = self._params()
         sums = torch.empty(4, C, dtype=torch.float32, device=raw.device)
-        ws = torch.empty(2 * lib.load().fmri_bn_ws_floats(M, C), dtype=torch.float32, device=raw.device)
         pg = param_scale is not None and not self.perm     # (C,H,W)-permuted BN1d: scattered below
-        lib.call("fmri_bn_bwd_reduce2", _P(x2), _P(g2), M, C, _P(sv.mean), _P(sv.rstd), _P(gamma), _P(beta),
-                 1 if relu else 0, _P(sums), _P(ws), ws.numel(), _P(self.gbeta) if pg else None,
-                 _P(self.ggamma) if pg else None, (1.0 / param_scale) if pg else 0.0, int(param_stream))
+        if stat is not None:
+            # groups stat_group, stat_group + 1 of the producing data gradient's epilogue rows (dy2 is ReLU-masked)
+            assert not self.perm
+            self._fold_bwd(stat, stat_group, 2, sums, param_scale, int(param_stream))
+        else:
+            ws = torch.empty(2 * lib.load().fmri_bn_ws_floats(M, C), dtype=torch.float32, device=raw.device)
+            lib.call("fmri_bn_bwd_reduce2", _P(x2), _P(g2), M, C, _P(sv.mean), _P(sv.rstd), _P(gamma), _P(beta),
+                     1 if relu else 0, _P(sums), _P(ws), ws.numel(), _P(self.gbeta) if pg else None,
+                     _P(self.ggamma) if pg else None, (1.0 / param_scale) if pg else 0.0, int(param_stream))
         if param_scale is not None and self.perm:
             self.accumulate_param_grads(sums[2 * int(param_stream):2 * int(param_stream) + 2], param_scale)
         if self.reducer is not None:

@@ -212,12 +212,28 @@ int fmri_pixel_sq(const void* x, const void* xt, int64_t npix, int C, int Cp, fl
                   void* stream);
 /* scal: float block, slots [0..2] += bce sums (orig, pred, sampled), [9] += sum (d bce / d logit)^2 */
 int fmri_gan_head(const float* logit, int ldl, int B, float* prob, float* scal, void* stream);
+/* fmri_gan_head / fmri_gan_head_bwd for a discriminator loss made of a subset of the three terms (bit 0 orig, 1 pred,
+ * 2 sampled; 'dcgan' / 'vae': 5, train_vgan_stage1.py:375,382): slot [9] and the cotangent only see those parts. */
+int fmri_gan_head_parts(const float* logit, int ldl, int B, float* prob, float* scal, int parts, void* stream);
+int fmri_gan_head_bwd_parts(const float* logit, int ldl, int B, void* dlogit, int ldg, float gscale, const float* norm,
+                            int parts, void* stream);
 int fmri_wae_logloss(const float* logit, int ldl, int n, int one_minus, float w, float* total, float* prob,
                      void* dlogit, int ldg, float gscale, void* stream);
 /* scal slots: in [0..5] bce_o,bce_p,bce_s,kl,mse,nle and [9] dl2; out [6..8] loss_encoder/discriminator/decoder,
  * [10] nA = 1/rms(d bce/d logit), [11] nB = 1/rms(d mse/d feature), [12] nA/nB, [13] 1.0; flags = {train_dis, train_dec} */
 int fmri_compose_gate(float* scal, int* flags, float batch, float nfeat, float lambda_mse, float equilibrium,
                       float margin, int gate_on, int force_dis, int force_dec, void* stream);
+/* The same with the hyper-parameters on the DEVICE, hp4_dev = [lambda_mse, equilibrium, margin, beta] -- the values the
+ * scripts decay every epoch (train_vgan_stage1.py:448-458); a step recorded into a HIP graph then follows the schedule --
+ * and with the other loss compositions of train_vgan_stage1.py:359-388: mode 0 'vae-gan', 1 'beta-vae' (KL weight
+ * beta / batch), 2 'dcgan' (pixel nle in place of the feature mse, discriminator loss bce_orig + bce_sampled), 3 'vae'
+ * (dcgan's losses, decoder loss lambda * nle, train_dis starts False).  npix = reals per image (3*H*W).  Further
+ * slots written: [16] nP = 1/rms(d nle/d x_tilde), [17] lambda*nA/nB, [18] 1 - lambda, [19] lambda*nA, [20] the factor
+ * the decoder gradients carry (nP/lambda for 'vae', else nA), [21] the KL weight. */
+int fmri_compose_gate_dev(float* scal, int* flags, float batch, float nfeat, float npix, const float* hp4_dev, int mode,
+                          int gate_on, int force_dis, int force_dec, void* stream);
+/* *counter_dev += 1 (the step count fmri_adam_dev derives its bias corrections from) */
+int fmri_counter_inc(int* counter_dev, void* stream);
 /* starting cotangents of the two back-propagated streams, fp16, multiplied by gscale * (*norm) (norm: device float) */
 int fmri_gan_head_bwd(const float* logit, int ldl, int B, void* dlogit, int ldg, float gscale, const float* norm,
                       void* stream);
@@ -225,6 +241,10 @@ int fmri_feat_mse_bwd(const void* feat, int B, int F, void* dfeat, float gscale,
 /* out = a * (*a_dev) * x + b * y   (fp16 tensors, fp32 math; y and a_dev may be NULL) */
 int fmri_axpby_f16(const void* x, const void* y, void* out, int64_t n, float a, float b, const float* a_dev,
                    void* stream);
+
+/* out = a * (*a_dev) * x + b * (*b_dev) * y */
+int fmri_axpby2_f16(const void* x, const void* y, void* out, int64_t n, float a, float b, const float* a_dev,
+                    const float* b_dev, void* stream);
 
 /* device-side unit-RMS re-normalisation of an fp32 cotangent before an fp16 backward pass:
  *   fmri_sumsq : *acc += sum x^2 (all-reduce acc across ranks if data parallel)
@@ -240,6 +260,15 @@ int fmri_rmsprop(float* p, const float* g, float* sq, int64_t n, float lr, float
                  const float* gdev, float clamp, const int* flag, void* stream);
 int fmri_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
               float bc1, float bc2_sqrt, float gscale, const float* gdev, float clamp, const int* flag, void* stream);
+
+/* The same updates with the learning rate (and Adam's step count, incremented with fmri_counter_inc BEFORE the call)
+ * read from device memory: lr schedules (ExponentialLR / StepLR, train_vgan_stage1.py:448-450) and Adam's bias
+ * correction then need no re-recording of a captured step. */
+int fmri_rmsprop_dev(float* p, const float* g, float* sq, int64_t n, const float* lr_dev, float alpha, float eps,
+                     float gscale, const float* gdev, float clamp, const int* flag, void* stream);
+int fmri_adam_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* lr_dev, float b1, float b2,
+                  float eps, const int* t_dev, float gscale, const float* gdev, float clamp, const int* flag,
+                  void* stream);
 
 #ifdef __cplusplus
 }

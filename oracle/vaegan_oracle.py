@@ -439,13 +439,29 @@ def equilibrium_gate(bce_o_mean: float, bce_p_mean: float, hp: GanHyper):
     return train_dis, train_dec
 
 
-def _compose_losses(fw, x_real, B, hp: GanHyper):
+def _compose_losses(fw, x_real, B, hp: GanHyper, mode: str = "vae-gan", beta: float = 1.0):
+    """VaeGan.loss + the loss compositions of train_vgan_stage1.py:359-388 (``mode``)."""
     dl, dc = fw["disc_layer"], fw["disc_class"]
     nle, kl, mse, bo, bp, bs = vaegan_loss(_q(x_real), fw["x_tilde"], dl[:B], dl[B:-B], dl[-B:], dc[:B], dc[B:-B],
                                            dc[-B:], fw["mus"], fw["log_variances"])
-    loss_enc = torch.sum(kl) + torch.sum(mse)                                   # stage1.py:369
-    loss_dis = torch.sum(bo) + torch.sum(bp) + torch.sum(bs)                   # :370-371
-    loss_dec = torch.sum(hp.lambda_mse * mse) - (1.0 - hp.lambda_mse) * loss_dis  # :372
+    if mode == "beta-vae":                                                               # :360-366
+        loss_enc = torch.sum(kl) * beta * (1.0 / B) + torch.sum(mse)
+        loss_dis = torch.sum(bo) + torch.sum(bp) + torch.sum(bs)
+        loss_dec = torch.sum(hp.lambda_mse * mse) - (1.0 - hp.lambda_mse) * loss_dis
+    elif mode == "vae-gan":                                                              # :369-372
+        loss_enc = torch.sum(kl) + torch.sum(mse)
+        loss_dis = torch.sum(bo) + torch.sum(bp) + torch.sum(bs)
+        loss_dec = torch.sum(hp.lambda_mse * mse) - (1.0 - hp.lambda_mse) * loss_dis
+    elif mode == "dcgan":                                                                # :375-381
+        loss_enc = torch.sum(kl) + torch.sum(nle)
+        loss_dis = torch.sum(bo) + torch.sum(bs)
+        loss_dec = torch.sum(hp.lambda_mse * nle) - (1.0 - hp.lambda_mse) * loss_dis
+    elif mode == "vae":                                                                  # :384-388
+        loss_enc = torch.sum(kl) + torch.sum(nle)
+        loss_dis = torch.sum(bo) + torch.sum(bs)
+        loss_dec = torch.sum(hp.lambda_mse * nle)
+    else:
+        raise ValueError(mode)
     logs = dict(loss_encoder=loss_enc.item(), loss_discriminator=loss_dis.item(), loss_decoder=loss_dec.item(),
                 nle=torch.sum(nle).item(), kl=torch.sum(kl).item(), mse=torch.sum(mse).item(),
                 bce_orig=torch.sum(bo).item(), bce_pred=torch.sum(bp).item(), bce_samp=torch.sum(bs).item())
@@ -453,8 +469,10 @@ def _compose_losses(fw, x_real, B, hp: GanHyper):
 
 
 def stage1_step(P: State, opts: Dict[str, OptState], x: Tensor, eps: Tensor, z_p: Tensor, cfg: ArchCfg,
-                hp: GanHyper = GanHyper(), literal: bool = False, keep_grads: bool = False):
-    """One Stage-I VAE/GAN step, mode 'vae-gan' (train/train_vgan_stage1.py:330-432).
+                hp: GanHyper = GanHyper(), literal: bool = False, keep_grads: bool = False, mode: str = "vae-gan",
+                beta: float = 1.0):
+    """One Stage-I VAE/GAN step (train/train_vgan_stage1.py:330-432), ``mode`` in 'vae-gan' (default), 'beta-vae',
+    'dcgan' (encoder not trained), 'vae' (discriminator not trained unless the gate re-arms both).
 
     One forward, three gradient sets at the pre-update weights, gate, three RMSprop steps.
     """
@@ -465,13 +483,21 @@ def stage1_step(P: State, opts: Dict[str, OptState], x: Tensor, eps: Tensor, z_p
     _leafify(P, enc_k + dec_k + dis_k)
     B = x.shape[0]
     fw = vaegan_forward(P, x, eps, z_p, cfg)
-    loss_enc, loss_dis, loss_dec, logs = _compose_losses(fw, x, B, hp)
-    train_dis, train_dec = equilibrium_gate(logs["bce_orig"] / B, logs["bce_pred"] / B, hp)
+    loss_enc, loss_dis, loss_dec, logs = _compose_losses(fw, x, B, hp, mode, beta)
+    train_enc = mode != "dcgan"                                                          # :376
+    train_dis, train_dec = mode != "vae", True                                           # :353-354, :388
+    if logs["bce_orig"] / B < hp.equilibrium - hp.margin or logs["bce_pred"] / B < hp.equilibrium - hp.margin:
+        train_dis = False                                                                # :396-398
+    if logs["bce_orig"] / B > hp.equilibrium + hp.margin or logs["bce_pred"] / B > hp.equilibrium + hp.margin:
+        train_dec = False                                                                # :399-401
+    if (not train_dec) and (not train_dis):
+        train_dis, train_dec = True, True                                                # :402-404
     allk = enc_k + dec_k + dis_k if literal else None
     g_enc = _grads(loss_enc, P, enc_k, True, allk)
     g_dec = _grads(loss_dec, P, dec_k, True, allk)
     g_dis = _grads(loss_dis, P, dis_k, False, allk)
-    opt_step(P, enc_k, g_enc, opts["encoder"])
+    if train_enc:
+        opt_step(P, enc_k, g_enc, opts["encoder"])
     if train_dec:
         opt_step(P, dec_k, g_dec, opts["decoder"])
     if train_dis:

@@ -129,7 +129,7 @@ def record_step(out, tag, logs, fw, grads):
 
 
 # ------------------------------------------------------------------------------------------------
-def case_stage1(name, cfg, B, seed, perturb, steps=2):
+def case_stage1(name, cfg, B, seed, perturb, steps=2, mode="vae-gan", beta=1.0):
     vg = load_reference(cfg)
     hp = O.GanHyper()
     model = vg.VaeGan(device="cpu", z_size=cfg.latent_dim)
@@ -164,7 +164,7 @@ def case_stage1(name, cfg, B, seed, perturb, steps=2):
     opt_d = rms(model.decoder.parameters(), hp.lr)
     opt_s = rms(model.discriminator.parameters(), hp.lr)
     out = {"meta/case": np.array("stage1"), "meta/B": B, "meta/seed": seed, "meta/perturb": perturb,
-           "meta/steps": steps, "meta/image_size": cfg.image_size}
+           "meta/steps": steps, "meta/image_size": cfg.image_size, "meta/mode": np.array(mode), "meta/beta": beta}
     for s in range(steps):
         eps, z_p = data["noise"][s, 0], data["noise"][s, 1]
         mus, lv = model.encoder(x)
@@ -175,12 +175,39 @@ def case_stage1(name, cfg, B, seed, perturb, steps=2):
         disc_class = model.discriminator(x, x_tilde, x_p, "GAN")
         nle, kld, mse, bo, bp, bs = vg.VaeGan.loss(x, x_tilde, disc_layer[:B], disc_layer[B:-B], disc_layer[-B:],
                                                    disc_class[:B], disc_class[B:-B], disc_class[-B:], mus, lv)
-        loss_enc = torch.sum(kld) + torch.sum(mse)
-        loss_dis = torch.sum(bo) + torch.sum(bp) + torch.sum(bs)
-        loss_dec = torch.sum(hp.lambda_mse * mse) - (1.0 - hp.lambda_mse) * loss_dis
-        train_dis, train_dec = gate(torch.mean(bo).item(), torch.mean(bp).item(), hp)
-        g = literal_three_backward(model, loss_enc, loss_dec, loss_dis, ("encoder", "decoder", "discriminator"))
-        apply_grads(model.encoder, "encoder.", g, opt_e)
+        # loss compositions of train_vgan_stage1.py:359-388, flags and gate :353-357, :396-404
+        train_enc, train_dis, train_dec = True, True, True
+        if mode == "beta-vae":
+            loss_enc = torch.sum(kld) * beta * (1 / B) + torch.sum(mse)
+            loss_dis = torch.sum(bo) + torch.sum(bp) + torch.sum(bs)
+            loss_dec = torch.sum(hp.lambda_mse * mse) - (1.0 - hp.lambda_mse) * loss_dis
+        elif mode == "vae-gan":
+            loss_enc = torch.sum(kld) + torch.sum(mse)
+            loss_dis = torch.sum(bo) + torch.sum(bp) + torch.sum(bs)
+            loss_dec = torch.sum(hp.lambda_mse * mse) - (1.0 - hp.lambda_mse) * loss_dis
+        elif mode == "dcgan":
+            train_enc = False
+            for param in model.encoder.parameters():
+                param.requires_grad = False
+            loss_enc = torch.sum(kld) + torch.sum(nle)
+            loss_dis = torch.sum(bo) + torch.sum(bs)
+            loss_dec = torch.sum(hp.lambda_mse * nle) - (1.0 - hp.lambda_mse) * loss_dis
+        elif mode == "vae":
+            loss_enc = torch.sum(kld) + torch.sum(nle)
+            loss_dis = torch.sum(bo) + torch.sum(bs)
+            loss_dec = torch.sum(hp.lambda_mse * nle)
+            train_dis = False
+        if torch.mean(bo).item() < hp.equilibrium - hp.margin or torch.mean(bp).item() < hp.equilibrium - hp.margin:
+            train_dis = False
+        if torch.mean(bo).item() > hp.equilibrium + hp.margin or torch.mean(bp).item() > hp.equilibrium + hp.margin:
+            train_dec = False
+        if train_dec is False and train_dis is False:
+            train_dis = True
+            train_dec = True
+        nets = (("encoder",) if train_enc else ()) + ("decoder", "discriminator")
+        g = literal_three_backward(model, loss_enc, loss_dec, loss_dis, nets)
+        if train_enc:
+            apply_grads(model.encoder, "encoder.", g, opt_e)
         if train_dec:
             apply_grads(model.decoder, "decoder.", g, opt_d)
         if train_dis:
@@ -679,6 +706,16 @@ if __name__ == "__main__":
         case_stage1("stage1_b32", O.ArchCfg.px64(), B=32, seed=0, perturb=False, steps=1)
     if want("stage1_px100_b2"):
         case_stage1("stage1_px100_b2", O.ArchCfg.px100(), B=2, seed=3, perturb=True, steps=1)
+    if want("stage1_betavae_b4"):
+        case_stage1("stage1_betavae_b4", O.ArchCfg.px64(), B=4, seed=0, perturb=True, mode="beta-vae", beta=4.0)
+    if want("stage1_dcgan_b4"):
+        case_stage1("stage1_dcgan_b4", O.ArchCfg.px64(), B=4, seed=0, perturb=True, mode="dcgan")
+    if want("stage1_vae_b4"):
+        case_stage1("stage1_vae_b4", O.ArchCfg.px64(), B=4, seed=0, perturb=True, mode="vae")
+    if want("stage3_px128_b2"):
+        case_cognitive("stage3_px128_b2", O.ArchCfg.px128(), B=2, V=3620, seed=5, perturb=True, stage=3, steps=1)
+    if want("wae3_px128_b2"):
+        case_wae23("wae3_px128_b2", O.ArchCfg.px128(), B=2, V=3620, seed=7, stage=3, steps=1)
     if want("stage2_b4"):
         case_cognitive("stage2_b4", O.ArchCfg.px64(), B=4, V=4096, seed=1, perturb=True, stage=2)
     if want("stage3_b4"):

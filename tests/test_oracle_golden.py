@@ -66,6 +66,40 @@ def test_stage1_matches_reference(golden_dir, name, cfg):
         _check_step(g, f"step{s}", out, P)
 
 
+@pytest.mark.parametrize("name", ["stage1_betavae_b4", "stage1_dcgan_b4", "stage1_vae_b4"])
+def test_stage1_modes_match_reference(golden_dir, name):
+    """The other loss compositions of train_vgan_stage1.py:359-388 ('beta-vae', 'dcgan', 'vae')."""
+    cfg = O.ArchCfg.px64()
+    g = _load(golden_dir, name)
+    B, seed, perturb, steps = int(g["meta/B"]), int(g["meta/seed"]), bool(g["meta/perturb"]), int(g["meta/steps"])
+    mode, beta = str(g["meta/mode"]), float(g["meta/beta"])
+    P = O.fill_state(O.vaegan_spec(cfg), seed, perturb)
+    data = O.synth_batch(B, cfg, seed=1234, steps=steps)
+    opts = _rms_opts("encoder", "decoder", "discriminator")
+    for s in range(steps):
+        out = O.stage1_step(P, opts, data["x"], data["noise"][s, 0], data["noise"][s, 1], cfg, keep_grads=True,
+                            mode=mode, beta=beta)
+        assert out["logs"].pop("train_dis") == bool(g[f"step{s}/logs/train_dis"])
+        assert out["logs"].pop("train_dec") == bool(g[f"step{s}/logs/train_dec"])
+        _check_step(g, f"step{s}", out, P)
+
+
+def test_px128_bold5000_shape_goldens(golden_dir):
+    """BASELINE configs[4] shape (128 px, V = 3620): Stage III of the VAE/GAN and of the WAE, one step at B = 2."""
+    cfg = O.ArchCfg.px128()
+    g = _load(golden_dir, "stage3_px128_b2")
+    B, V, seed, perturb = int(g["meta/B"]), int(g["meta/V"]), int(g["meta/seed"]), bool(g["meta/perturb"])
+    teacher = O.fill_state(O.vaegan_spec(cfg), seed, perturb)
+    P = dict(O.fill_state(O.cognitive_encoder_spec(cfg, V), seed + 100, perturb))
+    P.update({k: v for k, v in teacher.items() if k.startswith(("decoder.", "discriminator."))})
+    data = O.synth_batch(B, cfg, n_voxels=V, seed=1234, steps=1)
+    out = O.stage3_step(P, _rms_opts("encoder", "decoder", "discriminator"), data["fmri"], data["x"], data["noise"][0],
+                        cfg, V, keep_grads=True)
+    assert out["logs"].pop("train_dis") == bool(g["step0/logs/train_dis"])
+    assert out["logs"].pop("train_dec") == bool(g["step0/logs/train_dec"])
+    _check_step(g, "step0", out, P)
+
+
 def test_stage1_literal_equals_pruned():
     """The 'literal' three-full-backward variant (CPU-baseline timing) gives the same numbers."""
     cfg = O.ArchCfg.px64()

@@ -263,3 +263,164 @@ def test_hybrid_recorded_forward_step_equals_eager_step():
         else:
             for k in sa:
                 assert _tensor_err(sa[k], sb[k]) < 2e-2, (it, k, _tensor_err(sa[k], sb[k]))
+
+
+@pytest.mark.parametrize("mode,beta", [("beta-vae", 4.0), ("dcgan", 1.0), ("vae", 1.0)])
+def test_stage1_modes_match_oracle_and_golden(golden_dir, mode, beta):
+    """The other loss compositions of train_vgan_stage1.py:359-388 on the fused step: first-step losses against the
+    oracle and the reference's golden numbers (1e-3), same gate flags, gradients of the trained sub-networks, next-step
+    losses within the sign-like-update bound."""
+    from oracle import vaegan_oracle as O
+    from fmri_hip.params import ArchConfig
+    from fmri_hip.steps import Stage1Step, GanHyper
+    name = {"beta-vae": "stage1_betavae_b4", "dcgan": "stage1_dcgan_b4", "vae": "stage1_vae_b4"}[mode]
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    B, seed, perturb, steps = int(g["meta/B"]), int(g["meta/seed"]), bool(g["meta/perturb"]), int(g["meta/steps"])
+    assert str(g["meta/mode"]) == mode and float(g["meta/beta"]) == beta
+    cfg_o = O.ArchCfg.px64()
+    data = O.synth_batch(B, cfg_o, seed=1234, steps=steps)
+    st = Stage1Step(ArchConfig.px64(), DEV, hp=GanHyper(beta=beta), mode=mode)
+    st.load_recipe(seed, perturb)
+    P = O.fill_state(O.vaegan_spec(cfg_o), seed, perturb)
+    opts = {n: O.OptState(kind="rmsprop", lr=1e-4) for n in ("encoder", "decoder", "discriminator")}
+    x = data["x"].to(DEV)
+    keys = ("loss_encoder", "loss_decoder", "loss_discriminator", "nle", "kl", "mse", "bce_orig", "bce_pred", "bce_samp")
+    for s in range(steps):
+        st.forward(x, data["noise"][s, 0].to(DEV), data["noise"][s, 1].to(DEV))
+        st.gate(B)
+        st.backward()
+        grads = {k: v.detach().cpu().clone() for k, v in st.named_grads().items()}
+        st.apply()
+        logs = st.logs()
+        ref = O.stage1_step(P, opts, data["x"], data["noise"][s, 0], data["noise"][s, 1], cfg_o, keep_grads=True,
+                            mode=mode, beta=beta)
+        assert logs["train_dis"] == ref["logs"]["train_dis"] and logs["train_dec"] == ref["logs"]["train_dec"], s
+        assert logs["train_dis"] == bool(g[f"step{s}/logs/train_dis"]) and logs["train_dec"] == bool(
+            g[f"step{s}/logs/train_dec"])
+        for k in keys:
+            r = _rel(logs[k], ref["logs"][k])
+            print(mode, s, k, logs[k], ref["logs"][k], r)
+            if s == 0:
+                assert r < LOSS_RTOL, (k, logs[k], ref["logs"][k])
+                assert _rel(logs[k], float(g[f"step0/logs/{k}"])) < LOSS_RTOL, (k, "golden")
+            else:
+                assert r < 5e-2, (s, k, logs[k], ref["logs"][k])
+        if s == 0:
+            skip = [k for k in ref["grads"] if mode == "dcgan" and k.startswith("encoder.")]
+            gradcheck.check(grads, ref["grads"], ref["grads"], f"stage1 {mode}", skip=skip, tol16=None)
+    # post-step parameter fingerprints of the reference (sub-networks that were not trained stay put)
+    sd = {k: v.cpu() for k, v in st.state_dict().items()}
+    skeys = [str(k) for k in g[f"step{steps - 1}/state_keys"]]
+    summ = g[f"step{steps - 1}/state_sum"]
+    for i, k in enumerate(skeys):
+        if "num_batches" in k:
+            assert float(sd[k]) == summ[i][1], k
+        elif "running" not in k:
+            assert _rel(sd[k].double().norm().item(), summ[i][0]) < 2e-3, (k, sd[k].double().norm().item(), summ[i][0])
+
+
+def test_recorded_step_follows_hyper_parameter_schedule():
+    """lr, lambda, equilibrium and margin live in device memory: two replays of ONE captured step with the epoch-end
+    updates of train_vgan_stage1.py:448-458 applied in between equal two eagerly issued steps with the same schedule;
+    the gate of the second replay is the oracle's gate under the new equilibrium / margin and the size of its update
+    is the oracle's under the new learning rate."""
+    from oracle import vaegan_oracle as O
+    from fmri_hip import ops
+    from fmri_hip.params import ArchConfig
+    from fmri_hip.steps import Stage1Step
+    B = 8
+    cfg_o = O.ArchCfg.px64()
+    data = O.synth_batch(B, cfg_o, seed=1234, steps=1)
+    x, e, zp = data["x"].to(DEV), data["noise"][0, 0].to(DEV), data["noise"][0, 1].to(DEV)
+    # "epoch end": lr halved, lambda x 100, equilibrium far above every bce mean -> train_dis = False, train_dec = True
+    sched = dict(lr=0.5e-4, margin=0.01, equilibrium=10.0, lambda_mse=1e-4)
+    a = Stage1Step(ArchConfig.px64(), DEV)
+    a.load_recipe(0, True)
+    run = a.capture(x, e, zp, warmup=1)               # one real (warm-up) step, then the recording (executes nothing)
+    b = Stage1Step(ArchConfig.px64(), DEV)
+    b.load_state_dict(a.state_dict())
+    for oa, ob in ((a.opt_enc, b.opt_enc), (a.opt_dec, b.opt_dec), (a.opt_dis, b.opt_dis)):
+        ob.s1.copy_(oa.s1)
+    flags, before = [], None
+    for it in range(2):
+        if it == 1:
+            a.set_hyper(**sched)
+            b.set_hyper(**sched)
+            before = {k: v.clone() for k, v in a.state_dict().items()}
+        run()
+        side_was = ops._SIDE["on"]
+        ops._SIDE["on"] = False                       # capture() records a one-stream step
+        try:
+            b.step(x, e, zp)
+        finally:
+            ops._SIDE["on"] = side_was
+        torch.cuda.synchronize()
+        la, lb = a.logs(), b.logs()
+        flags.append((la["train_dis"], la["train_dec"]))
+        assert (la["train_dis"], la["train_dec"]) == (lb["train_dis"], lb["train_dec"]), it
+        for k in ("loss_encoder", "loss_decoder", "loss_discriminator", "kl"):
+            assert _rel(la[k], lb[k]) < (1e-5 if it == 0 else 5e-3), (it, k, la[k], lb[k])
+        if it == 0:
+            _same_update(a.state_dict(), b.state_dict(), "replay vs eager")
+    assert flags[1] == (False, True), flags
+    after = a.state_dict()
+    # oracle: warm-up step, default step, scheduled step
+    P = O.fill_state(O.vaegan_spec(cfg_o), 0, True)
+    opts = {n: O.OptState(kind="rmsprop", lr=1e-4) for n in ("encoder", "decoder", "discriminator")}
+    hp = O.GanHyper()
+    args = (data["x"], data["noise"][0, 0], data["noise"][0, 1], cfg_o)
+    O.stage1_step(P, opts, *args, hp=hp)
+    ref = O.stage1_step(P, opts, *args, hp=hp)
+    assert flags[0] == (ref["logs"]["train_dis"], ref["logs"]["train_dec"]), flags
+    hp = O.GanHyper(lr=sched["lr"], lambda_mse=sched["lambda_mse"], margin=sched["margin"],
+                    equilibrium=sched["equilibrium"])
+    for o in opts.values():
+        o.lr = sched["lr"]
+    P2 = {k: v.clone() for k, v in P.items()}
+    ref = O.stage1_step(P, opts, *args, hp=hp)
+    assert flags[1] == (ref["logs"]["train_dis"], ref["logs"]["train_dec"]), flags
+    for k in ("encoder.fc.0.weight", "decoder.conv.0.conv.weight", "discriminator.conv.2.conv.weight"):
+        du_e = (after[k].float().cpu() - before[k].float().cpu()).norm().item()
+        du_o = (P[k] - P2[k]).norm().item()
+        print(k, du_e, du_o)
+        if k.startswith("discriminator."):
+            assert du_e == 0.0 and du_o == 0.0, k          # gated off by the new equilibrium
+        else:
+            assert abs(du_e - du_o) < 0.1 * du_o, (k, du_e, du_o)    # half the step of lr = 1e-4
+
+
+def test_recorded_forward_survives_an_eager_step_in_between():
+    """capture_forward(): an eager step() at another batch size between two run() calls (the last, partial batch of an
+    epoch) must not leave run() back-propagating the eager batch (it rebinds the recorded forward's tensors)."""
+    from oracle import vaegan_oracle as O
+    from fmri_hip import ops
+    from fmri_hip.params import ArchConfig
+    from fmri_hip.steps import Stage1Step
+    B = 8
+    cfg_o = O.ArchCfg.px64()
+    data = O.synth_batch(B, cfg_o, seed=1234, steps=1)
+    x, e, zp = data["x"].to(DEV), data["noise"][0, 0].to(DEV), data["noise"][0, 1].to(DEV)
+    a = Stage1Step(ArchConfig.px64(), DEV)
+    a.load_recipe(0, True)
+    run = a.capture_forward(x, e, zp, warmup=1)
+    b = Stage1Step(ArchConfig.px64(), DEV)
+    b.load_state_dict(a.state_dict())
+    for oa, ob in ((a.opt_enc, b.opt_enc), (a.opt_dec, b.opt_dec), (a.opt_dis, b.opt_dis)):
+        ob.s1.copy_(oa.s1)
+    seq = [("run", None), ("eager", 4), ("run", None)]
+    for what, n in seq:
+        if what == "run":
+            run()
+            b.step(x, e, zp)
+        else:
+            a.step(x[:n], e[:n], zp[:n])
+            b.step(x[:n], e[:n], zp[:n])
+        ops.join_side()
+        torch.cuda.synchronize()
+    la, lb = a.logs(), b.logs()
+    for k in ("loss_encoder", "loss_decoder", "loss_discriminator"):
+        assert _rel(la[k], lb[k]) < 2e-2, (k, la[k], lb[k])
+    sa, sb = a.state_dict(), b.state_dict()
+    for k in sa:
+        if sa[k].dtype == torch.float32 and "running" not in k and sa[k].numel() > 1000:
+            assert _tensor_err(sa[k], sb[k]) < 2e-2, (k, _tensor_err(sa[k], sb[k]))

@@ -700,12 +700,21 @@ int fmri_pixel_sq(const void* x, const void* xt, int64_t npix, int C, int Cp, fl
 }
 int fmri_gan_head(const float* logit, int ldl, int B, float* prob, float* scal, void* stream) {
     if (!logit || !scal) return FMRI_E_BADARG;
-    return gan_head_launch(logit, ldl, B, prob, scal, S(stream));
+    return gan_head_launch(logit, ldl, B, prob, scal, 7, S(stream));
 }
 int fmri_gan_head_bwd(const float* logit, int ldl, int B, void* dlogit, int ldg, float gscale, const float* norm,
                       void* stream) {
     if (!logit || !dlogit) return FMRI_E_BADARG;
-    return gan_head_bwd_launch(logit, ldl, B, (half_t*)dlogit, ldg, gscale, norm, S(stream));
+    return gan_head_bwd_launch(logit, ldl, B, (half_t*)dlogit, ldg, gscale, norm, 7, S(stream));
+}
+int fmri_gan_head_parts(const float* logit, int ldl, int B, float* prob, float* scal, int parts, void* stream) {
+    if (!logit || !scal || parts < 0 || parts > 7) return FMRI_E_BADARG;
+    return gan_head_launch(logit, ldl, B, prob, scal, parts, S(stream));
+}
+int fmri_gan_head_bwd_parts(const float* logit, int ldl, int B, void* dlogit, int ldg, float gscale, const float* norm,
+                            int parts, void* stream) {
+    if (!logit || !dlogit || parts < 0 || parts > 7) return FMRI_E_BADARG;
+    return gan_head_bwd_launch(logit, ldl, B, (half_t*)dlogit, ldg, gscale, norm, parts, S(stream));
 }
 int fmri_wae_logloss(const float* logit, int ldl, int n, int one_minus, float w, float* total, float* prob,
                      void* dlogit, int ldg, float gscale, void* stream) {
@@ -715,13 +724,28 @@ int fmri_wae_logloss(const float* logit, int ldl, int n, int one_minus, float w,
 int fmri_compose_gate(float* scal, int* flags, float batch, float nfeat, float lambda_mse, float equilibrium,
                       float margin, int gate_on, int force_dis, int force_dec, void* stream) {
     if (!scal || !flags) return FMRI_E_BADARG;
-    return compose_gate_launch(scal, flags, batch, nfeat, lambda_mse, equilibrium, margin, gate_on, force_dis,
+    return compose_gate_launch(scal, flags, batch, nfeat, 0.f, lambda_mse, equilibrium, margin, 1.f, nullptr, 0, gate_on,
+                               force_dis, force_dec, S(stream));
+}
+int fmri_compose_gate_dev(float* scal, int* flags, float batch, float nfeat, float npix, const float* hp4_dev, int mode,
+                          int gate_on, int force_dis, int force_dec, void* stream) {
+    if (!scal || !flags || !hp4_dev || mode < 0 || mode > 3) return FMRI_E_BADARG;
+    return compose_gate_launch(scal, flags, batch, nfeat, npix, 0.f, 0.f, 0.f, 0.f, hp4_dev, mode, gate_on, force_dis,
                                force_dec, S(stream));
+}
+int fmri_counter_inc(int* counter_dev, void* stream) {
+    if (!counter_dev) return FMRI_E_BADARG;
+    return counter_inc_launch(counter_dev, S(stream));
 }
 int fmri_axpby_f16(const void* x, const void* y, void* out, int64_t n, float a, float b, const float* a_dev,
                    void* stream) {
     if (!x || !out || (n & 7)) return FMRI_E_BADARG;
-    return axpby_f16_launch((const half_t*)x, (const half_t*)y, (half_t*)out, n, a, b, a_dev, S(stream));
+    return axpby_f16_launch((const half_t*)x, (const half_t*)y, (half_t*)out, n, a, b, a_dev, nullptr, S(stream));
+}
+int fmri_axpby2_f16(const void* x, const void* y, void* out, int64_t n, float a, float b, const float* a_dev,
+                    const float* b_dev, void* stream) {
+    if (!x || !out || (n & 7)) return FMRI_E_BADARG;
+    return axpby_f16_launch((const half_t*)x, (const half_t*)y, (half_t*)out, n, a, b, a_dev, b_dev, S(stream));
 }
 int fmri_sumsq(const float* x, int64_t n, float* acc, void* stream) {
     if (!x || !acc) return FMRI_E_BADARG;
@@ -735,13 +759,25 @@ int fmri_renorm(const float* x, void* out16, int64_t n, float scale, const float
 int fmri_rmsprop(float* p, const float* g, float* sq, int64_t n, float lr, float alpha, float eps, float gscale,
                  const float* gdev, float clamp, const int* flag, void* stream) {
     if (!p || !g || !sq) return FMRI_E_BADARG;
-    return rmsprop_launch(p, g, sq, n, lr, alpha, eps, gscale, gdev, clamp, flag, S(stream));
+    return rmsprop_launch(p, g, sq, n, lr, alpha, eps, gscale, gdev, clamp, flag, nullptr, S(stream));
 }
 int fmri_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
               float bc1, float bc2_sqrt, float gscale, const float* gdev, float clamp, const int* flag,
               void* stream) {
     if (!p || !g || !m || !v) return FMRI_E_BADARG;
-    return adam_launch(p, g, m, v, n, lr, b1, b2, eps, bc1, bc2_sqrt, gscale, gdev, clamp, flag, S(stream));
+    return adam_launch(p, g, m, v, n, lr, b1, b2, eps, bc1, bc2_sqrt, gscale, gdev, clamp, flag, nullptr, nullptr,
+                       S(stream));
+}
+int fmri_rmsprop_dev(float* p, const float* g, float* sq, int64_t n, const float* lr_dev, float alpha, float eps,
+                     float gscale, const float* gdev, float clamp, const int* flag, void* stream) {
+    if (!p || !g || !sq || !lr_dev) return FMRI_E_BADARG;
+    return rmsprop_launch(p, g, sq, n, 0.f, alpha, eps, gscale, gdev, clamp, flag, lr_dev, S(stream));
+}
+int fmri_adam_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* lr_dev, float b1, float b2,
+                  float eps, const int* t_dev, float gscale, const float* gdev, float clamp, const int* flag,
+                  void* stream) {
+    if (!p || !g || !m || !v || !lr_dev || !t_dev) return FMRI_E_BADARG;
+    return adam_launch(p, g, m, v, n, 0.f, b1, b2, eps, 1.f, 1.f, gscale, gdev, clamp, flag, lr_dev, t_dev, S(stream));
 }
 
 }  // extern "C"

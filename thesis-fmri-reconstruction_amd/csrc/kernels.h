@@ -100,23 +100,25 @@ int feat_mse_bwd_launch(const half_t* feat, int B, int F, half_t* dfeat, float g
                         hipStream_t st);
 int pixel_sq_launch(const half_t* x, const half_t* xt, int64_t npix, int C, int Cp, float* total, half_t* dxt,
                     float gscale, hipStream_t st);
-int gan_head_launch(const float* logit, int ldl, int B, float* prob, float* scal, hipStream_t st);
+int gan_head_launch(const float* logit, int ldl, int B, float* prob, float* scal, int parts, hipStream_t st);
 int gan_head_bwd_launch(const float* logit, int ldl, int B, half_t* dlogit, int ldg, float gscale, const float* norm,
-                        hipStream_t st);
+                        int parts, hipStream_t st);
 int wae_logloss_launch(const float* logit, int ldl, int n, int one_minus, float w, float* total, float* prob,
                        half_t* dlogit, int ldg, float gscale, hipStream_t st);
-int compose_gate_launch(float* scal, int* flags, float batch, float nfeat, float lambda_mse, float equilibrium,
-                        float margin, int gate_on, int force_dis, int force_dec, hipStream_t st);
+int compose_gate_launch(float* scal, int* flags, float batch, float nfeat, float npix, float lambda_mse,
+                        float equilibrium, float margin, float beta, const float* hp_dev, int mode, int gate_on,
+                        int force_dis, int force_dec, hipStream_t st);
+int counter_inc_launch(int* t, hipStream_t st);
 int axpby_f16_launch(const half_t* x, const half_t* y, half_t* out, int64_t n, float a, float b, const float* pa,
-                     hipStream_t st);
+                     const float* pb, hipStream_t st);
 int sumsq_launch(const float* x, int64_t n, float* acc, hipStream_t st);
 int renorm_launch(const float* x, half_t* out, int64_t n, float scale, const float* sumsq, float count,
                   const float* factor_in, float* factor_out, hipStream_t st);
 int rmsprop_launch(float* p, const float* g, float* sq, int64_t n, float lr, float alpha, float eps, float gscale,
-                   const float* gdev, float clamp, const int* flag, hipStream_t st);
+                   const float* gdev, float clamp, const int* flag, const float* lr_dev, hipStream_t st);
 int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
                 float bc1, float bc2_sqrt, float gscale, const float* gdev, float clamp, const int* flag,
-                hipStream_t st);
+                const float* lr_dev, const int* t_dev, hipStream_t st);
 
 int ingest_u8_launch(const uint8_t* src, int N, int H, int W, int C, const int* flip, const int* shift,
                      const float* mean3, const float* std3, half_t* dst16, float* dst32, hipStream_t st);

@@ -17,7 +17,17 @@ namespace fmri {
 
 // scalar block layout (floats) -- keep in sync with fmri_hip/steps.py
 enum Slot { S_BCE_O = 0, S_BCE_P = 1, S_BCE_S = 2, S_KL = 3, S_MSE = 4, S_NLE = 5, S_LENC = 6, S_LDIS = 7,
-            S_LDEC = 8, S_DL2 = 9, S_NA = 10, S_NB = 11, S_RATIO = 12, S_ONE = 13 };
+            S_LDEC = 8, S_DL2 = 9, S_NA = 10, S_NB = 11, S_RATIO = 12, S_ONE = 13,
+            // [14], [15]: encoder-stream re-normalisation (fmri_sumsq / fmri_renorm)
+            S_NP = 16,      // 1 / rms(d nle / d x_tilde)                          (modes 'vae', 'dcgan')
+            S_C1 = 17,      // lambda * nA / nB : weight of the feature stream in the decoder cotangent ('vae-gan')
+            S_C2 = 18,      // 1 - lambda       : weight of the discriminator stream in the decoder cotangent
+            S_C3 = 19,      // lambda * nA      : weight of d nle in the decoder cotangent ('dcgan')
+            S_GDEC = 20,    // factor the decoder gradients carry ('vae': nP / lambda; else nA)
+            S_KLW = 21 };   // weight of the KL term in the encoder loss (beta / batch for 'beta-vae', else 1)
+
+// loss compositions of train/train_vgan_stage1.py:359-388
+enum Mode { M_VAEGAN = 0, M_BETAVAE = 1, M_DCGAN = 2, M_VAE = 3 };
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -177,8 +187,11 @@ __device__ __forceinline__ void gan_terms(float l, int part, float& p, float& bc
 // ---- discriminator class head: logits (fp32 [3B], bias already added) -> sigmoid, the three BCE sums
 // (eps 1e-3 inside the log, models/vae_gan.py:316-318) and sum of squared d(bce)/d(logit) (for the stream norm).
 // scal: [S_BCE_O..S_BCE_S] += bce sums, [S_DL2] += sum dl^2
+// parts: bit p set = part p (0 orig, 1 pred, 2 sampled) belongs to the discriminator loss that is back-propagated
+// (dcgan / vae: orig + sampled, train_vgan_stage1.py:375,382); the three bce sums are always all reported.
 __global__ __launch_bounds__(256) void gan_head_kernel(const float* __restrict__ logit, int ldl, int B,
-                                                       float* __restrict__ prob, float* __restrict__ scal) {
+                                                       float* __restrict__ prob, float* __restrict__ scal,
+                                                       int parts) {
     __shared__ float sh[4];
     float s[4] = {0.f, 0.f, 0.f, 0.f};
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 3 * B; i += gridDim.x * blockDim.x) {
@@ -186,7 +199,7 @@ __global__ __launch_bounds__(256) void gan_head_kernel(const float* __restrict__
         const int part = i / B;
         gan_terms(logit[(int64_t)i * ldl], part, p, bce, dl);
         s[part] += bce;
-        s[3] += dl * dl;
+        if ((parts >> part) & 1) s[3] += dl * dl;
         if (prob) prob[i] = p;
     }
 #pragma unroll
@@ -198,11 +211,12 @@ __global__ __launch_bounds__(256) void gan_head_kernel(const float* __restrict__
 
 // d(sum bce)/d logit * gscale * (*norm) -> fp16 rows of stride ldg (column 0; others zero)
 __global__ void gan_head_bwd_kernel(const float* __restrict__ logit, int ldl, int B, half_t* __restrict__ dlogit,
-                                    int ldg, float gscale, const float* __restrict__ norm) {
+                                    int ldg, float gscale, const float* __restrict__ norm, int parts) {
     const float sc = gscale * (norm ? *norm : 1.f);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 3 * B; i += gridDim.x * blockDim.x) {
         float p, bce, dl;
         gan_terms(logit[(int64_t)i * ldl], i / B, p, bce, dl);
+        if (!((parts >> (i / B)) & 1)) dl = 0.f;
         for (int c = 0; c < ldg; ++c) dlogit[(int64_t)i * ldg + c] = (half_t)(c == 0 ? dl * sc : 0.f);
     }
 }
@@ -231,26 +245,44 @@ __global__ __launch_bounds__(256) void wae_logloss_kernel(const float* __restric
 
 // ---- loss composition + equilibrium gate + stream normalisation factors, one thread.
 //  in : bce_o, bce_p, bce_s, kl, mse, nle, dl2 (all already summed over the global batch)
-//  out: loss_encoder, loss_discriminator, loss_decoder; nA = 1/rms(dlogit), nB = 1/rms(dfeat), ratio = nA/nB;
-//       flags[0] = train_dis, flags[1] = train_dec
+//  out: loss_encoder, loss_discriminator, loss_decoder; nA = 1/rms(dlogit), nB = 1/rms(dfeat), ratio = nA/nB, the
+//       mixing weights S_C1..S_C3, S_GDEC, S_KLW; flags[0] = train_dis, flags[1] = train_dec
+//  hp (device, may be null -> the host values): [lambda_mse, equilibrium, margin, beta] -- the per-epoch decays of
+//  train_vgan_stage1.py:448-458 update that vector, so a replayed HIP graph sees them.
+//  mode (train_vgan_stage1.py:359-388): vae-gan, beta-vae (KL weight beta / batch), dcgan (pixel nle instead of the
+//  feature mse, discriminator loss without the reconstruction term), vae (dcgan's losses, decoder loss lambda * nle,
+//  discriminator not trained unless the gate re-arms both).  dl2 must match the mode's discriminator loss.
 __global__ void compose_gate_kernel(float* __restrict__ scal, int* __restrict__ flags, float batch, float nfeat,
-                                    float lambda_mse, float equilibrium, float margin, int gate_on, int force_dis,
+                                    float npix, float lambda_mse, float equilibrium, float margin, float beta,
+                                    const float* __restrict__ hp, int mode, int gate_on, int force_dis,
                                     int force_dec) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (hp) { lambda_mse = hp[0]; equilibrium = hp[1]; margin = hp[2]; beta = hp[3]; }
     const float bo = scal[S_BCE_O], bp = scal[S_BCE_P], bs = scal[S_BCE_S];
-    const float l_dis = bo + bp + bs;
-    scal[S_LENC] = scal[S_KL] + scal[S_MSE];
+    const bool pix = mode == M_DCGAN || mode == M_VAE;
+    const float rec = pix ? scal[S_NLE] : scal[S_MSE];
+    const float l_dis = pix ? bo + bs : bo + bp + bs;
+    const float klw = mode == M_BETAVAE ? beta / batch : 1.f;
+    scal[S_KLW] = klw;
+    scal[S_LENC] = klw * scal[S_KL] + rec;
     scal[S_LDIS] = l_dis;
-    scal[S_LDEC] = lambda_mse * scal[S_MSE] - (1.f - lambda_mse) * l_dis;
+    scal[S_LDEC] = mode == M_VAE ? lambda_mse * rec : lambda_mse * rec - (1.f - lambda_mse) * l_dis;
     const float rms_a = sqrtf(scal[S_DL2] / (3.f * batch));
     const float rms_b = sqrtf(2.f * scal[S_MSE] / (batch * nfeat));
+    const float rms_p = sqrtf(2.f * scal[S_NLE] / (batch * fmaxf(npix, 1.f)));
     const float na = 1.f / fmaxf(rms_a, 1e-20f);
     const float nb = 1.f / fmaxf(rms_b, 1e-20f);
+    const float np = 1.f / fmaxf(rms_p, 1e-20f);
     scal[S_NA] = na;
     scal[S_NB] = nb;
+    scal[S_NP] = np;
     scal[S_RATIO] = na / nb;
     scal[S_ONE] = 1.f;
-    int train_dis = 1, train_dec = 1;
+    scal[S_C1] = lambda_mse * na / nb;
+    scal[S_C2] = 1.f - lambda_mse;
+    scal[S_C3] = lambda_mse * na;
+    scal[S_GDEC] = mode == M_VAE ? np / fmaxf(lambda_mse, 1e-30f) : na;
+    int train_dis = mode == M_VAE ? 0 : 1, train_dec = 1;
     if (gate_on) {
         const float mo = bo / batch, mp = bp / batch;
         if (mo < equilibrium - margin || mp < equilibrium - margin) train_dis = 0;
@@ -265,8 +297,10 @@ __global__ void compose_gate_kernel(float* __restrict__ scal, int* __restrict__ 
 
 // ---- out = a*(*pa)*x + b*y over fp16 (cotangent mixing, fp32 math); y / pa may be null
 __global__ void axpby_f16_kernel(const half_t* __restrict__ x, const half_t* __restrict__ y, half_t* __restrict__ out,
-                                 int64_t n8, float a, float b, const float* __restrict__ pa) {
+                                 int64_t n8, float a, float b, const float* __restrict__ pa,
+                                 const float* __restrict__ pb) {
     const float aa = a * (pa ? *pa : 1.f);
+    b *= pb ? *pb : 1.f;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
         const h8 xv = *(const h8*)(x + i * 8);
         h8 o;
@@ -308,8 +342,9 @@ __global__ void renorm_kernel(const float* __restrict__ x, half_t* __restrict__ 
 // whole update so the equilibrium gate never needs a host sync.  g_true = g * gscale / (*gdev), then clamped.
 __global__ void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ sq, int64_t n,
                                float lr, float alpha, float eps, float gscale, const float* __restrict__ gdev,
-                               float clamp, const int* __restrict__ flag) {
+                               float clamp, const int* __restrict__ flag, const float* __restrict__ lr_dev) {
     if (flag && *flag == 0) return;
+    if (lr_dev) lr = *lr_dev;      // device-resident learning rate: schedules reach a replayed HIP graph
     const float gs = gscale / (gdev ? *gdev : 1.f);
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float gg = g[i] * gs;
@@ -323,8 +358,15 @@ __global__ void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ 
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps, float bc1,
                             float bc2_sqrt, float gscale, const float* __restrict__ gdev, float clamp,
-                            const int* __restrict__ flag) {
+                            const int* __restrict__ flag, const float* __restrict__ lr_dev,
+                            const int* __restrict__ t_dev) {
     if (flag && *flag == 0) return;
+    if (lr_dev) lr = *lr_dev;
+    if (t_dev) {                   // device-resident step count (already incremented for this step): bias corrections
+        const float t = (float)*t_dev;
+        bc1 = 1.f - powf(b1, t);
+        bc2_sqrt = sqrtf(1.f - powf(b2, t));
+    }
     const float gs = gscale / (gdev ? *gdev : 1.f);
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float gg = g[i] * gs;
@@ -373,14 +415,15 @@ int pixel_sq_launch(const half_t* x, const half_t* xt, int64_t npix, int C, int 
                        gscale);
     return LAUNCH_OK();
 }
-int gan_head_launch(const float* logit, int ldl, int B, float* prob, float* scal, hipStream_t st) {
-    hipLaunchKernelGGL(gan_head_kernel, dim3(nblk(3 * (int64_t)B, 64)), dim3(256), 0, st, logit, ldl, B, prob, scal);
+int gan_head_launch(const float* logit, int ldl, int B, float* prob, float* scal, int parts, hipStream_t st) {
+    hipLaunchKernelGGL(gan_head_kernel, dim3(nblk(3 * (int64_t)B, 64)), dim3(256), 0, st, logit, ldl, B, prob, scal,
+                       parts);
     return LAUNCH_OK();
 }
 int gan_head_bwd_launch(const float* logit, int ldl, int B, half_t* dlogit, int ldg, float gscale, const float* norm,
-                        hipStream_t st) {
+                        int parts, hipStream_t st) {
     hipLaunchKernelGGL(gan_head_bwd_kernel, dim3(nblk(3 * (int64_t)B, 64)), dim3(256), 0, st, logit, ldl, B, dlogit,
-                       ldg, gscale, norm);
+                       ldg, gscale, norm, parts);
     return LAUNCH_OK();
 }
 int wae_logloss_launch(const float* logit, int ldl, int n, int one_minus, float w, float* total, float* prob,
@@ -389,15 +432,23 @@ int wae_logloss_launch(const float* logit, int ldl, int n, int one_minus, float 
                        prob, dlogit, ldg, gscale);
     return LAUNCH_OK();
 }
-int compose_gate_launch(float* scal, int* flags, float batch, float nfeat, float lambda_mse, float equilibrium,
-                        float margin, int gate_on, int force_dis, int force_dec, hipStream_t st) {
-    hipLaunchKernelGGL(compose_gate_kernel, dim3(1), dim3(64), 0, st, scal, flags, batch, nfeat, lambda_mse,
-                       equilibrium, margin, gate_on, force_dis, force_dec);
+int compose_gate_launch(float* scal, int* flags, float batch, float nfeat, float npix, float lambda_mse,
+                        float equilibrium, float margin, float beta, const float* hp_dev, int mode, int gate_on,
+                        int force_dis, int force_dec, hipStream_t st) {
+    hipLaunchKernelGGL(compose_gate_kernel, dim3(1), dim3(64), 0, st, scal, flags, batch, nfeat, npix, lambda_mse,
+                       equilibrium, margin, beta, hp_dev, mode, gate_on, force_dis, force_dec);
+    return LAUNCH_OK();
+}
+__global__ void counter_inc_kernel(int* t) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *t += 1;
+}
+int counter_inc_launch(int* t, hipStream_t st) {
+    hipLaunchKernelGGL(counter_inc_kernel, dim3(1), dim3(64), 0, st, t);
     return LAUNCH_OK();
 }
 int axpby_f16_launch(const half_t* x, const half_t* y, half_t* out, int64_t n, float a, float b, const float* pa,
-                     hipStream_t st) {
-    hipLaunchKernelGGL(axpby_f16_kernel, dim3(nblk(n / 8)), dim3(256), 0, st, x, y, out, n / 8, a, b, pa);
+                     const float* pb, hipStream_t st) {
+    hipLaunchKernelGGL(axpby_f16_kernel, dim3(nblk(n / 8)), dim3(256), 0, st, x, y, out, n / 8, a, b, pa, pb);
     return LAUNCH_OK();
 }
 int sumsq_launch(const float* x, int64_t n, float* acc, hipStream_t st) {
@@ -411,16 +462,16 @@ int renorm_launch(const float* x, half_t* out, int64_t n, float scale, const flo
     return LAUNCH_OK();
 }
 int rmsprop_launch(float* p, const float* g, float* sq, int64_t n, float lr, float alpha, float eps, float gscale,
-                   const float* gdev, float clamp, const int* flag, hipStream_t st) {
+                   const float* gdev, float clamp, const int* flag, const float* lr_dev, hipStream_t st) {
     hipLaunchKernelGGL(rmsprop_kernel, dim3(nblk(n)), dim3(256), 0, st, p, g, sq, n, lr, alpha, eps, gscale, gdev,
-                       clamp, flag);
+                       clamp, flag, lr_dev);
     return LAUNCH_OK();
 }
 int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
                 float bc1, float bc2_sqrt, float gscale, const float* gdev, float clamp, const int* flag,
-                hipStream_t st) {
+                const float* lr_dev, const int* t_dev, hipStream_t st) {
     hipLaunchKernelGGL(adam_kernel, dim3(nblk(n)), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, bc1, bc2_sqrt,
-                       gscale, gdev, clamp, flag);
+                       gscale, gdev, clamp, flag, lr_dev, t_dev);
     return LAUNCH_OK();
 }
 

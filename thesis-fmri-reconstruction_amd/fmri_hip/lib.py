@@ -57,9 +57,16 @@ _SIGS = {
     "fmri_pixel_sq": [_p, _p, _l, _i, _i, _p, _p, _f, _p],
     "fmri_gan_head": [_p, _i, _i, _p, _p, _p],
     "fmri_gan_head_bwd": [_p, _i, _i, _p, _i, _f, _p, _p],
+    "fmri_gan_head_parts": [_p, _i, _i, _p, _p, _i, _p],
+    "fmri_gan_head_bwd_parts": [_p, _i, _i, _p, _i, _f, _p, _i, _p],
     "fmri_wae_logloss": [_p, _i, _i, _i, _f, _p, _p, _p, _i, _f, _p],
     "fmri_compose_gate": [_p, _p, _f, _f, _f, _f, _f, _i, _i, _i, _p],
     "fmri_axpby_f16": [_p, _p, _p, _l, _f, _f, _p, _p],
+    "fmri_axpby2_f16": [_p, _p, _p, _l, _f, _f, _p, _p, _p],
+    "fmri_compose_gate_dev": [_p, _p, _f, _f, _f, _p, _i, _i, _i, _i, _p],
+    "fmri_counter_inc": [_p, _p],
+    "fmri_rmsprop_dev": [_p, _p, _p, _l, _p, _f, _f, _f, _p, _f, _p, _p],
+    "fmri_adam_dev": [_p, _p, _p, _p, _l, _p, _f, _f, _f, _p, _f, _p, _f, _p, _p],
     "fmri_sumsq": [_p, _l, _p, _p],
     "fmri_renorm": [_p, _p, _l, _f, _p, _f, _p, _p, _p],
     "fmri_rmsprop": [_p, _p, _p, _l, _f, _f, _f, _f, _p, _f, _p, _p],

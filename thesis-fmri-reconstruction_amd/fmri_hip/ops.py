@@ -854,11 +854,11 @@ def act_backward(y: torch.Tensor, dy: torch.Tensor, act: int, colsum: Optional[t
 
 
 def axpby(x: torch.Tensor, y: Optional[torch.Tensor], a: float, b: float, out: Optional[torch.Tensor] = None,
-          a_dev: Optional[torch.Tensor] = None):
-    """out = a * (*a_dev) * x + b * y  (fp16 tensors; a_dev: optional device fp32 scalar)."""
+          a_dev: Optional[torch.Tensor] = None, b_dev: Optional[torch.Tensor] = None):
+    """out = a * (*a_dev) * x + b * (*b_dev) * y  (fp16 tensors; a_dev / b_dev: optional device fp32 scalars)."""
     if out is None:
         out = torch.empty_like(x)
-    lib.call("fmri_axpby_f16", _P(x), _P(y), _P(out), x.numel(), float(a), float(b), _P(a_dev))
+    lib.call("fmri_axpby2_f16", _P(x), _P(y), _P(out), x.numel(), float(a), float(b), _P(a_dev), _P(b_dev))
     return out
 
 

@@ -33,7 +33,9 @@ _P = lib.ptr
 
 # slots of the fp32 scalar block (csrc/loss.hip enum Slot)
 (S_BCE_O, S_BCE_P, S_BCE_S, S_KL, S_MSE, S_NLE, S_LENC, S_LDIS, S_LDEC, S_DL2, S_NA, S_NB, S_RATIO,
- S_ONE, S_ESQ, S_NE) = range(16)
+ S_ONE, S_ESQ, S_NE, S_NP, S_C1, S_C2, S_C3, S_GDEC, S_KLW) = range(22)
+# loss compositions of train/train_vgan_stage1.py:359-388 (csrc/loss.hip enum Mode)
+MODES = {"vae-gan": 0, "beta-vae": 1, "dcgan": 2, "vae": 3}
 N_REDUCED = 10      # slots [0, N_REDUCED) are sums over the batch -> all-reduced in data-parallel runs
 LOG_KEYS = ("bce_orig", "bce_pred", "bce_samp", "kl", "mse", "nle", "loss_encoder", "loss_discriminator",
             "loss_decoder")
@@ -48,6 +50,7 @@ class GanHyper:
     equilibrium: float = 0.68
     alpha: float = 0.9
     eps: float = 1e-8
+    beta: float = 1.0      # KL factor of mode 'beta-vae' (configs/gan_config.py:32)
 
 
 @dataclass
@@ -58,29 +61,43 @@ class Scales:
     b: float = 16.0        # d sum(mse) stream through discriminator / decoder (unit RMS per feature)
     dec: float = 2048.0    # lambda*B - (1-lambda)*A through the decoder (carries norm nA)
     enc: float = 16.0      # encoder backward (carries norm nB)
+    p: float = 16.0        # d nle / d x_tilde through the decoder (mode 'vae'; carries norm nP)
 
 
 class _Optim:
     """Fused RMSprop / Adam over a FlatGroup, optionally gated by a device flag; ``gdev`` is the device
-    normalisation factor still carried by the gradients (divided out inside the kernel)."""
+    normalisation factor still carried by the gradients (divided out inside the kernel).  The learning rate (and
+    Adam's step count) live in device memory: ``set_lr`` -- the per-epoch ExponentialLR / StepLR of the scripts
+    (train_vgan_stage1.py:448-450) -- reaches a step that was recorded into a HIP graph."""
 
     def __init__(self, group, kind="rmsprop", lr=1e-4, alpha=0.9, eps=1e-8, betas=(0.5, 0.999)):
-        self.g, self.kind, self.lr, self.alpha, self.eps, self.betas = group, kind, lr, alpha, eps, betas
+        self.g, self.kind, self.alpha, self.eps, self.betas = group, kind, alpha, eps, betas
         self.s1 = torch.zeros_like(group.data)
         self.s2 = torch.zeros_like(group.data) if kind == "adam" else None
         self.t = 0
+        self._lr = float(lr)
+        self.lr_dev = torch.full((1,), float(lr), dtype=torch.float32, device=group.device)
+        self.t_dev = torch.zeros(1, dtype=torch.int32, device=group.device) if kind == "adam" else None
+
+    @property
+    def lr(self) -> float:
+        return self._lr
+
+    def set_lr(self, lr: float):
+        self._lr = float(lr)
+        self.lr_dev.fill_(float(lr))
 
     def step(self, flag: Optional[torch.Tensor] = None, clamp: float = 0.0, gdev: Optional[torch.Tensor] = None):
         g = self.g
         if self.kind == "rmsprop":
-            lib.call("fmri_rmsprop", _P(g.data), _P(g.grad), _P(self.s1), g.numel, self.lr, self.alpha, self.eps, 1.0,
-                     _P(gdev), clamp, _P(flag))
+            lib.call("fmri_rmsprop_dev", _P(g.data), _P(g.grad), _P(self.s1), g.numel, _P(self.lr_dev), self.alpha,
+                     self.eps, 1.0, _P(gdev), clamp, _P(flag))
         else:
             self.t += 1
             b1, b2 = self.betas
-            lib.call("fmri_adam", _P(g.data), _P(g.grad), _P(self.s1), _P(self.s2), g.numel, self.lr, b1, b2,
-                     self.eps, 1.0 - b1 ** self.t, float(np.sqrt(1.0 - b2 ** self.t)), 1.0, _P(gdev), clamp,
-                     _P(flag))
+            lib.call("fmri_counter_inc", _P(self.t_dev))
+            lib.call("fmri_adam_dev", _P(g.data), _P(g.grad), _P(self.s1), _P(self.s2), g.numel, _P(self.lr_dev), b1, b2,
+                     self.eps, _P(self.t_dev), 1.0, _P(gdev), clamp, _P(flag))
         g.version += 1
 
 
@@ -191,9 +208,16 @@ class _GanStepBase:
     """Shared pieces of the Stage-I/II/III steps: loss kernels, gate, scalar block, logging."""
 
     def _init_common(self, device, hp, scales, distributed, sync_bn, nets):
-        self.hp, self.sc = hp, scales
+        # fresh instances: GanHyper / Scales are mutable (the per-epoch decays are written as step.set_hyper(...))
+        self.hp = GanHyper() if hp is None else hp
+        self.sc = Scales() if scales is None else scales
+        self.mode = "vae-gan"
         self.device = torch.device(device)
         self.scal = torch.zeros(32, dtype=torch.float32, device=device)
+        # [lambda_mse, equilibrium, margin, beta] on the device: read by the gate kernel, so a recorded step follows
+        # the per-epoch decays (train_vgan_stage1.py:451-458)
+        self.hp_dev = torch.tensor([self.hp.lambda_mse, self.hp.equilibrium, self.hp.margin, self.hp.beta],
+                                   dtype=torch.float32, device=device)
         self.flags = torch.zeros(2, dtype=torch.int32, device=device)
         self.dd = _Dist(distributed, sync_bn)
         _attach_reducers(nets, self.dd)
@@ -202,28 +226,49 @@ class _GanStepBase:
     def _slot(self, i):
         return self.scal[i:i + 1]
 
+    def set_hyper(self, lr: Optional[float] = None, lambda_mse: Optional[float] = None,
+                  equilibrium: Optional[float] = None, margin: Optional[float] = None, beta: Optional[float] = None):
+        """The epoch-end updates of the scripts (lr_*.step(), margin *= decay_margin, equilibrium *= decay_equilibrium,
+        lambda_mse *= decay_mse; train_vgan_stage1.py:448-458) -- host copies and the device values the kernels read."""
+        hp = self.hp
+        if lr is not None:
+            hp.lr = float(lr)
+            for o in (getattr(self, n, None) for n in ("opt_enc", "opt_dec", "opt_dis")):
+                if o is not None:
+                    o.set_lr(lr)
+        for name, v in (("lambda_mse", lambda_mse), ("equilibrium", equilibrium), ("margin", margin), ("beta", beta)):
+            if v is not None:
+                setattr(hp, name, float(v))
+        self.hp_dev.copy_(torch.tensor([hp.lambda_mse, hp.equilibrium, hp.margin, hp.beta], dtype=torch.float32))
+
     def _gan_losses(self, feat, logit32, B, x16, xt16, H, W):
         """BCE / feature-mse / pixel terms of VaeGan.loss into the scalar block (+ all-reduce)."""
         dev = feat.device
         F = feat[0].numel()
         prob = torch.empty(3 * B, dtype=torch.float32, device=dev)
-        lib.call("fmri_gan_head", _P(logit32), 1, B, _P(prob), _P(self.scal))
+        lib.call("fmri_gan_head_parts", _P(logit32), 1, B, _P(prob), _P(self.scal), self._dis_parts())
         lib.call("fmri_feat_mse", _P(feat), B, F, None, _P(self._slot(S_MSE)))
         lib.call("fmri_pixel_sq", _P(x16), _P(xt16), B * H * W, 3, 8, _P(self._slot(S_NLE)), None, 1.0)
         if not getattr(self, "_defer_loss_reduce", False):
             self.dd.all_reduce(self.scal[:N_REDUCED])
         return prob, F
 
+    def _dis_parts(self) -> int:
+        """Terms of the back-propagated discriminator loss: orig | pred | sampled ('dcgan' / 'vae': orig + sampled)."""
+        return 5 if self.mode in ("dcgan", "vae") else 7
+
     def _gate(self, B_global, F, gate_on=True, force_dis=-1, force_dec=-1):
-        hp = self.hp
-        lib.call("fmri_compose_gate", _P(self.scal), _P(self.flags), float(B_global), float(F), hp.lambda_mse,
-                 hp.equilibrium, hp.margin, 1 if gate_on else 0, force_dis, force_dec)
+        fw = self.fw
+        lib.call("fmri_compose_gate_dev", _P(self.scal), _P(self.flags), float(B_global), float(F),
+                 float(3 * fw["H"] * fw["W"]), _P(self.hp_dev), MODES[self.mode], 1 if gate_on else 0, force_dis,
+                 force_dec)
 
     def _start_cotangents(self, feat, logit32, B):
         """fp16 starting cotangents of stream A (logits) and stream B (raw conv-3 features)."""
         dev = feat.device
         dlogit16 = torch.empty(3 * B, 8, dtype=torch.float16, device=dev)
-        lib.call("fmri_gan_head_bwd", _P(logit32), 1, B, _P(dlogit16), 8, self.sc.a, _P(self._slot(S_NA)))
+        lib.call("fmri_gan_head_bwd_parts", _P(logit32), 1, B, _P(dlogit16), 8, self.sc.a, _P(self._slot(S_NA)),
+                 self._dis_parts())
         # stream B's cotangent is written straight into the second half of the buffer that stacks both streams for the
         # discriminator's conv backward (DiscriminatorNet fills the first half with stream A: no concatenation copy)
         stack = torch.empty((2 * feat.shape[0],) + tuple(feat.shape[1:]), dtype=feat.dtype, device=dev)
@@ -292,12 +337,24 @@ class _GanStepBase:
                 self.dd.recorder = None
             torch.cuda.current_stream().wait_stream(side)
             self._graph = rec
-            return rec.replay
+            return self._versioned(rec.replay)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             self.step(*static_inputs)
         self._graph = graph
-        return graph.replay
+        return self._versioned(graph.replay)
+
+    def _versioned(self, replay):
+        """A replay updates the master weights without passing through ``_Optim.step``: bump the groups' version
+        counters so that the first eager step afterwards re-packs its fp16 weights."""
+        groups = [o.g for o in (getattr(self, n, None) for n in ("opt_enc", "opt_dec", "opt_dis", "opt_wd"))
+                  if o is not None]
+
+        def run():
+            replay()
+            for g in groups:
+                g.version += 1
+        return run
 
     def logs(self):
         v = self.scal.tolist()
@@ -310,13 +367,20 @@ class _GanStepBase:
 class Stage1Step(_GanStepBase):
     """Stage-I VAE/GAN step (image -> image)."""
 
-    def __init__(self, cfg: ArchConfig, device, hp: GanHyper = GanHyper(), scales: Scales = Scales(),
-                 distributed: bool = False, sync_bn: bool = True):
+    def __init__(self, cfg: ArchConfig, device, hp: Optional[GanHyper] = None, scales: Optional[Scales] = None,
+                 distributed: bool = False, sync_bn: bool = True, mode: str = "vae-gan"):
+        """``mode``: the loss composition of train_vgan_stage1.py:359-388 -- 'vae-gan' (default), 'beta-vae' (KL weight
+        hp.beta / batch), 'dcgan' (pixel nle, encoder not trained), 'vae' (pixel nle, discriminator not trained unless
+        the gate re-arms both)."""
+        if mode not in MODES:
+            raise ValueError(f"mode must be one of {sorted(MODES)}")
         self.cfg = cfg
         self.enc = EncoderNet(cfg, device)
         self.dec = DecoderNet(cfg, device, self.enc.size)
         self.dis = DiscriminatorNet(cfg, device)
         self._init_common(device, hp, scales, distributed, sync_bn, (self.enc, self.dec, self.dis))
+        self.mode = mode
+        hp = self.hp
         self.opt_enc = _Optim(self.enc.group, "rmsprop", hp.lr, hp.alpha, hp.eps)
         self.opt_dec = _Optim(self.dec.group, "rmsprop", hp.lr, hp.alpha, hp.eps)
         self.opt_dis = _Optim(self.dis.group, "rmsprop", hp.lr, hp.alpha, hp.eps)
@@ -377,6 +441,8 @@ class Stage1Step(_GanStepBase):
         repack are queued on the side stream right behind their last weight gradient, i.e. they run under the backward
         pass of the next sub-network instead of after the whole backward (nothing later in the step reads those weights);
         ``apply`` then only updates the encoder."""
+        if self.mode in ("dcgan", "vae"):
+            return self._backward_pixel(early_apply)
         fw, sc, hp, cfg = self.fw, self.sc, self.hp, self.cfg
         B, H, W = fw["B"], fw["H"], fw["W"]
         Z = cfg.latent_dim
@@ -395,23 +461,26 @@ class Stage1Step(_GanStepBase):
         self.dd.all_reduce_async(self.dis.group.grad)
         if early:
             ops.side_run(dev, lambda: self._apply_one(self.opt_dis, self.dis, self.flags[0:1], S_NA))
-        # decoder cotangent, stored = dec * nA * (lambda*B_true - (1-lambda)*A_true)
+        # decoder cotangent, stored = dec * nA * (lambda*B_true - (1-lambda)*A_true); the weights lambda*nA/nB and
+        # 1-lambda are device scalars written by the gate kernel (a recorded step follows the lambda schedule)
         cot = torch.empty(3 * B, H, W, 8, dtype=torch.float16, device=dev)
-        lam = hp.lambda_mse
         # block order [x_tilde: feature loss (encoder path) | x_tilde: decoder loss | x_p: decoder loss]: the two blocks
         # that go through the SAME forward activations (group 0) are adjacent, so the decoder's BatchNorm backward takes
         # them in one pass (BatchNorm.backward2), and the two training blocks are adjacent, so every decoder weight
         # gradient is one launch over 2B rows
         cot[:B].copy_(dimg_b[:B])
-        axpby(dimg_b, dimg_a, sc.dec * lam / sc.b, -sc.dec * (1.0 - lam) / sc.a, out=cot[B:], a_dev=self._slot(S_RATIO))
+        axpby(dimg_b, dimg_a, sc.dec / sc.b, -sc.dec / sc.a, out=cot[B:], a_dev=self._slot(S_C1),
+              b_dev=self._slot(S_C2))
         entries = [dict(g=0, scale=sc.b, train=False, need_dz=True), dict(g=0, scale=sc.dec, train=True),
                    dict(g=1, scale=sc.dec, train=True)]
         dz = self.dec.backward(fw["dctx"], cot, entries, join=dp)[0]  # = nB * dz_true
         self.dd.all_reduce_async(self.dec.group.grad)
         if early:
-            ops.side_run(dev, lambda: self._apply_one(self.opt_dec, self.dec, self.flags[1:2], S_NA))
+            ops.side_run(dev, lambda: self._apply_one(self.opt_dec, self.dec, self.flags[1:2], S_GDEC))
         dhead32 = torch.empty(B, 2 * Z, dtype=torch.float32, device=dev)
-        lib.call("fmri_latent_bwd", _P(fw["head32"]), _P(fw["eps"]), _P(dz), Z, 1.0, 1.0, _P(self._slot(S_NB)), B, Z,
+        # KL weight: 1, or beta / batch for 'beta-vae' (train_vgan_stage1.py:360-362)
+        klw = hp.beta / float(B * self.dd.world) if self.mode == "beta-vae" else 1.0
+        lib.call("fmri_latent_bwd", _P(fw["head32"]), _P(fw["eps"]), _P(dz), Z, 1.0, klw, _P(self._slot(S_NB)), B, Z,
                  1.0, None, _P(dhead32), 1)                              # = nB * dhead_true
         if extra_dmu is not None:
             dhead32[:, :Z].addcmul_(extra_dmu, self._slot(S_NB))            # carried at the same device factor nB
@@ -423,17 +492,71 @@ class Stage1Step(_GanStepBase):
         self.dd.all_reduce(eg.grad[:tail])
         self.dd.wait_all()
 
+    def _backward_pixel(self, early_apply: bool):
+        """Modes 'dcgan' and 'vae' (train_vgan_stage1.py:374-388): the reconstruction term is the pixel nle.
+
+        dcgan: decoder <- lambda*d nle - (1-lambda)*d(bce_orig + bce_sampled) on [x_tilde ; x_p], discriminator <-
+               d(bce_orig + bce_sampled), encoder not trained.
+        vae  : encoder <- d(KL + nle) through the decoder, decoder <- lambda*d nle, discriminator <- d(bce_orig +
+               bce_sampled), applied only if the gate re-armed it (flags[0])."""
+        fw, sc, cfg = self.fw, self.sc, self.cfg
+        B, H, W = fw["B"], fw["H"], fw["W"]
+        Z = cfg.latent_dim
+        d_in = fw["disc_in"]
+        dev = d_in.device
+        dp = self.dd.on
+        self._applied_early = False
+        for n in (self.enc, self.dec, self.dis):
+            n.group.zero_grad()
+        dlogit16 = torch.empty(3 * B, 8, dtype=torch.float16, device=dev)
+        lib.call("fmri_gan_head_bwd_parts", _P(fw["logit32"]), 1, B, _P(dlogit16), 8, sc.a, _P(self._slot(S_NA)),
+                 self._dis_parts())
+        x16, xt16 = d_in[:B], d_in[B:2 * B]
+        if self.mode == "dcgan":
+            dimg_a, _ = self.dis.backward(fw["sctx"], dlogit16, sc.a, None, sc.b, True, slice(B, 3 * B), join=dp)
+            self.dd.all_reduce_async(self.dis.group.grad)
+            # stored = dec * nA * (lambda * d nle - (1-lambda) * A), d nle / d x_tilde = x_tilde - x
+            dnle = axpby(xt16, x16, 1.0, -1.0)
+            cot = torch.empty(2 * B, H, W, 8, dtype=torch.float16, device=dev)
+            axpby(dnle, dimg_a[:B], sc.dec, -sc.dec / sc.a, out=cot[:B], a_dev=self._slot(S_C3),
+                  b_dev=self._slot(S_C2))
+            axpby(dimg_a[B:], None, -sc.dec / sc.a, 0.0, out=cot[B:], a_dev=self._slot(S_C2))
+            entries = [dict(g=0, scale=sc.dec, train=True), dict(g=1, scale=sc.dec, train=True)]
+            self.dec.backward(fw["dctx"], cot, entries, join=dp)
+            self.dd.all_reduce_async(self.dec.group.grad)
+            self.dd.wait_all()
+            return
+        # vae
+        self.dis.backward(fw["sctx"], dlogit16, sc.a, None, sc.b, True, None, join=dp)
+        self.dd.all_reduce_async(self.dis.group.grad)
+        # stored = p * nP * (x_tilde - x); the decoder gradients carry nP and are scaled by lambda in the optimizer
+        cot = axpby(xt16, x16, sc.p, -sc.p, a_dev=self._slot(S_NP), b_dev=self._slot(S_NP))
+        entries = [dict(g=0, scale=sc.p, train=True, need_dz=True)]
+        dz = self.dec.backward(fw["dctx"], cot, entries, join=dp)[0]        # = nP * dz_true
+        self.dd.all_reduce_async(self.dec.group.grad)
+        dhead32 = torch.empty(B, 2 * Z, dtype=torch.float32, device=dev)
+        lib.call("fmri_latent_bwd", _P(fw["head32"]), _P(fw["eps"]), _P(dz), Z, 1.0, 1.0, _P(self._slot(S_NP)), B, Z,
+                 1.0, None, _P(dhead32), 1)                                  # = nP * dhead_true
+        dhead16 = self._renorm(dhead32, sc.enc, self._slot(S_NP), B * self.dd.world)    # S_NE = nP * nE
+        eg = self.enc.group
+        tail = eg.offsets["fc.0.weight"]
+        self.enc.backward(fw["ectx"], dhead16, sc.enc,
+                          after_fc=(lambda: self.dd.all_reduce_async(eg.grad[tail:])) if dp else None)
+        self.dd.all_reduce(eg.grad[:tail])
+        self.dd.wait_all()
+
     def _apply_one(self, opt, net, flag, slot):
         """Optimizer update of one sub-network + refresh of everything derived from its weights (current stream)."""
         opt.step(flag, gdev=self._slot(slot))
         refresh_net(net)
 
     def apply(self):
-        self.opt_enc.step(None, gdev=self._slot(S_NE))
+        if self.mode != "dcgan":                         # 'dcgan': train_enc = False (train_vgan_stage1.py:376)
+            self.opt_enc.step(None, gdev=self._slot(S_NE))
         if getattr(self, "_applied_early", False):
             self._applied_early = False
             return
-        self.opt_dec.step(self.flags[1:2], gdev=self._slot(S_NA))
+        self.opt_dec.step(self.flags[1:2], gdev=self._slot(S_GDEC))
         self.opt_dis.step(self.flags[0:1], gdev=self._slot(S_NA))
 
     def capture_forward(self, x, eps, z_p, warmup: int = 2):
@@ -469,10 +592,13 @@ class Stage1Step(_GanStepBase):
         finally:
             self._defer_loss_reduce = False
 
+        fw_captured = self.fw                 # the tensors the recorded forward writes
+
         def run():
             for n in nets:
                 refresh_net(n)               # no-ops for the sub-networks the last backward refreshed early
             graph.replay()
+            self.fw = fw_captured            # an eager step() / forward() in between rebinds self.fw to its own batch
             if not gate_in_graph:
                 self.dd.all_reduce(self.scal[:N_REDUCED])
                 self.gate(B * self.dd.world)
@@ -507,7 +633,7 @@ class Stage1Step(_GanStepBase):
         """True-scale gradients (the device normalisation factors divided out) -- syncs; tests/API only."""
         s = self.scal.tolist()
         out = {}
-        for pre, n, f in (("encoder.", self.enc, s[S_NE]), ("decoder.", self.dec, s[S_NA]),
+        for pre, n, f in (("encoder.", self.enc, s[S_NE]), ("decoder.", self.dec, s[S_GDEC]),
                           ("discriminator.", self.dis, s[S_NA])):
             for k, v in n.group.grads.items():
                 out[pre + k] = v / f
@@ -521,8 +647,8 @@ class CognitiveStep(_GanStepBase):
     train/train_vgan_stage3.py:324-411 (stage=3: cognitive encoder frozen, decoder + discriminator trained,
     gate on, clamp +-1)."""
 
-    def __init__(self, cfg: ArchConfig, n_voxels: int, device, stage: int, hp: GanHyper = GanHyper(),
-                 scales: Scales = Scales(), distributed: bool = False, sync_bn: bool = True):
+    def __init__(self, cfg: ArchConfig, n_voxels: int, device, stage: int, hp: Optional[GanHyper] = None,
+                 scales: Optional[Scales] = None, distributed: bool = False, sync_bn: bool = True):
         assert stage in (2, 3)
         self.cfg, self.stage, self.n_voxels = cfg, stage, n_voxels
         self.cog = CognitiveEncoderNet(cfg, n_voxels, device)
@@ -531,6 +657,7 @@ class CognitiveStep(_GanStepBase):
         self.teacher_enc = EncoderNet(cfg, device) if stage == 2 else None
         nets = [self.cog, self.dec, self.dis] + ([self.teacher_enc] if stage == 2 else [])
         self._init_common(device, hp, scales, distributed, sync_bn, nets)
+        hp = self.hp
         self.opt_enc = _Optim(self.cog.group, "rmsprop", hp.lr, hp.alpha, hp.eps)
         self.opt_dec = _Optim(self.dec.group, "rmsprop", hp.lr, hp.alpha, hp.eps)
         self.opt_dis = _Optim(self.dis.group, "rmsprop", hp.lr, hp.alpha, hp.eps)
@@ -640,8 +767,7 @@ class CognitiveStep(_GanStepBase):
             self.dec.group.zero_grad()
             self.dis.group.zero_grad()
             dimg_a, dimg_b = self.dis.backward(fw["sctx"], dlogit16, sc.a, dfeat16, sc.b, True, slice(B, 3 * B))
-            lam = hp.lambda_mse
-            cot = axpby(dimg_b, dimg_a, sc.dec * lam / sc.b, -sc.dec * (1.0 - lam) / sc.a, a_dev=self._slot(S_RATIO))
+            cot = axpby(dimg_b, dimg_a, sc.dec / sc.b, -sc.dec / sc.a, a_dev=self._slot(S_C1), b_dev=self._slot(S_C2))
             entries = [dict(g=0, scale=sc.dec, train=True), dict(g=1, scale=sc.dec, train=True)]
             self.dec.backward(fw["dctx"], cot, entries)
             for n in (self.dis, self.dec):

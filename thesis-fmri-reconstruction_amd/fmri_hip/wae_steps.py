@@ -85,9 +85,10 @@ class WaeStep(_LatentDiscPhase):
     """WAE/GAN Stage I / II / III step."""
 
     def __init__(self, cfg: ArchConfig, device, stage: int = 1, n_voxels: int = 0, hp: Optional[WaeHyper] = None,
-                 scales: Scales = Scales(), distributed: bool = False, sync_bn: bool = True):
+                 scales: Optional[Scales] = None, distributed: bool = False, sync_bn: bool = True):
         assert stage in (1, 2, 3)
-        self.cfg, self.stage, self.n_voxels, self.sc = cfg, stage, n_voxels, scales
+        self.cfg, self.stage, self.n_voxels = cfg, stage, n_voxels
+        self.sc = Scales() if scales is None else scales
         self.hp = hp if hp is not None else (WaeHyper() if stage == 1 else WaeHyper.stage23())
         self.device = torch.device(device)
         self.img_enc = EncoderNet(cfg, device)                       # Stage I: trained; II/III: Stage-I teacher
@@ -251,9 +252,10 @@ class DualStage1Step(Stage1Step, _LatentDiscPhase):
     ``torch14_zero_grad=True`` reproduces the pinned torch 1.4: the script's `optimizer_decoder.step()` at :417
     runs on zeroed gradients from the second iteration on, which only decays the decoder's RMSprop state."""
 
-    def __init__(self, cfg: ArchConfig, device, hp: GanHyper = GanHyper(), scales: Scales = Scales(), lam: float = 1.0,
-                 distributed: bool = False, sync_bn: bool = True, torch14_zero_grad: bool = True):
+    def __init__(self, cfg: ArchConfig, device, hp: Optional[GanHyper] = None, scales: Optional[Scales] = None,
+                 lam: float = 1.0, distributed: bool = False, sync_bn: bool = True, torch14_zero_grad: bool = True):
         super().__init__(cfg, device, hp, scales, distributed, sync_bn)
+        hp = self.hp
         self.lam = lam
         self.torch14 = torch14_zero_grad
         self.wd = WaeDiscriminatorNet(cfg, device)

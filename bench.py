@@ -2,7 +2,7 @@
 """Headline benchmark: Stage-I VAE/GAN training step, 64x64x3 stimuli, latent 128, batch 256 per GPU
 (BASELINE.json configs[1]), images/sec, on N MI355X of one node.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 100 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -10,6 +10,12 @@ A "step" = one full pass of the hot path over one synthetic batch already reside
 forward (encoder, 2x decoder, fused REC+GAN discriminator), losses, two-stream backward giving the three
 gradient sets, SUM all-reduce over RCCL (N > 1), gated RMSprop updates, fp16 weight re-pack.
 Prints ONE JSON line on rank 0.
+
+--workload selects the other BASELINE configs (same contract, their own metric names):
+    stage1        configs[1]  Stage-I VAE/GAN 64 px, B = 256 per GPU                       (default, the headline)
+    stage2        configs[2]  Stage-II cognitive VAE/GAN, V = 4096, decoder frozen, B = 256 per GPU
+    dual1         configs[3]  Stage-I WAE / Dual-GAN, B = 128 per GPU (512 over 4 GPUs)
+    stage3_px128  configs[4]  Stage-III cognitive WAE, 128 px stimuli, V = 3620, B = 128 per GPU (1024 over 8 GPUs)
 """
 import argparse
 import json
@@ -27,6 +33,8 @@ import torch  # noqa: E402
 
 FLOP_PER_IMAGE = 13.81e9          # SURVEY 8(d) / BASELINE.md 3: algorithmic Stage-I step FLOPs per image
 MFMA_PEAK_TFLOPS = 2500.0         # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0             # HBM3E peak, MI355X_MICROARCH.md
+NBATCH = 8                        # synthetic batches the timed steps rotate through
 
 
 def host_cores() -> int:
@@ -74,32 +82,175 @@ def cpu_baseline(batch: int, steps: int):
 
 def pmc_traffic(label):
     """(2*FETCH_SIZE + WRITE_SIZE) * 1024 per launch of the kernel `label`, from the committed rocprofv3 PMC passes of
-    this same command (tools/pmc_traffic.py); None when the file or the kernel is not there."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            kernels = json.load(f)["kernels"]
-    except (OSError, ValueError, KeyError):
-        return None
+    this same command (tools/pmc_traffic.py); None when no committed pass holds the kernel."""
     want = label.replace(" ", "")
-    for name, v in kernels.items():
-        n = name.replace(" ", "")
-        n = n[4:] if n.startswith("void") else n
-        if n.split("(")[0] == want:
-            return v["bytes_per_launch"]
-    return None
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
+        try:
+            with open(path) as f:
+                kernels = json.load(f)["kernels"]
+        except (OSError, ValueError, KeyError):
+            continue
+        for kname, v in kernels.items():
+            n = kname.replace(" ", "")
+            n = n[4:] if n.startswith("void") else n
+            if n.split("(")[0] == want:
+                return v["bytes_per_launch"], name
+    return None, None
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# workloads: name -> (metric, unit, description, batch per GPU, builder)
+# a builder returns (step object, run(i) closure issuing one eager step on synthetic batch i % NBATCH, FLOPs per sample)
+# ------------------------------------------------------------------------------------------------------------------
+def _images(rs, B, px, dev):
+    return torch.from_numpy(rs.uniform(-1, 1, (B, 3, px, px)).astype(np.float32)).to(dev)
+
+
+def _noise(rs, k, B, Z, dev):
+    return torch.from_numpy(rs.standard_normal((k, B, Z)).astype(np.float32)).to(dev)
+
+
+def build_stage1(dev, B, rank, dist_on, sync_bn):
+    from fmri_hip.params import ArchConfig, stage1_step_flops
+    from fmri_hip.steps import Stage1Step
+    cfg = ArchConfig.px64()
+    st = Stage1Step(cfg, dev, distributed=dist_on, sync_bn=sync_bn)
+    st.load_recipe(0, False)
+    xs = [_images(np.random.RandomState(1234 + 97 * i + rank), B, 64, dev) for i in range(NBATCH)]
+    nz = [_noise(np.random.RandomState(1236 + 97 * i + rank), 2, B, cfg.latent_dim, dev) for i in range(NBATCH)]
+    return st, (lambda i: st.step(xs[i % NBATCH], nz[i % NBATCH][0], nz[i % NBATCH][1])), stage1_step_flops(cfg), \
+        (xs[0], nz[0][0], nz[0][1])
+
+
+def build_stage2(dev, B, rank, dist_on, sync_bn):
+    from fmri_hip.params import ArchConfig, stage2_step_flops
+    from fmri_hip.steps import CognitiveStep
+    cfg, V = ArchConfig.px64(), 4096
+    st = CognitiveStep(cfg, V, dev, 2, distributed=dist_on, sync_bn=sync_bn)
+    st.load_recipe(1, False)
+    xs = [_images(np.random.RandomState(1234 + 97 * i + rank), B, 64, dev) for i in range(NBATCH)]
+    fm = [torch.from_numpy(np.random.RandomState(1235 + 97 * i + rank).standard_normal((B, V)).astype(np.float32)).to(dev)
+          for i in range(NBATCH)]
+    nz = [_noise(np.random.RandomState(1236 + 97 * i + rank), 3, B, cfg.latent_dim, dev) for i in range(NBATCH)]
+
+    def run(i):
+        j = i % NBATCH
+        return st.step(fm[j], xs[j], nz[j][0], nz[j][1], nz[j][2])
+    return st, run, stage2_step_flops(cfg, V), None
+
+
+def build_dual1(dev, B, rank, dist_on, sync_bn):
+    from fmri_hip.params import ArchConfig, dual1_step_flops
+    from fmri_hip.wae_steps import DualStage1Step
+    cfg = ArchConfig.px64()
+    st = DualStage1Step(cfg, dev, distributed=dist_on, sync_bn=sync_bn)
+    st.load_recipe(8, False)
+    xs = [_images(np.random.RandomState(1234 + 97 * i + rank), B, 64, dev) for i in range(NBATCH)]
+    nz = [_noise(np.random.RandomState(1236 + 97 * i + rank), 3, B, cfg.latent_dim, dev) for i in range(NBATCH)]
+
+    def run(i):
+        j = i % NBATCH
+        return st.step(xs[j], nz[j][0], nz[j][1], nz[j][2])
+    return st, run, dual1_step_flops(cfg), None
+
+
+def build_stage3_px128(dev, B, rank, dist_on, sync_bn):
+    """configs[4]: the WAE Stage-III step (train/train_wae_stage3.py) at 128 px / V = 3620: decoder + latent
+    discriminator trained on the pixel loss + latent penalty; FLOPs per sample = C + decoder forward, weight and data
+    gradient (3 D) + the latent discriminator."""
+    from fmri_hip.params import ArchConfig, forward_flops
+    from fmri_hip.wae_steps import WaeStep
+    cfg, V = ArchConfig.px128(), 3620
+    st = WaeStep(cfg, dev, 3, V, distributed=dist_on, sync_bn=sync_bn)
+    st.load_recipe(7, False)
+    xs = [_images(np.random.RandomState(1234 + 97 * i + rank), B, 128, dev) for i in range(NBATCH)]
+    fm = [torch.from_numpy(np.random.RandomState(1235 + 97 * i + rank).standard_normal((B, V)).astype(np.float32)).to(dev)
+          for i in range(NBATCH)]
+    f = forward_flops(cfg, V)
+    return st, (lambda i: st.step(xs[i % NBATCH], fmri=fm[i % NBATCH])), f["C"] + f["E"] + 3.0 * f["D"] + 8.0 * f["W"], \
+        None
+
+
+WORKLOADS = {
+    "stage1": ("images/sec Stage-I VAE/GAN 64x64 bs256", "images/sec",
+               "Stage-I VAE/GAN training step, 64x64x3 random images, latent 128, RMSprop x3, random-init weights "
+               "(BASELINE configs[1])", 256, build_stage1),
+    "stage2": ("samples/sec Stage-II cognitive VAE/GAN V4096 64x64 bs256", "samples/sec",
+               "Stage-II cognitive VAE/GAN step, synthetic 4096-voxel fMRI -> 64x64 image, teacher distillation, decoder "
+               "frozen, RMSprop x2 (BASELINE configs[2])", 256, build_stage2),
+    "dual1": ("images/sec Stage-I WAE/Dual-GAN 64x64 bs128/GPU", "images/sec",
+              "Stage-I Dual WAE + VAE/GAN step (VAE/GAN step + latent discriminator phase + latent penalty), 64x64x3, "
+              "128 images per GPU (BASELINE configs[3]: 512 over 4 GPUs)", 128, build_dual1),
+    "stage3_px128": ("samples/sec Stage-III cognitive WAE 128x128 V3620 bs128/GPU", "samples/sec",
+                     "Stage-III cognitive WAE step, BOLD5000-shaped 3620-voxel fMRI -> 128x128 image, decoder + latent "
+                     "discriminator trained, Adam (BASELINE configs[4]: 1024 over 8 GPUs)", 128, build_stage3_px128),
+}
+
+
+def hbm_rows(dev, B):
+    """GB/s of the HBM-bound kernels of the path (SURVEY 8d asks for them beside the MFMA roofline), each timed alone
+    with HIP events over 20 launches on data larger than the caches' working set of the step: the cognitive encoder's
+    Linear(V -> 1024) at batch B, the BatchNorm apply / two-stream backward passes on the largest activation
+    (discriminator block 1: 3B x 32 x 32 x 128) and the fused RMSprop update of the encoder's 18 M parameters."""
+    from fmri_hip import lib, ops
+    from fmri_hip.params import ArchConfig
+    from fmri_hip.nets import CognitiveEncoderNet
+    P = lib.ptr
+    out = {}
+
+    def timed(fn, nbytes, reps=20):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        return dict(gb_s=round(nbytes / ms / 1e6, 1), frac_of_peak=round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 3),
+                    us=round(ms * 1e3, 1), mbytes=round(nbytes / 1e6, 1))
+    V = 4096
+    cog = CognitiveEncoderNet(ArchConfig.px64(), V, dev)
+    cog.group.load_recipe(np.random.RandomState(3), False)
+    x = torch.randn(B, V, device=dev).half()
+    cog.fc1.forward(x)
+    out["cognitive_fc1_fwd"] = timed(lambda: cog.fc1.forward(x), 2 * B * V + 2 * V * 1024 + 2 * B * 1024)
+    M, C = 3 * B * 32 * 32, 128
+    raw = torch.randn(M, C, device=dev).half()
+    y = torch.empty_like(raw)
+    sc = torch.ones(C, device=dev)
+    sh = torch.zeros(C, device=dev)
+    out["bn_apply"] = timed(lambda: lib.call("fmri_bn_apply", P(raw), P(y), M, C, P(sc), P(sh), 1), 4 * M * C)
+    dy2 = torch.randn(2 * M, C, device=dev).half()
+    dx2 = torch.empty_like(dy2)
+    s4 = torch.zeros(4, C, device=dev)
+    out["bn_bwd_apply_2streams"] = timed(
+        lambda: lib.call("fmri_bn_bwd_apply2", P(raw), P(dy2), P(dx2), M, C, float(M), P(sh), P(sc), P(sc), P(sh), 1,
+                         P(s4)), 10 * M * C)
+    n = 18_071_360
+    p, g, sq = (torch.randn(n, device=dev) for _ in range(3))
+    sq.abs_()
+    lr = torch.full((1,), 1e-4, device=dev)
+    out["rmsprop_encoder"] = timed(lambda: lib.call("fmri_rmsprop_dev", P(p), P(g), P(sq), n, P(lr), 0.9, 1e-8, 1.0,
+                                                    None, 0.0, None), 20 * n)
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=256, help="images per GPU (weak scaling)")
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="stage1")
+    ap.add_argument("--batch", type=int, default=0, help="samples per GPU (weak scaling); 0 = the workload's own")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hbm-rows", action="store_true")
     ap.add_argument("--sync-bn", action="store_true",
-                    help="data-parallel runs: all-reduce the BatchNorm partial sums (statistics of the GLOBAL batch, 32 "
-                         "small collectives per step).  Default: per-rank statistics over the rank's own 256 images, "
+                    help="data-parallel runs: all-reduce the BatchNorm partial sums (statistics of the GLOBAL batch, one "
+                         "small collective per BatchNorm call).  Default: per-rank statistics over the rank's own batch, "
                          "i.e. what the single-GPU reference computes per batch and what torch DDP does by default")
     ap.add_argument("--local-bn", action="store_true", help="(default; kept for compatibility)")
     ap.add_argument("--serial", action="store_true",
@@ -137,42 +288,50 @@ def main():
     if a.serial:
         os.environ["FMRI_SIDE_STREAM"] = "off"
     from fmri_hip import lib, ops
-    from fmri_hip.params import ArchConfig
-    from fmri_hip.steps import Stage1Step
     lib.load()
 
-    cfg = ArchConfig.px64()
-    B = a.batch
-    st = Stage1Step(cfg, dev, distributed=world > 1 or force_dist, sync_bn=a.sync_bn)
-    st.load_recipe(0, False)
-    x = torch.from_numpy(np.random.RandomState(1234 + rank).uniform(-1, 1, (B, 3, 64, 64)).astype(np.float32)).to(dev)
-    nz = torch.from_numpy(np.random.RandomState(1236 + rank).standard_normal((2, B, cfg.latent_dim))
-                          .astype(np.float32)).to(dev)
+    metric, unit, desc, wl_batch, builder = WORKLOADS[a.workload]
+    B = a.batch or wl_batch
+    st, run_i, flop_per_sample, static = builder(dev, B, rank, world > 1 or force_dist, a.sync_bn)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    log(f"rank {rank}/{world}: model built, batch {B}; host cores {host_cores()} (cpu_count {os.cpu_count()})")
+    log(f"rank {rank}/{world}: {a.workload} built, batch {B}; host cores {host_cores()} (cpu_count {os.cpu_count()})")
     for i in range(a.warmup):
-        st.step(x, nz[0], nz[1])
+        run_i(i)
         if i == 0:
             torch.cuda.synchronize()
             log("first step done")
     barrier()
     log("warm-up done")
-    # The step (forward, losses, gate, two-stream backward, three optimizer updates, weight repack) is recorded once
-    # into HIP graphs and the K timed steps are K replays -- the same launches, issued by the GPU front end instead of
-    # ~370 Python/ctypes calls, so the number does not depend on the host CPU of the box.  In multi-process runs the
-    # RCCL collectives stay eager calls between the graph segments.  --eager issues every launch from Python.
-    eager_run = lambda: st.step(x, nz[0], nz[1])
-    modes = {"eager": eager_run}
+    # Launch modes.  eager: every launch issued from Python, over NBATCH rotating synthetic batches.  For the headline
+    # workload the step can also be recorded into HIP graphs (graph: one-stream full step; hybrid: recorded forward +
+    # eager two-stream backward): the recorded inputs are static buffers, refreshed from the rotating batches by three
+    # device copies per step inside the timed region.  In multi-process runs the RCCL collectives stay eager calls
+    # between the graph segments.  A short probe picks the fastest mode, the same on every rank.
+    modes = {"eager": run_i}
     single = world == 1 and not force_dist
-    if not a.eager:
+    if a.workload == "stage1" and not a.eager:
+        sx, se, sz = (t.clone() for t in static)
+        # the rotating batches (same seeds as the builder's) that feed the static input buffers of the recorded modes
+        rs_x = [_images(np.random.RandomState(1234 + 97 * i + rank), B, 64, dev) for i in range(NBATCH)]
+        rs_n = [_noise(np.random.RandomState(1236 + 97 * i + rank), 2, B, 128, dev) for i in range(NBATCH)]
+
+        def staged(replay):
+            def run(i):
+                j = i % NBATCH
+                sx.copy_(rs_x[j])
+                se.copy_(rs_n[j][0])
+                sz.copy_(rs_n[j][1])
+                return replay()
+            return run
         try:
-            modes["graph"] = st.capture(x, nz[0], nz[1])
-            modes["graph"]()
+            g = st.capture(sx, se, sz)
+            modes["graph"] = staged(g)
+            modes["graph"](0)
             log("step captured into HIP graph(s)")
         except Exception as e:               # capture is an optimisation: fall back to eager launches
             log(f"graph capture failed ({type(e).__name__}: {e}); continuing with eager launches")
@@ -180,8 +339,9 @@ def main():
         if (single or not a.sync_bn) and ops._SIDE["on"] and not a.graph:
             # hybrid: recorded forward + eagerly issued two-stream backward (half the Python work of a step)
             try:
-                modes["hybrid"] = st.capture_forward(x, nz[0], nz[1])
-                modes["hybrid"]()
+                h = st.capture_forward(sx, se, sz)
+                modes["hybrid"] = staged(h)
+                modes["hybrid"](0)
             except Exception as e:
                 log(f"forward capture failed ({type(e).__name__}: {e})")
                 modes.pop("hybrid", None)
@@ -197,8 +357,8 @@ def main():
     def probe(fn, n=6):
         barrier()
         t = time.perf_counter()
-        for _ in range(n):
-            fn()
+        for i in range(n):
+            fn(i)
         barrier()
         tt = torch.tensor([time.perf_counter() - t], dtype=torch.float64, device=dev)
         if world > 1:
@@ -213,24 +373,23 @@ def main():
         mode = min(times, key=times.get)
         log("probe: " + ", ".join(f"{k} {1e3 * v:.2f} ms/step" for k, v in times.items()) + f" -> {mode}")
     run = modes[mode]
-    use_graph = mode == "graph"
     barrier()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        run()
+    for i in range(a.steps):
+        run(i)
     barrier()
     dt = time.perf_counter() - t0
     log(f"timed region done: {1e3 * dt / a.steps:.2f} ms/step ({mode})")
-    # dominant-kernel timing: HIP events around every launch of that kernel over a few eagerly issued steps (events
-    # cannot be placed inside a replayed graph)
-    # The side stream is switched off for this pass: next to concurrently running weight-gradient kernels a launch's
-    # duration says nothing about the kernel (igemm_win: 276 us alone, 345 us while sharing the CUs).
+    logs = st.logs()
+    # dominant-kernel timing: HIP events around every fmri_igemm launch over a few eagerly issued steps (events cannot be
+    # placed inside a replayed graph).  The side stream is switched off for this pass: next to concurrently running
+    # weight-gradient kernels a launch's duration says nothing about the kernel.
     ops.join_side()
     side_was, ops._SIDE["on"] = ops._SIDE["on"], False
     ops.PROFILE = [] if rank == 0 else None
     prof_steps = min(a.steps, 5)
-    for _ in range(prof_steps):
-        st.step(x, nz[0], nz[1])
+    for i in range(prof_steps):
+        run_i(i)
     barrier()
     prof, ops.PROFILE = ops.PROFILE, None
     ops._SIDE["on"] = side_was
@@ -238,7 +397,6 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-    logs = st.logs()
 
     if rank == 0:
         value = world * B * a.steps / dt
@@ -252,33 +410,42 @@ def main():
         label, (ms, fl, nl) = max(by.items(), key=lambda kv: kv[1][0]) if by else ("none", (0.0, 0.0, 0))
         nl = max(nl, 1)
         achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        traffic, traffic_src = pmc_traffic(label)
+        finite = all(np.isfinite(v) for v in logs.values() if isinstance(v, float))
         out = {
-            "metric": "images/sec Stage-I VAE/GAN 64x64 bs256", "value": round(value, 1), "unit": "images/sec",
+            "metric": metric, "value": round(value, 1), "unit": unit,
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "Stage-I VAE/GAN training step, 64x64x3 random images, latent 128, "
-                                   "RMSprop x3, random-init weights (BASELINE configs[1])",
-                       "batch_per_gpu": B, "global_batch": B * world,
+            "config": {"workload": desc, "name": a.workload, "batch_per_gpu": B, "global_batch": B * world,
+                       "synthetic_batches": NBATCH,
                        "parallelism": f"dp{world}" + ("" if world == 1 else ("-syncbn" if a.sync_bn else "-localbn"))},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(label),
-                         "traffic_unit": "bytes per launch leaving L2 (PMC passes of this workload recorded in "
-                                         "profiles/r01_pmc_traffic.json; hardware counters cannot be read in-process)",
+                         "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "traffic_unit": "bytes per launch leaving L2, (2*FETCH_SIZE + WRITE_SIZE)*1024 of the rocprofv3 "
+                                         f"PMC passes of this workload committed as profiles/{traffic_src} (hardware "
+                                         "counters cannot be read in-process)" if traffic else None,
                          "kernel": label,
                          "measured": "HIP events around each launch of the kernel, 5 steps issued on ONE stream (the "
                                      "timed region overlaps weight gradients on a second stream when launched eagerly)",
                          "launches_per_step": nl // max(prof_steps, 1),
                          "avg_launch_ms": round(ms / nl, 4),
-                         "avg_launch_gflop": round(fl / nl / 1e9, 2)},
+                         "avg_launch_gflop": round(fl / nl / 1e9, 2),
+                         "other_kernels": {k: {"tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1),
+                                               "ms_per_step": round(v[0] / max(prof_steps, 1), 3)}
+                                           for k, v in sorted(by.items(), key=lambda kv: -kv[1][0])[1:6] if v[0] > 0}},
             "launch": {"graph": "hip-graph replay" if single else "hip-graph segments + eager collectives",
                        "hybrid": "forward replayed from a HIP graph, backward eager with weight gradients on a side "
                                  "stream" + ("" if single else " and eager collectives"),
                        "eager": "eager, one stream" if not ops._SIDE["on"]
                        else "eager, weight gradients on a side stream"}[mode],
-            "step_mfma_frac": round(value / world * FLOP_PER_IMAGE / 1e12 / MFMA_PEAK_TFLOPS, 4),
-            "losses_last_step": {k: logs[k] for k in ("loss_encoder", "loss_decoder", "loss_discriminator", "kl")},
+            "step_mfma_frac": round(value / world * flop_per_sample / 1e12 / MFMA_PEAK_TFLOPS, 4),
+            "gflop_per_sample": round(flop_per_sample / 1e9, 2),
+            "losses_last_step": {k: v for k, v in logs.items() if isinstance(v, float)},
+            "losses_finite": bool(finite),
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_hbm_rows:
+            out["hbm_bound_kernels"] = dict(peak_gb_s=HBM_PEAK_GBS, rows=hbm_rows(dev, 256))
+        if world == 1 and not a.no_cpu_baseline and a.workload == "stage1":
             out["cpu_baseline"] = cpu_baseline(32, 10)        # ~10-15 s of CPU work (bounded to 25 s inside)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1 or force_dist:

@@ -178,3 +178,166 @@ def test_eval_forward_matches_reference_golden(golden_dir):
     ref_sd = eval_state(cfg, seed)
     for k in ("encoder.conv.0.bn.running_mean", "decoder.fc.1.running_var", "decoder.conv.2.bn.num_batches_tracked"):
         assert torch.equal(sd[k].cpu().reshape(-1).float(), ref_sd[k].reshape(-1).float()), k
+
+
+@pytest.mark.gpu
+def test_literal_stage2_loop_body_runs_on_engine():
+    """The Stage-II loop body of train/train_vgan_stage2.py:330-407 on the drop-in modules: VaeGanCognitive wiring with
+    the teacher distillation (models/vae_gan.py:359-395, noise passed explicitly in the reference's draw order),
+    ``loss_encoder.backward(retain_graph=True)``, ``p.grad.data.clamp_(-1, 1)``, ``optimizer_encoder.step()``,
+    ``model.zero_grad()``, then the discriminator the same way -- against the oracle's Stage-II step."""
+    from oracle import vaegan_oracle as O
+    import gradcheck
+    _cfg64()
+    import models.vae_gan as vg
+    dev = "cuda:0"
+    cfg = O.ArchCfg.px64()
+    B, V, seed = 4, 4096, 1
+    data = O.synth_batch(B, cfg, n_voxels=V, seed=1234, steps=1)
+    tsd = O.fill_state(O.vaegan_spec(cfg), seed, True)
+    csd = O.fill_state(O.cognitive_encoder_spec(cfg, V), seed + 100, True)
+    teacher = vg.VaeGan(device=dev, z_size=128).to(dev)
+    teacher.load_state_dict(tsd)
+    cog = vg.CognitiveEncoder(input_size=V, z_size=128).to(dev)
+    cog.load_state_dict({k[len("encoder."):]: v for k, v in csd.items()})
+    model = vg.VaeGanCognitive(device=dev, encoder=cog, decoder=teacher.decoder, discriminator=teacher.discriminator,
+                               teacher_net=teacher, stage=2, z_size=128).to(dev)
+    model.train()
+    lr = 1e-4
+    mk = lambda p: torch.optim.RMSprop(params=p, lr=lr, alpha=0.9, eps=1e-8, weight_decay=0, momentum=0, centered=False)
+    opt_e, opt_s = mk(model.encoder.parameters()), mk(model.discriminator.parameters())
+    fmri, image = data["fmri"].to(dev), data["x"].to(dev)
+    nz = data["noise"][0]
+    eps, z_p, eps_t = nz[0].to(dev), nz[1].to(dev).requires_grad_(True), nz[2].to(dev)
+    mus, lv = model.encoder(fmri)
+    x_tilde = model.decoder(eps * torch.exp(0.5 * lv) + mus)
+    for param in model.teacher_net.encoder.parameters():
+        param.requires_grad = False
+    mu_t, lv_t = model.teacher_net.encoder(image)
+    gt_x = model.decoder(eps_t * torch.exp(0.5 * lv_t) + mu_t)
+    x_p = model.decoder(z_p)
+    disc_layer = model.discriminator(gt_x, x_tilde, x_p, "REC")
+    disc_class = model.discriminator(gt_x, x_tilde, x_p, "GAN")
+    nle, kld, mse, bo, bp, bs = vg.VaeGanCognitive.loss(gt_x, x_tilde, disc_layer[:B], disc_layer[B:-B], disc_layer[-B:],
+                                                        disc_class[:B], disc_class[B:-B], disc_class[-B:], mus, lv)
+    loss_encoder = torch.sum(kld) + torch.sum(mse)
+    loss_discriminator = torch.sum(bo) + torch.sum(bp) + torch.sum(bs)
+    model.zero_grad()
+    loss_encoder.backward(retain_graph=True)
+    [p.grad.data.clamp_(-1, 1) for p in model.encoder.parameters()]
+    g_enc = {"encoder." + k: p.grad.clone() for k, p in model.encoder.named_parameters()}
+    opt_e.step()
+    model.zero_grad()
+    loss_discriminator.backward()
+    [p.grad.data.clamp_(-1, 1) for p in model.discriminator.parameters()]
+    g_dis = {"discriminator." + k: p.grad.clone() for k, p in model.discriminator.named_parameters()}
+    opt_s.step()
+    # oracle (its optimizer steps update the tensors in place: keep the initial values)
+    w_init = {k: v.clone() for k, v in {**tsd, **csd}.items()}
+    P = dict(csd)
+    P.update({k: v for k, v in tsd.items() if k.startswith(("decoder.", "discriminator."))})
+    for k, v in tsd.items():
+        P["teacher_net." + k] = P[k] if k.startswith(("decoder.", "discriminator.")) else v
+    opts = {n: O.OptState(kind="rmsprop", lr=lr) for n in ("encoder", "decoder", "discriminator")}
+    ref = O.stage2_step(P, opts, data["fmri"], data["x"], nz, cfg, V, keep_grads=True)
+    got = dict(loss_encoder=loss_encoder.item(), loss_discriminator=loss_discriminator.item(), nle=nle.sum().item(),
+               kl=kld.sum().item(), mse=mse.sum().item(), bce_orig=bo.sum().item(), bce_pred=bp.sum().item(),
+               bce_samp=bs.sum().item())
+    for k, v in got.items():
+        assert abs(v - ref["logs"][k]) < 1e-3 * abs(ref["logs"][k]), (k, v, ref["logs"][k])
+    # gradients BEFORE the clamp are what the oracle returns; the clamp only touches elements beyond +-1
+    grads = {**g_enc, **g_dis}
+    refg = {k: v.clamp(-1, 1) for k, v in ref["grads"].items() if v is not None}
+    gradcheck.check(grads, refg, refg, "api stage2", tol16=None)
+    # the two optimizer steps moved the same parameters the same way: RMSprop's first update is +-3.16 lr per element
+    # (sign-like), so compare the UPDATE vectors -- a few % of the signs differ under fp16 noise at B = 4
+    sd = model.state_dict()
+    for k, v in P.items():
+        if k.startswith(("encoder.", "discriminator.")) and v.dtype == torch.float32 and "running" not in k \
+                and v.numel() > 1000:
+            w0 = w_init[k].reshape(-1)
+            ua, ub = sd[k].float().cpu().reshape(-1) - w0, v.reshape(-1) - w0
+            cos = (ua @ ub / (ua.norm() * ub.norm() + 1e-30)).item()
+            assert cos > 0.9 and abs(ua.norm().item() / ub.norm().item() - 1) < 0.05, (k, cos)
+
+
+@pytest.mark.gpu
+def test_literal_wae_stage1_loop_body_runs_on_engine():
+    """The WAE Stage-I loop body of train/train_wae_stage1.py:259-311 on the drop-in modules, including the
+    ``requires_grad`` toggling between the two phases (free_params / frozen_params, :33-40) and the pairs of
+    ``backward(retain_graph=True)`` calls -- against the oracle's WAE Stage-I step."""
+    from oracle import vaegan_oracle as O
+    _cfg64()
+    import models.vae_gan as vg
+    dev = "cuda:0"
+    cfg = O.ArchCfg.px64()
+    B, seed = 4, 5
+    data = O.synth_batch(B, cfg, seed=1234, steps=1)
+    sd0 = O.fill_state(O.encoder_spec(cfg) + O.decoder_spec(cfg) + O.wae_discriminator_spec(cfg), seed, False)
+    model = vg.WaeGan(device=dev, z_size=128).to(dev)
+    model.load_state_dict(sd0)
+
+    def free_params(module):
+        for p in module.parameters():
+            p.requires_grad = True
+
+    def frozen_params(module):
+        for p in module.parameters():
+            p.requires_grad = False
+    opt_enc = torch.optim.Adam(model.encoder.parameters(), lr=1e-4, betas=(0.5, 0.999))
+    opt_dec = torch.optim.Adam(model.decoder.parameters(), lr=1e-4, betas=(0.5, 0.999))
+    opt_dis = torch.optim.Adam(model.discriminator.parameters(), lr=0.5e-4, betas=(0.5, 0.999))
+    x = data["x"].to(dev)
+    model.train()
+    model.encoder.zero_grad()
+    model.decoder.zero_grad()
+    model.discriminator.zero_grad()
+    # ---------- discriminator phase
+    frozen_params(model.decoder)
+    frozen_params(model.encoder)
+    free_params(model.discriminator)
+    z_real, var = model.encoder(x)
+    z_fake = (data["noise"][0, 2] * 0.5).to(dev)
+    d_real = model.discriminator(z_real)
+    d_fake = model.discriminator(z_fake)
+    loss_discriminator_fake = -10 * torch.sum(torch.log(d_fake + 1e-3))
+    loss_discriminator_real = -10 * torch.sum(torch.log(1 - d_real + 1e-3))
+    loss_discriminator_fake.backward(retain_graph=True)
+    loss_discriminator_real.backward(retain_graph=True)
+    opt_dis.step()
+    # ---------- generator phase
+    free_params(model.encoder)
+    free_params(model.decoder)
+    frozen_params(model.discriminator)
+    z_real, var = model.encoder(x)
+    x_recon = model.decoder(z_real)
+    d_real = model.discriminator(z_real)
+    loss_reconstruction = torch.sum(torch.sum(0.5 * (x_recon - x) ** 2, 1))
+    loss_penalty = -10 * torch.sum(torch.log(d_real + 1e-3))
+    loss_reconstruction.backward(retain_graph=True)
+    loss_penalty.backward()
+    opt_enc.step()
+    opt_dec.step()
+    # oracle
+    P = O.fill_state(O.encoder_spec(cfg) + O.decoder_spec(cfg) + O.wae_discriminator_spec(cfg), seed, False)
+    opts = {"encoder": O.OptState(kind="adam", lr=1e-4), "decoder": O.OptState(kind="adam", lr=1e-4),
+            "discriminator": O.OptState(kind="adam", lr=0.5e-4)}
+    ref = O.wae_stage1_step(P, opts, data["x"], data["noise"][0, 2], cfg)
+    got = dict(loss_reconstruction=loss_reconstruction.item(), loss_penalty=loss_penalty.item(),
+               loss_discriminator_fake=loss_discriminator_fake.item(),
+               loss_discriminator_real=loss_discriminator_real.item())
+    for k, v in got.items():
+        tol = 5e-3 if k == "loss_penalty" else 1e-3        # the penalty is scored after the discriminator's Adam step
+        assert abs(v - ref["logs"][k]) < tol * abs(ref["logs"][k]), (k, v, ref["logs"][k])
+    # Adam's first update is lr * sign(g): compare the update vectors (elements whose gradient changed sign under fp16
+    # noise move the other way)
+    sd = model.state_dict()
+    for k, v in P.items():
+        if v.dtype == torch.float32 and "running" not in k and v.numel() > 1000:
+            w0 = sd0[k].reshape(-1)
+            ua, ub = sd[k].float().cpu().reshape(-1) - w0, v.reshape(-1) - w0
+            if ub.norm().item() == 0.0:          # l_var: the WAE encoder's variance head receives no gradient
+                assert ua.norm().item() == 0.0, k
+                continue
+            cos = (ua @ ub / (ua.norm() * ub.norm() + 1e-30)).item()
+            assert cos > 0.9 and abs(ua.norm().item() / ub.norm().item() - 1) < 0.05, (k, cos)

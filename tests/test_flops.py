@@ -3,7 +3,7 @@
 128 px: E = 1012.9, D = 3450.9, S = 875.3, step 31.62 GFLOP / image)."""
 import pytest
 
-from fmri_hip.params import ArchConfig, forward_flops, stage1_step_flops
+from fmri_hip.params import ArchConfig, forward_flops, stage1_step_flops, stage2_step_flops
 
 
 def test_px64_constants():
@@ -33,3 +33,7 @@ def test_px100_as_shipped():
 def test_bench_constant_matches_counter():
     import bench
     assert bench.FLOP_PER_IMAGE == pytest.approx(stage1_step_flops(ArchConfig.px64()), rel=1e-3)
+
+
+def test_stage2_constant():
+    assert round(stage2_step_flops(ArchConfig.px64(), 4096) / 1e9, 2) == 11.61

@@ -173,3 +173,48 @@ def test_checkpoint_bridge_stage1_to_stage2_to_stage3(tmp_path):
         assert torch.equal(v, ck2[k]), k
     s3.step(fmri, x, nz[0], nz[1])
     assert np.isfinite(s3.logs()["loss_decoder"])
+
+
+def test_stage3_px128_matches_reference_golden(golden_dir):
+    """BASELINE configs[4] shape (128 px, V = 3620), Stage III of the VAE/GAN: first-step losses against the numbers the
+    real reference produced (tests/golden/stage3_px128_b2.npz)."""
+    from oracle import vaegan_oracle as O
+    from fmri_hip.params import ArchConfig
+    from fmri_hip.steps import CognitiveStep
+    g = np.load(os.path.join(golden_dir, "stage3_px128_b2.npz"))
+    B, V, seed, perturb = int(g["meta/B"]), int(g["meta/V"]), int(g["meta/seed"]), bool(g["meta/perturb"])
+    cfg_o = O.ArchCfg.px128()
+    data = O.synth_batch(B, cfg_o, n_voxels=V, seed=1234, steps=1)
+    st = CognitiveStep(ArchConfig.px128(), V, DEV, 3)
+    st.load_recipe(seed, perturb)
+    nz = data["noise"][0]
+    st.step(data["fmri"].to(DEV), data["x"].to(DEV), nz[0].to(DEV), nz[1].to(DEV), nz[2].to(DEV))
+    logs = st.logs()
+    for k in LOSS_KEYS:
+        want = float(g[f"step0/logs/{k}"])
+        print(k, logs[k], want, _rel(logs[k], want))
+        assert _rel(logs[k], want) < 1e-3, (k, logs[k], want)
+    assert logs["train_dis"] == bool(g["step0/logs/train_dis"]) and logs["train_dec"] == bool(g["step0/logs/train_dec"])
+
+
+def test_stage2_full_batch_first_step_matches_oracle():
+    """BASELINE configs[2] (Stage II, V = 4096, B = 256, decoder frozen): first-step losses against the CPU oracle run
+    live on the same seeded inputs."""
+    from oracle import vaegan_oracle as O
+    from fmri_hip.params import ArchConfig
+    from fmri_hip.steps import CognitiveStep
+    B, V, seed = 256, 4096, 1
+    cfg_o = O.ArchCfg.px64()
+    data = O.synth_batch(B, cfg_o, n_voxels=V, seed=1234, steps=1)
+    st = CognitiveStep(ArchConfig.px64(), V, DEV, 2)
+    st.load_recipe(seed, True)
+    P, _ = _oracle_state(O, cfg_o, V, seed, True, 2)
+    opts = {n: O.OptState(kind="rmsprop", lr=1e-4) for n in ("encoder", "decoder", "discriminator")}
+    nz = data["noise"][0]
+    st.step(data["fmri"].to(DEV), data["x"].to(DEV), nz[0].to(DEV), nz[1].to(DEV), nz[2].to(DEV))
+    logs = st.logs()
+    ref = O.stage2_step(P, opts, data["fmri"], data["x"], nz, cfg_o, V)
+    for k in LOSS_KEYS:
+        print(k, logs[k], ref["logs"][k], _rel(logs[k], ref["logs"][k]))
+        assert _rel(logs[k], ref["logs"][k]) < 1e-3, (k, logs[k], ref["logs"][k])
+    assert logs["train_dis"] and not logs["train_dec"]

@@ -188,3 +188,48 @@ def test_dual_stage1_matches_oracle_and_golden(golden_dir):
                 assert _terr(grads[k], ref["grads"][k]) < 0.1, k
         # running statistics after the first (sign-like) parameter update follow the 5e-2 "next forward" bound
         _check_counters(st, g, f"step{s}", 2e-2 if s == 0 else 5e-2)
+
+
+def test_wae_stage3_px128_matches_reference_golden(golden_dir):
+    """BASELINE configs[4] (Stage-III cognitive WAE, 128 x 128 stimuli, BOLD5000-shaped V = 3620): first-step losses
+    against the numbers the real reference produced (tests/golden/wae3_px128_b2.npz)."""
+    from oracle import vaegan_oracle as O
+    from fmri_hip.params import ArchConfig
+    from fmri_hip.wae_steps import WaeStep
+    g = np.load(os.path.join(golden_dir, "wae3_px128_b2.npz"))
+    B, V, seed = int(g["meta/B"]), int(g["meta/V"]), int(g["meta/seed"])
+    cfg_o = O.ArchCfg.px128()
+    data = O.synth_batch(B, cfg_o, n_voxels=V, seed=1234, steps=1)
+    st = WaeStep(ArchConfig.px128(), DEV, 3, V)
+    st.load_recipe(seed, False)
+    st.step(data["x"].to(DEV), fmri=data["fmri"].to(DEV))
+    logs = st.logs()
+    for k in WAE_KEYS:
+        want = float(g[f"step0/logs/{k}"])
+        print(k, logs[k], want, _rel(logs[k], want))
+        assert _rel(logs[k], want) < (1e-3 if k != "loss_penalty" else 5e-3), (k, logs[k], want)
+
+
+def test_dual_stage1_batch128_first_step_matches_oracle():
+    """BASELINE configs[3] per-GPU shape (Dual WAE + VAE/GAN Stage I, 512 images over 4 GPUs = 128 per GPU): first-step
+    losses against the CPU oracle run live."""
+    from oracle import vaegan_oracle as O
+    from fmri_hip.params import ArchConfig
+    from fmri_hip.wae_steps import DualStage1Step
+    B, seed, lam = 128, 8, 1.0
+    cfg_o = O.ArchCfg.px64()
+    data = O.synth_batch(B, cfg_o, seed=1234, steps=1)
+    st = DualStage1Step(ArchConfig.px64(), DEV, lam=lam)
+    st.load_recipe(seed, True)
+    P = O.fill_state(O.vaegan_spec(cfg_o), seed, True)
+    P.update(O.fill_state(O.wae_discriminator_spec(cfg_o, pre="wae_discriminator."), seed + 200, True))
+    opts = {n: O.OptState(kind="rmsprop", lr=1e-4) for n in ("encoder", "decoder", "discriminator",
+                                                                "wae_discriminator")}
+    nz = data["noise"][0]
+    st.step(data["x"].to(DEV), nz[0].to(DEV), nz[1].to(DEV), nz[2].to(DEV))
+    logs = st.logs()
+    ref = O.dual_stage1_step(P, opts, data["x"], nz, cfg_o, lam=lam)
+    assert logs["train_dis"] == ref["logs"]["train_dis"] and logs["train_dec"] == ref["logs"]["train_dec"]
+    for k in GAN_KEYS + WAE_KEYS[1:]:
+        print(k, logs[k], ref["logs"][k], _rel(logs[k], ref["logs"][k]))
+        assert _rel(logs[k], ref["logs"][k]) < 1e-3, (k, logs[k], ref["logs"][k])

@@ -262,3 +262,25 @@ def stage1_step_flops(cfg: ArchConfig) -> float:
     """Stage-I step = 3 x (E + 2 D + 3 S) per image (forward + wgrad + dgrad, each layer once)."""
     f = forward_flops(cfg)
     return 3.0 * (f["E"] + 2.0 * f["D"] + 3.0 * f["S"])
+
+
+def stage2_step_flops(cfg: ArchConfig, n_voxels: int = 4096) -> float:
+    """Stage-II step per sample: forward C + E(teacher) + 3 D + 3 S; discriminator weight + data gradient
+    2 x 3 S; decoder data gradient on the x_tilde path D (decoder frozen); cognitive encoder weight + data gradient 2 C."""
+    f = forward_flops(cfg, n_voxels)
+    return (f["C"] + f["E"] + 3.0 * f["D"] + 3.0 * f["S"]) + 6.0 * f["S"] + f["D"] + 2.0 * f["C"]
+
+
+def stage3_step_flops(cfg: ArchConfig, n_voxels: int = 4096) -> float:
+    """Stage-III step per sample (cognitive encoder frozen): forward C + 2 D + 3 S, weight + data gradients of the
+    discriminator (2 x 3 S) and of the two decoder calls (2 x 2 D)."""
+    f = forward_flops(cfg, n_voxels)
+    return f["C"] + 6.0 * f["D"] + 9.0 * f["S"]
+
+
+def dual1_step_flops(cfg: ArchConfig) -> float:
+    """Dual WAE + VAE/GAN Stage-I step per image: the Stage-I step, the third decoder call on the encoder means
+    (forward only: it moves BatchNorm statistics, train/wae_vgan_stage1.py:406) and the latent discriminator (D phase on
+    2 rows per image forward + weight + data gradient, penalty pass forward + data gradient)."""
+    f = forward_flops(cfg)
+    return stage1_step_flops(cfg) + f["D"] + (2.0 * 3.0 + 2.0) * f["W"]

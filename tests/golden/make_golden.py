@@ -662,27 +662,52 @@ def case_eval(name, cfg, B, seed):
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
 
 
+def load_reference_data_loader():
+    """Import the reference's ``data_preprocessing.data_loader`` (for its ``rand_shift`` and ``GreyToColor``).  Its
+    top-level imports of packages that are not installed here and that those two never touch (nibabel, skimage) are
+    satisfied with empty stub modules, like torchvision for models.vae_gan."""
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    for name in ("nibabel", "skimage", "skimage.transform"):
+        if name not in sys.modules:
+            try:
+                importlib.import_module(name)
+            except ImportError:
+                sys.modules[name] = types.ModuleType(name)
+    if isinstance(sys.modules.get("skimage"), types.ModuleType) and not hasattr(sys.modules["skimage"], "transform"):
+        sys.modules["skimage"].transform = sys.modules["skimage.transform"]
+    for m in ("configs.data_config", "configs"):
+        sys.modules.pop(m, None)
+    return importlib.import_module("data_preprocessing.data_loader")
+
+
 def case_ingest(name):
-    """Tail of the image pipeline on uint8 images: torchvision-0.5 / scipy semantics evaluated with the real libraries
-    that are present here (scipy.ndimage.shift as called at data_preprocessing/data_loader.py:216; ToTensor /
-    Normalize / flip restated with torch ops -- torchvision itself is not installed in the build container)."""
-    from scipy.ndimage import shift as nd_shift
+    """Tail of the image pipeline on uint8 images (train_vgan_stage1.py:162-170, data_loader.py:186-217):
+    RandomHorizontalFlip -> RandomShift -> ToTensor -> GreyToColor -> Normalize.  The shift and the grey -> colour
+    step are the REFERENCE'S OWN ``rand_shift`` (seeded numpy draw, scipy.ndimage.shift nearest / order 0) and
+    ``GreyToColor`` (data_preprocessing/data_loader.py:203-217, :374-400), imported from /root/reference; ToTensor /
+    Normalize / the flip are torchvision-0.5 semantics restated with torch ops (torchvision is not installed here)."""
+    dl = load_reference_data_loader()
     rs = np.random.RandomState(31)
     out = {"meta/case": np.array("ingest")}
-    for tag, n, h, w, c in (("rgb", 3, 20, 24, 3), ("grey", 2, 17, 13, 1)):
+    for tag, n, h, w, c in (("rgb", 3, 20, 24, 3), ("grey", 2, 16, 16, 1)):
         img = rs.randint(0, 256, (n, h, w, c)).astype(np.uint8)
         flip = rs.randint(0, 2, n).astype(np.int32)
-        shifts = rs.randint(-5, 6, (n, 2)).astype(np.int32)
+        shifts = np.zeros((n, 2), np.int32)
         mean, std = (0.5, 0.5, 0.5), (0.5, 0.5, 0.5)
         res = []
         for i in range(n):
             a = img[i]
             if flip[i]:
                 a = np.ascontiguousarray(a[:, ::-1, :])
-            a = nd_shift(a, [int(shifts[i, 0]), int(shifts[i, 1]), 0], prefilter=False, order=0, mode="nearest")
+            seed = 1000 + 17 * i + (0 if tag == "rgb" else 500)
+            np.random.seed(seed)
+            shifts[i] = np.random.randint(-5, 6, size=2)              # the draw rand_shift makes (data_loader.py:215)
+            np.random.seed(seed)
+            a = dl.rand_shift(a, 5)                                    # REFERENCE code
             t = torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1))).float().div(255)      # ToTensor
             if t.shape[0] != 3:
-                t = t.expand(3, h, w).clone()                                                       # GreyToColor
+                t = dl.GreyToColor(h)(t[0]).clone()                    # REFERENCE code (square grey images)
             t = (t - torch.tensor(mean).view(3, 1, 1)) / torch.tensor(std).view(3, 1, 1)           # Normalize
             res.append(t.numpy())
         out[f"{tag}/img"] = img

@@ -341,3 +341,70 @@ def test_literal_wae_stage1_loop_body_runs_on_engine():
                 continue
             cos = (ua @ ub / (ua.norm() * ub.norm() + 1e-30)).item()
             assert cos > 0.9 and abs(ua.norm().item() / ub.norm().item() - 1) < 0.05, (k, cos)
+
+
+def test_init_parameters_bounds_and_fans():
+    """VaeGan.init_parameters (reference models/vae_gan.py:252-264): every Conv2d / ConvTranspose2d / Linear weight is
+    U(-s, s) with s = 1 / sqrt(prod(shape[1:])) / sqrt(3) -- for a ConvTranspose2d that fan is (C_out, k, k), not C_in --
+    biases are 0, BatchNorm parameters are left at their defaults."""
+    import math
+    _cfg64()
+    import models.vae_gan as vg
+    torch.manual_seed(11)
+    m = vg.VaeGan(device="cpu", z_size=128)
+    seen = 0
+    for name, mod in m.named_modules():
+        if isinstance(mod, (torch.nn.Conv2d, torch.nn.ConvTranspose2d, torch.nn.Linear)):
+            w = mod.weight.detach()
+            s = 1.0 / math.sqrt(float(np.prod(w.shape[1:]))) / math.sqrt(3.0)
+            assert float(w.abs().max()) <= s * (1 + 1e-6), name
+            if w.numel() >= 1000:
+                assert float(w.abs().max()) > 0.98 * s, name                       # the bound is attained
+                assert abs(float(w.std()) - s / math.sqrt(3.0)) < 0.05 * s, name    # uniform, not normal
+                assert abs(float(w.mean())) < 0.05 * s, name
+            if mod.bias is not None:
+                assert float(mod.bias.detach().abs().max()) == 0.0, name
+            seen += 1
+        elif isinstance(mod, (torch.nn.BatchNorm2d, torch.nn.BatchNorm1d)):
+            assert torch.equal(mod.weight.detach(), torch.ones_like(mod.weight)), name
+            assert torch.equal(mod.bias.detach(), torch.zeros_like(mod.bias)), name
+    assert seen == 3 + 3 + 4 + 1 + 4 + 2      # enc: 3 conv, fc, 2 heads; dec: fc, 3 deconv, conv; dis: 4 conv, 2 fc
+    # the transposed convolutions' fan: decoder.conv.1 maps 256 -> 128 channels, weight (256, 128, 5, 5)
+    w = m.decoder.conv[1].conv.weight.detach()
+    assert tuple(w.shape) == (256, 128, 5, 5)
+    assert float(w.abs().max()) > 0.98 / math.sqrt(128 * 25) / math.sqrt(3.0)
+
+
+@pytest.mark.gpu
+def test_encoder_and_decoder_blocks_forward_on_their_own():
+    """EncoderBlock.forward(ten, out) / DecoderBlock.forward(ten) (reference models/vae_gan.py:23-35, :56-60) on the
+    engine against torch on the CPU, train and eval mode, running statistics included."""
+    import torch.nn.functional as F
+    _cfg64()
+    import models.vae_gan as vg
+    dev = "cuda:0"
+    torch.manual_seed(3)
+    for kind in ("enc", "dec"):
+        blk = (vg.EncoderBlock(64, 128) if kind == "enc" else vg.DecoderBlock(128, 64, out=True))
+        with torch.no_grad():
+            blk.conv.weight.copy_((torch.randn_like(blk.conv.weight) * 0.05).half().float())
+            blk.bn.weight.uniform_(0.5, 1.5)
+            blk.bn.bias.uniform_(-0.2, 0.2)
+        ref = (vg.EncoderBlock if kind == "enc" else vg.DecoderBlock)
+        x = torch.randn(3, 64 if kind == "enc" else 128, 12, 12).half().float()
+        w, g, b = blk.conv.weight.detach().clone(), blk.bn.weight.detach().clone(), blk.bn.bias.detach().clone()
+        rm, rv = torch.zeros_like(g), torch.ones_like(g)
+        raw = F.conv2d(x, w, None, 2, 2) if kind == "enc" else F.conv_transpose2d(x, w, None, 2, 2, output_padding=1)
+        want = F.relu(F.batch_norm(raw, rm, rv, g, b, True, 0.9, 1e-5))
+        blk = blk.to(dev)
+        blk.train()
+        got = blk(x.to(dev), True) if kind == "enc" else blk(x.to(dev))
+        act = got[0] if kind == "enc" else got
+        assert (act.cpu() - want).abs().max().item() < 2e-2 * want.abs().max().item()
+        if kind == "enc":
+            assert (got[1].cpu() - raw).abs().max().item() < 2e-3 * raw.abs().max().item()
+        assert torch.allclose(blk.bn.running_mean.cpu(), rm, atol=2e-3) and int(blk.bn.num_batches_tracked) == 1
+        blk.eval()
+        want_e = F.relu(F.batch_norm(raw, rm, rv, g, b, False, 0.9, 1e-5))
+        got_e = blk(x.to(dev))
+        assert (got_e.cpu() - want_e).abs().max().item() < 2e-2 * want_e.abs().max().item()

@@ -351,3 +351,81 @@ def test_graph_segments_with_eager_collectives_equal_eager_steps():
     assert p.exitcode == 0
     ok, worst, la, lb = _collect([p], q, 1)[0]
     assert ok, (worst, la, lb)
+
+
+# ---- the other fused steps, two ranks (global-batch BatchNorm statistics) vs one process on the global batch ----------
+def _build_step(kind, dist_on):
+    from fmri_hip.params import ArchConfig
+    from fmri_hip.steps import CognitiveStep
+    from fmri_hip.wae_steps import DualStage1Step, WaeStep
+    cfg = ArchConfig.px64()
+    if kind in ("stage2", "stage3"):
+        st = CognitiveStep(cfg, 512, "cuda:0", int(kind[-1]), distributed=dist_on, sync_bn=True)
+        st.load_recipe(1, True)
+    elif kind in ("wae1", "wae2", "wae3"):
+        st = WaeStep(cfg, "cuda:0", int(kind[-1]), 512 if kind != "wae1" else 0, distributed=dist_on, sync_bn=True)
+        st.load_recipe(5, False)
+    else:
+        st = DualStage1Step(cfg, "cuda:0", distributed=dist_on, sync_bn=True)
+        st.load_recipe(8, True)
+    return st
+
+
+def _run_step(kind, st, data, sl):
+    x, nz = data["x"][sl].cuda(), data["noise"][0][:, sl].cuda()
+    if kind in ("stage2", "stage3"):
+        st.step(data["fmri"][sl].cuda(), x, nz[0], nz[1], nz[2])
+    elif kind == "wae1":
+        st.step(x, nz[2])
+    elif kind in ("wae2", "wae3"):
+        st.step(x, fmri=data["fmri"][sl].cuda())
+    else:
+        st.step(x, nz[0], nz[1], nz[2])
+    torch.cuda.synchronize()
+    return st.logs(), {k: float(v.float().norm()) for k, v in st.state_dict().items()}
+
+
+@_guarded
+def _worker_other(rank, world, port, kind, q):
+    _init(rank, world, port)
+    from oracle import vaegan_oracle as O
+    torch.cuda.set_device(0)
+    B = 4
+    data = O.synth_batch(2 * B, O.ArchCfg.px64(), n_voxels=512, seed=1234, steps=1)
+    st = _build_step(kind, True)
+    logs, sdn = _run_step(kind, st, data, slice(rank * B, (rank + 1) * B))
+    q.put((rank, logs, sdn))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["stage2", "stage3", "wae1", "wae2", "dual1"])
+def test_two_rank_other_steps_equal_single_process_global_batch(kind):
+    """CognitiveStep (Stage II / III), WaeStep and DualStage1Step with distributed=True on two half batches (asynchronous
+    per-sub-network gradient reductions, global-batch BatchNorm statistics, summed loss scalars) against the same step in
+    one process on the full batch: same logged losses, same parameters after the step, identical on both ranks."""
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_other, args=(r, 2, port, kind, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(_collect(procs, q, 2), key=lambda t: t[0])
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    from oracle import vaegan_oracle as O
+    data = O.synth_batch(8, O.ArchCfg.px64(), n_voxels=512, seed=1234, steps=1)
+    logs1, sd1 = _run_step(kind, _build_step(kind, False), data, slice(0, 8))
+    for rank, logs, sdn in res:
+        for k, v in logs1.items():
+            if isinstance(v, float):
+                assert abs(logs[k] - v) < 5e-4 * abs(v) + 1e-6, (kind, rank, k, logs[k], v)
+            else:
+                assert logs[k] == v, (kind, rank, k)
+        for k, v in sd1.items():
+            slack = 1e-3 if v < 1.0 else 0.0       # tiny tensors (biases): one sign-like update flips the norm
+            assert abs(sdn[k] - v) < 3e-3 * v + slack + 1e-6, (kind, rank, k, sdn[k], v)
+    for k in res[0][2]:
+        assert abs(res[0][2][k] - res[1][2][k]) <= 1e-6 * abs(res[0][2][k]) + 1e-9, (kind, k)

@@ -754,6 +754,7 @@ class CognitiveStep(_GanStepBase):
             self.dis.group.zero_grad()
             _, dimg_b = self.dis.backward(fw["sctx"], dlogit16, sc.a, dfeat16, sc.b, True, slice(B, 2 * B),
                                           img_streams=(False, True))
+            self.dd.all_reduce_async(self.dis.group.grad)       # under the decoder / cognitive-encoder backward
             entries = [dict(g=fw["g_tilde"], scale=sc.b, train=False, need_dz=True)]
             dz = self.dec.backward(fw["dctx"], dimg_b, entries)[0]
             dhead32 = torch.empty(B, 2 * Z, dtype=torch.float32, device=dev)
@@ -761,17 +762,18 @@ class CognitiveStep(_GanStepBase):
                      Z, 1.0, None, _P(dhead32), 1)
             dhead16 = self._renorm(dhead32, sc.enc, self._slot(S_NB), B * self.dd.world)
             self.cog.backward(fw["cctx"], dhead16, sc.enc)
-            for n in (self.dis, self.cog):
-                self.dd.all_reduce(n.group.grad)
+            self.dd.all_reduce_async(self.cog.group.grad)
+            self.dd.wait_all()
         else:
             self.dec.group.zero_grad()
             self.dis.group.zero_grad()
             dimg_a, dimg_b = self.dis.backward(fw["sctx"], dlogit16, sc.a, dfeat16, sc.b, True, slice(B, 3 * B))
+            self.dd.all_reduce_async(self.dis.group.grad)       # under the decoder backward
             cot = axpby(dimg_b, dimg_a, sc.dec / sc.b, -sc.dec / sc.a, a_dev=self._slot(S_C1), b_dev=self._slot(S_C2))
             entries = [dict(g=0, scale=sc.dec, train=True), dict(g=1, scale=sc.dec, train=True)]
             self.dec.backward(fw["dctx"], cot, entries)
-            for n in (self.dis, self.dec):
-                self.dd.all_reduce(n.group.grad)
+            self.dd.all_reduce_async(self.dec.group.grad)
+            self.dd.wait_all()
 
     def apply(self):
         if self.stage == 2:

@@ -193,7 +193,7 @@ class WaeStep(_LatentDiscPhase):
         entries = [dict(g=g_rec, scale=rec_scale, train=train_dec, need_dz=train_enc)]
         dz_rec = self.dec.backward(dctx, dxt, entries)
         if train_dec:
-            self.dd.all_reduce(self.dec.group.grad)
+            self.dd.all_reduce_async(self.dec.group.grad)           # runs under the encoder's backward pass
         if train_enc:
             dz = dz_rec[0] + dz_pen[:, :Z]
             dhead32 = torch.zeros(B, 2 * Z, dtype=torch.float32, device=dev)        # l_var gets no gradient
@@ -201,7 +201,9 @@ class WaeStep(_LatentDiscPhase):
             dhead16 = self._renorm(dhead32, sc.enc, Bg)
             self.enc.group.zero_grad()
             self.enc.backward(ectx, dhead16, sc.enc)
-            self.dd.all_reduce(self.enc.group.grad)
+            self.dd.all_reduce_async(self.enc.group.grad)
+        self.dd.wait_all()
+        if train_enc:
             self.opt_enc.step(gdev=self.scal[S_NE:S_NE + 1])
         if train_dec:
             self.opt_dec.step()

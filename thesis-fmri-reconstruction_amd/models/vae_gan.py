@@ -33,12 +33,12 @@ def _arch() -> ArchConfig:
     return ArchConfig.from_module(config)
 
 
-def _unit_scale(t: torch.Tensor) -> float:
-    """Host-side power-of-two factor bringing a cotangent to ~unit RMS * 16 before the fp16 backward."""
-    r = float(t.float().pow(2).mean().sqrt())
-    if not numpy.isfinite(r) or r <= 0.0:
-        return 1.0
-    return float(2.0 ** numpy.round(numpy.log2(16.0 / r)))
+def _unit_scale(t: torch.Tensor) -> torch.Tensor:
+    """Device-side power-of-two factor (fp32 scalar tensor) bringing a cotangent to ~unit RMS * 16 before the fp16
+    backward -- computed and applied on the device: no host synchronisation inside ``backward()``."""
+    r = t.float().pow(2).mean().sqrt()
+    f = torch.exp2(torch.round(torch.log2(16.0 / r)))
+    return torch.where(torch.isfinite(f) & (f > 0), f, torch.ones_like(f))
 
 
 class _EngineBacked(nn.Module):
@@ -87,10 +87,15 @@ class _EngineBacked(nn.Module):
         self.__dict__["_pver"] = -1
 
 
-def _collect_grads(net, params, scale_inv=1.0):
+def _collect_grads(net, params, f=None):
+    """Parameter gradients of the engine's last backward; ``f``: device scalar the cotangent was multiplied by."""
+    inv = None if f is None else 1.0 / f
     out = []
     for k, p in zip(net.group.pkeys, params):
-        out.append(net.group.grads[k].clone() if p.requires_grad else None)
+        g = None
+        if p.requires_grad:
+            g = net.group.grads[k].clone() if inv is None else net.group.grads[k] * inv
+        out.append(g)
     return out
 
 
@@ -121,8 +126,8 @@ class _EncoderFn(Function):
         dhead = torch.cat([dmu, dlv], 1).float().contiguous()
         f = _unit_scale(dhead)
         net.group.zero_grad()
-        net.backward(ctx.ectx, (dhead * f).half(), f)
-        return (None, None, *_collect_grads(net, ctx.params))
+        net.backward(ctx.ectx, (dhead * f).half(), 1.0)
+        return (None, None, *_collect_grads(net, ctx.params, f))
 
 
 class _DecoderFn(Function):
@@ -144,9 +149,9 @@ class _DecoderFn(Function):
         f = _unit_scale(dimg)
         cot = _ops.images_to_nhwc((dimg * f).contiguous())
         net.group.zero_grad()
-        res = net.backward(ctx.dctx, cot, [dict(g=0, scale=f, train=train, need_dz=ctx.need_dz)])
-        dz = res.get(0) if ctx.need_dz else None
-        return (None, dz, *_collect_grads(net, ctx.params))
+        res = net.backward(ctx.dctx, cot, [dict(g=0, scale=1.0, train=train, need_dz=ctx.need_dz)])
+        dz = res.get(0) / f if ctx.need_dz else None
+        return (None, dz, *_collect_grads(net, ctx.params, f))
 
 
 class _DiscriminatorFn(Function):
@@ -185,21 +190,21 @@ class _DiscriminatorFn(Function):
             n3, h, w, c = feat.shape
             f = _unit_scale(dout)
             dfeat16 = _ops.images_to_nhwc((dout * f).reshape(n3, c, h, w).contiguous())
-            _, dimg = net.backward(ctx.sctx, None, 1.0, dfeat16, f, False, rows, img_streams=(False, True),
+            _, dimg = net.backward(ctx.sctx, None, 1.0, dfeat16, 1.0, False, rows, img_streams=(False, True),
                                    train_b=train)
         else:
             dlogit = (dout * ctx.prob * (1.0 - ctx.prob)).float()
             f = _unit_scale(dlogit)
             dl16 = torch.zeros(3 * B, 8, dtype=torch.float16, device=dout.device)
             dl16[:, :1] = (dlogit * f).half()
-            dimg, _ = net.backward(ctx.sctx, dl16, f, None, 1.0, train, rows)
+            dimg, _ = net.backward(ctx.sctx, dl16, 1.0, None, 1.0, train, rows)
         gi = [None, None, None]
         if want_img:
-            full = _ops.nhwc_to_images(dimg, 3, 1.0 / f)
+            full = _ops.nhwc_to_images(dimg, 3, 1.0) / f
             for i in range(3):
                 if ctx.needs[i]:
                     gi[i] = full[i * B:(i + 1) * B]
-        return (None, None, gi[0], gi[1], gi[2], *_collect_grads(net, ctx.params))
+        return (None, None, gi[0], gi[1], gi[2], *_collect_grads(net, ctx.params, f))
 
 
 class _WaeDiscriminatorFn(Function):
@@ -222,15 +227,51 @@ class _WaeDiscriminatorFn(Function):
         dl16 = torch.zeros(dlogit.shape[0], 8, dtype=torch.float16, device=dout.device)
         dl16[:, :1] = (dlogit * f).half()
         net.group.zero_grad()
-        dz = net.backward(ctx.wctx, dl16, f, train, ctx.need_dz)
-        return (None, dz, *_collect_grads(net, ctx.params))
+        dz = net.backward(ctx.wctx, dl16, 1.0, train, ctx.need_dz)
+        return (None, dz / f if dz is not None else None, *_collect_grads(net, ctx.params, f))
 
 
 # ------------------------------------------------------------------------------------------------
 # parameter holders mirroring the reference module tree (so state_dict keys are identical)
 # ------------------------------------------------------------------------------------------------
-class EncoderBlock(nn.Module):
-    """conv(k5,s2,p2,no bias) + BN(momentum .9) + ReLU holder (reference models/vae_gan.py:11-35)."""
+class _BlockNet:
+    """Engine objects of ONE conv / deconv + BatchNorm + ReLU block (EncoderBlock / DecoderBlock used on their own)."""
+
+    def __init__(self, kind, cin, cout, out_pad, device):
+        from fmri_hip.params import FlatGroup, _bn
+        shape = (cout, cin, config.kernel_size, config.kernel_size) if kind == "conv" else \
+            (cin, cout, config.kernel_size, config.kernel_size)
+        self.group = FlatGroup([("conv.weight", shape, "w")] + _bn("bn.", cout), device)
+        self.conv = _ops.ConvLayer(self.group, "conv.weight", None, kind, cin, cout, config.kernel_size, config.stride,
+                                   config.padding, out_pad)
+        self.bn = _ops.BatchNorm(self.group, "bn.", cout)
+        self.cout = cout
+
+    def all_bns(self):
+        return [self.bn]
+
+    def forward(self, x):
+        raw = self.conv.forward(_ops.images_to_nhwc(x), bn_groups=0 if self.bn.eval_mode else 1)
+        act, _ = self.bn.forward(raw, relu=True, updates=1, stat_acc=self.conv.take_stats())
+        return _ops.nhwc_to_images(act, self.cout), raw
+
+
+class _Block(_EngineBacked):
+    """A block called on its own runs its forward on the engine (train-mode batch statistics, running statistics
+    updated, eval mode honoured) but is not differentiable: training goes through the parent networks (Encoder /
+    Decoder / Discriminator), whose autograd bridges cover whole sub-networks."""
+
+    def _forward(self, ten):
+        if torch.is_grad_enabled() and (ten.requires_grad or any(p.requires_grad for p in self.parameters())):
+            # forward values are exact; make it explicit that no graph is recorded
+            ten = ten.detach()
+        act, raw = self._engine().forward(ten)
+        self._engine_params_changed()
+        return act, raw
+
+
+class EncoderBlock(_Block):
+    """conv(k5,s2,p2,no bias) + BN(momentum .9) + ReLU (reference models/vae_gan.py:11-35)."""
 
     def __init__(self, channel_in, channel_out):
         super(EncoderBlock, self).__init__()
@@ -238,9 +279,19 @@ class EncoderBlock(nn.Module):
                               padding=config.padding, stride=config.stride, bias=False)
         self.bn = nn.BatchNorm2d(num_features=channel_out, momentum=0.9)
 
+    def _make_net(self, device):
+        return _BlockNet("conv", self.conv.in_channels, self.conv.out_channels, 0, device)
 
-class DecoderBlock(nn.Module):
-    """deconv(k5,s2,p2,output_padding) + BN + ReLU holder (reference models/vae_gan.py:38-60)."""
+    def forward(self, ten, out=False, t=False):
+        """``out=True`` also returns the raw convolution output (models/vae_gan.py:23-30)."""
+        act, raw = self._forward(ten)
+        if out:
+            return act, _ops.nhwc_to_images(raw, self.conv.out_channels)
+        return act
+
+
+class DecoderBlock(_Block):
+    """deconv(k5,s2,p2,output_padding) + BN + ReLU (reference models/vae_gan.py:38-60)."""
 
     def __init__(self, channel_in, channel_out, out=False):
         super(DecoderBlock, self).__init__()
@@ -248,6 +299,12 @@ class DecoderBlock(nn.Module):
                                        padding=config.padding, stride=config.stride,
                                        output_padding=1 if out else 0, bias=False)
         self.bn = nn.BatchNorm2d(channel_out, momentum=0.9)
+
+    def _make_net(self, device):
+        return _BlockNet("deconv", self.conv.in_channels, self.conv.out_channels, self.conv.output_padding[0], device)
+
+    def forward(self, ten):
+        return self._forward(ten)[0]
 
 
 class Encoder(_EngineBacked):

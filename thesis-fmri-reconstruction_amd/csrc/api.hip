@@ -248,6 +248,41 @@ int fmri_igemm_ep(const void* in, const void* w, void* out, const float* bias, c
             }
         }
     }
+    // stride-2 convolution k5 p2, Ci % 32 == 0, 128-channel tiles, no bias / activation -> window-resident kernel
+    // (csrc/igemm_c5.hip); FMRI_C5=off disables
+    static const char* c5_env = getenv("FMRI_C5");
+    static const bool no_c5 = c5_env && !strcmp(c5_env, "off");
+    if (!no_c5 && mode == FMRI_CONV && stride == 2 && k == 5 && pad == 2 && (Ci & 31) == 0 && bn_tile == 128 &&
+        (copad & 127) == 0 && !out_f32 && splits == 1 && !bias && act == FMRI_ACT_NONE &&
+        Ho == (Hi - 1) / 2 + 1 && Wo == (Wi - 1) / 2 + 1 && a.cls[0].Kpad >= 25 * Ci &&
+        (int64_t)N * Hi * Wi * Ci * 2 < 0x7fffffffLL && (int64_t)copad * a.cls[0].Kpad * 2 < 0xffffffffLL &&
+        (w_elems == 0 || w_elems >= (int64_t)copad * a.cls[0].Kpad)) {
+        C5Args q;
+        q.in = a.in; q.w = a.w + a.cls[0].w_off; q.out = (half_t*)out;
+        q.N = N; q.Hi = Hi; q.Wi = Wi; q.Ci = Ci; q.Ho = Ho; q.Wo = Wo; q.CoStore = CoStore; q.Co = Co;
+        q.Kpad = a.cls[0].Kpad; q.nsub = Ci / 32;
+        q.pw16 = Wo > 8 ? 1 : 0;
+        const int ipb = q.pw16 ? 1 : 2;
+        q.tiles_x = q.pw16 ? (Wo + 15) / 16 : 1;
+        q.tiles_y = (Ho + 7) / 8;
+        q.ntiles = ((N + ipb - 1) / ipb) * q.tiles_y * q.tiles_x;
+        q.in_bytes = (uint32_t)((int64_t)N * Hi * Wi * Ci * 2);
+        q.w_bytes = (uint32_t)((int64_t)copad * q.Kpad * 2);
+        q.fdTPI = make_fastdiv((uint32_t)(q.tiles_y * q.tiles_x));
+        q.fdTX = make_fastdiv((uint32_t)q.tiles_x);
+        q.st = se;
+        // statistics: one row per tile; groups must not share a tile
+        if (se.part) {
+            if (se.group_n > 0 && (se.group_n % ipb)) q.st.part = nullptr;
+            q.st.tpg[0] = se.group_n > 0 ? (se.group_n / ipb) * q.tiles_y * q.tiles_x : q.ntiles;
+            if (q.st.tpg[0] > se.rows_cap) q.st.part = nullptr;
+        }
+        q.bb = bb;
+        if (!q.st.part) q.bb.x = nullptr;       // no statistics rows: plain output (*ep_done = 0 tells the caller)
+        const int r = igemm_c5_launch(q, copad, S(stream));
+        if (r == OK && ep_done && q.st.part) *ep_done = q.st.tpg[0];
+        if (r != E_UNSUPPORTED) return r;
+    }
     // stride-2 transposed convolution k5 p2, Ci % 128 == 0, >= 64 output channels, no bias / activation: all four parity
     // classes per block (csrc/igemm_tc5.hip); FMRI_TC5=off disables
     static const char* tc5_env = getenv("FMRI_TC5");
@@ -280,6 +315,10 @@ int fmri_igemm_ep(const void* in, const void* w, void* out, const float* bias, c
         q.tiles_y = (Yc0 + q.PH - 1) >> q.ph_log2;
         q.ntiles = Yc0 > 0 && Xc0 > 0 ? ((N + q.IPB - 1) / q.IPB) * q.tiles_y * q.tiles_x : 0;
         q.nslice = (q.IPB * q.IH * q.IW * 8 + 255) / 256;
+        // whole class grid (and input) inside one 8 x 8 tile per image: the window's halo is all padding -> dense form
+        static const char* dense_env = getenv("FMRI_TC5_DENSE");
+        static const bool no_dense = dense_env && !strcmp(dense_env, "off");
+        if (!no_dense && q.IPB == 2 && q.tiles_x == 1 && q.tiles_y == 1 && Hi <= 8 && Wi <= 8) q.nslice = 4;
         q.in_bytes = (uint32_t)((int64_t)N * Hi * Wi * Ci * 2);
         q.w_bytes = (uint32_t)(w_elems * 2);
         q.fdTPI = make_fastdiv((uint32_t)(q.tiles_y * q.tiles_x));
@@ -297,7 +336,12 @@ int fmri_igemm_ep(const void* in, const void* w, void* out, const float* bias, c
         }
         if (!q.st.part) q.bb.x = nullptr;       // no statistics rows: plain output (*ep_done = 0 tells the caller)
         if (ok && q.ntiles > 0) {
-            const int r = igemm_tc5_launch(q, bn_tile, copad, S(stream));
+            // FMRI_TC5B=on: the 8-wave two-tile form (csrc/igemm_tc5b.hip) where it applies
+            static const char* tc5b_env = getenv("FMRI_TC5B");
+            static const bool use_tc5b = tc5b_env && !strcmp(tc5b_env, "on");
+            int r = E_UNSUPPORTED;
+            if (use_tc5b) r = igemm_tc5b_launch(q, bn_tile, copad, S(stream));
+            if (r == E_UNSUPPORTED) r = igemm_tc5_launch(q, bn_tile, copad, S(stream));
             if (r == OK && ep_done && q.st.part) *ep_done = q.st.tpg[0];
             if (r != E_UNSUPPORTED) return r;
         }

@@ -199,6 +199,22 @@ struct Tc5Args {
     Tc5Class cls[4];
 };
 
+// window-resident stride-2 convolution k5 p2 (igemm_c5.hip): 128 output pixels x 128 channels per block
+struct C5Args {
+    const half_t* in;      // [N][Hi][Wi][Ci], Ci % 32 == 0
+    const half_t* w;       // [copad][Kpad], column = (ky*5 + kx)*Ci + ci
+    half_t* out;           // [N][Ho][Wo][CoStore]
+    int32_t N, Hi, Wi, Ci;
+    int32_t Ho, Wo, CoStore, Co;
+    int32_t Kpad, nsub;                          // nsub = Ci / 32
+    int32_t pw16;                                // 1: tiles of 8 x 16 pixels of one image, 0: 8 x 8 pixels of two images
+    int32_t tiles_x, tiles_y, ntiles;
+    uint32_t in_bytes, w_bytes;                  // buffer descriptor ranges (in_bytes < 2^31)
+    FastDiv fdTPI, fdTX;
+    StatEpi st;
+    BnBwdEpi bb;
+};
+
 // weight-gradient implicit GEMM (wgrad.hip):
 //   dW[a][tap*Bc + b] (+)= sum_m P[m][a] * Q[n, y*s+dy(tap), x*s+dx(tap), b],  m = (n, y, x)
 struct WgradArgs {

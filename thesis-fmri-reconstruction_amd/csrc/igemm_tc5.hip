@@ -65,7 +65,7 @@ __device__ __forceinline__ void wait_vm() {
 }  // namespace
 
 // NSL = 4 KB DMA slices per window chunk: 6 -> two window buffers (80 KB LDS with the 128-row weight ring),
-// 7 (two 10 x 10 image windows per tile) -> one buffer, reloaded between chunks.
+// 7 (two 10 x 10 image windows per tile) -> one buffer, reloaded between chunks; 4 -> dense 8 x 8 windows (see DENSE).
 // STATS: 0 none, 1 BatchNorm forward statistics (StatEpi), 2 BatchNorm backward statistics + ReLU mask (BnBwdEpi)
 template <int BN, int NSL, int STATS>
 __global__ __launch_bounds__(256, 2) void igemm_tc5_kernel(const Tc5Args a) {
@@ -74,7 +74,12 @@ __global__ __launch_bounds__(256, 2) void igemm_tc5_kernel(const Tc5Args a) {
     constexpr int TN = BN / WN / 16;            // 4 (BN = 128) or 2 (BN = 64)
     constexpr int BROWS = BN / 32;
     constexpr int W_BYTES = BN * 128;
-    constexpr int WINB = NSL * 4096;
+    // NSL == 4 ("dense"): the class grid fits one 8 x 8 tile per image (input <= 8 x 8), so the 1-pixel halo of the window is
+    // all padding: only the 8 x 8 interior (2 images x 64 pixels x 128 B = 4 slices) is kept, and fragment addresses that
+    // fall into the halo point at a 128-byte block of zeros behind each window buffer.
+    constexpr bool DENSE = NSL == 4;
+    constexpr int WINB = DENSE ? 4 * 4096 + 128 : NSL * 4096;
+    constexpr int ZERO_OFF = 4 * 4096;               // dense: zeros at [ZERO_OFF, +128) of every window buffer
     constexpr int PBUFS = NSL <= 6 ? 2 : 1;
     constexpr int WBUF0 = PBUFS * WINB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -120,10 +125,15 @@ __global__ __launch_bounds__(256, 2) void igemm_tc5_kernel(const Tc5Args a) {
             soff[e] = 0x80000000u;                         // out of range -> the DMA writes zeros
             const int q = e * 256 + tid;
             const int pixel = q >> 3;
-            const int ip = (int)fd_div((uint32_t)pixel, fIHW);
-            const int rem = pixel - ip * IHW;
-            const int j = (int)fd_div((uint32_t)rem, fIW);
-            const int i = rem - j * a.IW;
+            int ip, j, i;
+            if constexpr (DENSE) {
+                ip = pixel >> 6; j = ((pixel >> 3) & 7) + 1; i = (pixel & 7) + 1;     // interior only, origin (0, 0)
+            } else {
+                ip = (int)fd_div((uint32_t)pixel, fIHW);
+                const int rem = pixel - ip * IHW;
+                j = (int)fd_div((uint32_t)rem, fIW);
+                i = rem - j * a.IW;
+            }
             const int n = grp * a.IPB + ip;
             const int iy = y0 - 1 + j, ix = x0 - 1 + i;
             if (ip < a.IPB && n < a.N && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi)
@@ -160,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void igemm_tc5_kernel(const Tc5Args a) {
     const int frow = lane & 15, fq = lane >> 4;
     const int tp_log2 = a.pw_log2 + a.ph_log2;
     // GEMM row rr of an image's tile -> tile column (8-wide tiles: rows rotated by -y*IW, see igemm_win.hip)
-    const int rotIW = a.pw_log2 == 3 ? a.IW : 0;
+    const int rotIW = (a.pw_log2 == 3 && !DENSE) ? a.IW : 0;     // dense 8-pixel rows are conflict-free as they are
     auto tile_x = [&](int rr) __attribute__((always_inline)) { return (rr - (rr >> 3) * rotIW) & (PW - 1); };
 
     // ---- A fragment addresses: window shift (sy, sx) in 0..2 of row tile tm; ks = 1 is the same address ^ 64
@@ -175,8 +185,16 @@ __global__ __launch_bounds__(256, 2) void igemm_tc5_kernel(const Tc5Args a) {
         for (int sy = 0; sy < 3; ++sy)
 #pragma unroll
             for (int sx = 0; sx < 3; ++sx) {
-                const int pix = base + sy * a.IW + sx;
-                aoff[sy * 3 + sx][tm] = (uint32_t)((pix << 7) + ((fq ^ (pix & 6)) << 4));
+                if constexpr (DENSE) {
+                    const int yy = (rr >> 3) + sy - 1, xx = (rr & 7) + sx - 1;
+                    const int pix = ip * 64 + yy * 8 + xx;
+                    const bool in = (unsigned)yy < (unsigned)a.Hi && (unsigned)xx < (unsigned)a.Wi;
+                    aoff[sy * 3 + sx][tm] = in ? (uint32_t)((pix << 7) + ((fq ^ (pix & 6)) << 4))
+                                               : (uint32_t)(ZERO_OFF + (fq << 4));
+                } else {
+                    const int pix = base + sy * a.IW + sx;
+                    aoff[sy * 3 + sx][tm] = (uint32_t)((pix << 7) + ((fq ^ (pix & 6)) << 4));
+                }
             }
     }
     // ---- B fragment address (row = wn*(BN/WN) + tn*16 + frow; the swizzle term does not depend on tn or wn)
@@ -375,6 +393,10 @@ __global__ __launch_bounds__(256, 2) void igemm_tc5_kernel(const Tc5Args a) {
         vw = vwn; sw = swn; rs = rsn;
     };
 
+    if constexpr (DENSE) {
+        // the zero blocks behind the two window buffers (visible after the first step's barrier)
+        if (tid < 16) *(f4*)(smem + (tid >> 3) * WINB + ZERO_OFF + (tid & 7) * 16) = (f4){0.f, 0.f, 0.f, 0.f};
+    }
     // prologue: window of (class 0, chunk 0) and the first weight tile
     load_slices(std::integral_constant<int, 0>{}, 0, std::integral_constant<int, 0>{}, std::integral_constant<int, NSL>{});
     load_w(std::integral_constant<int, 0>{}, vw, sw, rs);
@@ -395,7 +417,7 @@ template <int BN, int NSL, int STATS>
 static int launch_tc5(const Tc5Args& a, int copad, hipStream_t st) {
     auto kern = igemm_tc5_kernel<BN, NSL, STATS>;
     constexpr int PBUFS = NSL <= 6 ? 2 : 1;
-    constexpr int lds = PBUFS * NSL * 4096 + 2 * BN * 128;
+    constexpr int lds = PBUFS * (NSL == 4 ? 4 * 4096 + 128 : NSL * 4096) + 2 * BN * 128;
     static_assert(lds <= 80 * 1024, "two blocks per CU");
     // raising the dynamic-LDS limit is idempotent; every call sets it (no library-global state)
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
@@ -412,9 +434,16 @@ static int launch_tc5s(const Tc5Args& a, int copad, hipStream_t st) {
 
 // bias == null and act == none only (see the epilogue); nslice in {6, 7}; bn_tile in {64, 128}
 int igemm_tc5_launch(const Tc5Args& a, int bn_tile, int copad, hipStream_t st) {
-    if ((a.nslice != 6 && a.nslice != 7) || a.bias != nullptr || a.act != ACT_NONE) return E_UNSUPPORTED;
-    if (bn_tile == 128) return a.nslice == 6 ? launch_tc5s<128, 6>(a, copad, st) : launch_tc5s<128, 7>(a, copad, st);
-    if (bn_tile == 64) return a.nslice == 6 ? launch_tc5s<64, 6>(a, copad, st) : launch_tc5s<64, 7>(a, copad, st);
+    if ((a.nslice != 4 && a.nslice != 6 && a.nslice != 7) || a.bias != nullptr || a.act != ACT_NONE) return E_UNSUPPORTED;
+    if (a.nslice == 4 && (a.Hi > 8 || a.Wi > 8 || a.IPB != 2 || a.tiles_x != 1 || a.tiles_y != 1)) return E_BADARG;
+    if (bn_tile == 128) {
+        if (a.nslice == 4) return launch_tc5s<128, 4>(a, copad, st);
+        return a.nslice == 6 ? launch_tc5s<128, 6>(a, copad, st) : launch_tc5s<128, 7>(a, copad, st);
+    }
+    if (bn_tile == 64) {
+        if (a.nslice == 4) return launch_tc5s<64, 4>(a, copad, st);
+        return a.nslice == 6 ? launch_tc5s<64, 6>(a, copad, st) : launch_tc5s<64, 7>(a, copad, st);
+    }
     return E_UNSUPPORTED;
 }
 

@@ -194,8 +194,14 @@ def igemm_kernel_label(N, Hi, Wi, Ci, Ho, Wo, CoStore, Co, k, stride, pad, mode,
         ph = 16 if (pw == 8 and yc > 8) else 8
         ipb = 128 // (pw * ph)
         nsl = (ipb * (ph + 2) * (pw + 2) * 8 + 255) // 256
-        if nsl in (6, 7):
-            return f"fmri::igemm_tc5_kernel<{tile},{nsl},false>"
+        if ipb == 2 and yc <= 8 and xc <= 8 and Hi <= 8 and Wi <= 8 and os.environ.get("FMRI_TC5_DENSE") != "off":
+            nsl = 4
+        if nsl in (4, 6, 7):
+            return f"fmri::igemm_tc5_kernel<{tile},{nsl},0>"
+    if (mode == MODE_CONV and stride == 2 and k == 5 and pad == 2 and Ci % 32 == 0 and tile == 128 and not out_f32
+            and splits == 1 and bias_none and act == ACT_NONE and Ho == (Hi - 1) // 2 + 1 and Wo == (Wi - 1) // 2 + 1
+            and os.environ.get("FMRI_C5") != "off"):
+        return f"fmri::igemm_c5_kernel<{16 if Wo > 8 else 8}>"
     unit = (mode == MODE_TCONV2 or stride == 1) and spatial and 2 <= k <= 5 and not out_f32 and splits == 1
     if unit and Ci % 64 == 0 and tile >= 64:
         return f"fmri::igemm_win_kernel<{tile},2,2>"

@@ -98,7 +98,14 @@ typedef struct fmri_epilogue {
     int32_t bn_x_img0[4];
     int32_t bn_relu;
     int32_t reserved;
+    /* ReLU backward of the layer BELOW, for a data gradient whose output is the cotangent of that layer's ReLU output
+     * (autograd of nn.ReLU after discriminator.conv.0, models/vae_gan.py:145-147): act_y = the saved ReLU output
+     * (geometry of `out`), `out` receives (act_y > 0) ? dy : 0.  Independent of the statistics fields.  Kernels that
+     * apply it set FMRI_EP_ACT_APPLIED in *ep_done; if the bit comes back clear `out` holds the plain dy (use
+     * fmri_act_bwd). */
+    const void* act_y;
 } fmri_epilogue;
+#define FMRI_EP_ACT_APPLIED 0x40000000
 int fmri_igemm_ep(const void* in, const void* w, void* out, const float* bias, const void* zero16, int N, int Hi,
                   int Wi, int Ci, int Ho, int Wo, int CoStore, int Co, int k, int stride, int pad, int mode, int act,
                   int out_f32, int splits, int64_t slab_stride, int bn_tile, int64_t w_elems, const fmri_epilogue* ep,

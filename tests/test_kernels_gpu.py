@@ -106,6 +106,37 @@ def test_conv_forward_dgrad_wgrad(cin, cout, stride, H, W, N):
     _close(g.grads["w"].cpu() * 4.0, wr.grad, "conv wgrad", tol=3e-3)
 
 
+C5_CASES = [
+    # cin, cout, H, W, N          conv k5 s2 p2 without bias -> csrc/igemm_c5.hip
+    (32, 128, 64, 64, 3),         # discriminator.conv.1: one 32-channel sub-chunk, 8 x 16 tiles
+    (64, 128, 32, 32, 2),         # encoder.conv.1: two sub-chunks
+    (128, 256, 16, 16, 5),        # 8 x 8 tiles of two images, odd image count, two channel blocks
+    (256, 256, 16, 16, 2),        # eight sub-chunks
+    (128, 256, 25, 25, 2),        # odd size 25 -> 13 (100-px config): partial tiles, odd last input row / column
+    (128, 256, 13, 13, 3),        # 13 -> 7: partial 8 x 8 tiles
+    (64, 128, 50, 50, 1),         # 50 -> 25: two tiles per row, four per column
+    (32, 128, 20, 36, 2),         # rectangular: 10 x 18 outputs
+    (96, 128, 12, 12, 2),         # three sub-chunks (odd count: ring stage parity)
+]
+
+
+@pytest.mark.parametrize("cin,cout,H,W,N", C5_CASES)
+def test_conv_stride2_window_kernel(cin, cout, H, W, N):
+    """csrc/igemm_c5.hip (window-resident stride-2 convolution) against the fp32 convolution, and against the tap-list
+    kernel it replaces (FMRI_C5 is read once per process, so that comparison goes through the label only)."""
+    from fmri_hip.ops import ConvLayer, ACT_NONE, igemm_kernel_label, MODE_CONV
+    torch.manual_seed(cin * 7 + cout + H * 3 + W + N)
+    w = _h(torch.randn(cout, cin, 5, 5) * 0.05)
+    x = _h(torch.randn(N, cin, H, W))
+    g = _G({"w": w})
+    layer = ConvLayer(g, "w", None, "conv", cin, cout, 5, 2, 2)
+    Ho, Wo = layer.out_hw(H, W)
+    assert "igemm_c5" in igemm_kernel_label(N, H, W, cin, Ho, Wo, cout, cout, 5, 2, 2, MODE_CONV, False, 1, 128)
+    y16 = layer.forward(_nhwc16(x), ACT_NONE)
+    ref = F.conv2d(x, w, None, 2, 2)
+    _close(_from_nhwc(y16, cout), ref, "conv s2 (window kernel)")
+
+
 def test_conv0_wgrad_large_batch_routes_to_narrow_kernel():
     """discriminator.conv.0-shaped weight gradient with enough 8x8 tiles (>= 32768) to take the wave-private window
     kernel (csrc/wgrad_narrow.hip); the small-batch cases above stay on the generic kernel."""
@@ -121,6 +152,49 @@ def test_conv0_wgrad_large_batch_routes_to_narrow_kernel():
     _join()
     ref = torch.nn.grad.conv2d_weight(x, w.shape, dy, stride=1, padding=2)
     _close(g.grads["w"].cpu() * 2.0, ref, "conv0 wgrad (narrow kernel)", tol=3e-3)
+
+
+def test_conv0_bias_gradient_from_the_narrow_wgrad_kernel():
+    """wgrad(..., bias_too=True): the bias gradient is the spare column of csrc/wgrad_narrow.hip (taps x ones)."""
+    from fmri_hip.ops import ConvLayer
+    torch.manual_seed(6)
+    N, H = 512, 64
+    w = _h(torch.randn(32, 3, 5, 5) * 0.1)
+    x = _h(torch.randn(N, 3, H, H))
+    dy = _h(torch.randn(N, 32, H, H) * 0.1)
+    g = _G({"w": w, "b": torch.zeros(32)})
+    layer = ConvLayer(g, "w", "b", "conv", 3, 32, 5, 1, 2)
+    layer.wgrad(_nhwc16(x), _nhwc16(dy), 2.0, bias_too=True)
+    _join()
+    ref = dy.double().sum((0, 2, 3)).float()
+    _close(g.grads["b"].cpu() * 2.0, ref, "conv0 bias gradient (narrow kernel column)", tol=3e-3)
+    refw = torch.nn.grad.conv2d_weight(x, w.shape, dy, stride=1, padding=2)
+    _close(g.grads["w"].cpu() * 2.0, refw, "conv0 wgrad (narrow kernel)", tol=3e-3)
+    # small batch: the generic kernel has no such column, the layer reduces dy itself
+    g2 = _G({"w": w, "b": torch.zeros(32)})
+    layer2 = ConvLayer(g2, "w", "b", "conv", 3, 32, 5, 1, 2)
+    layer2.wgrad(_nhwc16(x[:3]), _nhwc16(dy[:3]), 1.0, bias_too=True)
+    _join()
+    _close(g2.grads["b"].cpu(), dy[:3].double().sum((0, 2, 3)).float(), "conv0 bias gradient (reduction)", tol=3e-3)
+
+
+@pytest.mark.parametrize("H,N", [(32, 3), (25, 2)])
+def test_dgrad_epilogue_relu_backward(H, N):
+    """fmri_epilogue.act_y: the 128 -> 32 channel data gradient (csrc/igemm_tc32.hip) masks with the ReLU of the layer
+    below; bit-identical to the plain data gradient followed by fmri_act_bwd."""
+    from fmri_hip.ops import ConvLayer, act_backward, ACT_RELU
+    torch.manual_seed(H + N)
+    w = _h(torch.randn(128, 32, 5, 5) * 0.05)
+    g = _G({"w": w})
+    layer = ConvLayer(g, "w", None, "conv", 32, 128, 5, 2, 2)
+    Ho, Wo = layer.out_hw(H, H)
+    dy = (torch.randn(N, Ho, Wo, 128, device=DEV) * 0.5).half()
+    y0 = torch.relu(torch.randn(N, H, H, 32, device=DEV)).half()
+    plain = layer.dgrad(dy, H, H)
+    assert not layer.act_applied
+    masked = layer.dgrad(dy, H, H, relu_y=y0)
+    assert layer.act_applied
+    assert torch.equal(masked, act_backward(y0, plain, ACT_RELU))
 
 
 DECONV_CASES = [
@@ -161,10 +235,14 @@ def test_deconv_forward_dgrad_wgrad(cin, cout, H, op, N):
 
 EPI_STAT_CASES = [
     # kind, cin, cout, stride, H, out_pad, N, groups, expect the epilogue
-    ("conv", 64, 128, 2, 16, 0, 4, 1, True),        # igemm 128 x 128, Ci % 64 == 0
-    ("conv", 32, 128, 2, 32, 0, 8, 1, True),        # K-steps straddle taps
-    ("conv", 3, 64, 2, 16, 0, 4, 1, True),          # 2 K-steps, 64-channel tile
-    ("conv", 128, 256, 2, 32, 0, 200, 1, True),     # 256 x 256 tile (8 waves)
+    ("conv", 64, 128, 2, 16, 0, 4, 1, True),        # igemm_c5, two images per tile
+    ("conv", 32, 128, 2, 32, 0, 8, 1, True),        # igemm_c5, 8 x 16 tiles, one sub-chunk
+    ("conv", 3, 64, 2, 16, 0, 4, 1, True),          # generic kernel: 2 K-steps, 64-channel tile
+    ("conv", 128, 256, 2, 32, 0, 200, 1, True),     # igemm_c5, many tiles, two channel blocks
+    ("conv", 128, 256, 2, 13, 0, 3, 1, True),       # igemm_c5, partial tiles, odd image count
+    ("conv", 64, 128, 2, 50, 0, 2, 2, True),        # igemm_c5, two BatchNorm batches of one image
+    ("conv", 256, 256, 2, 16, 0, 6, 3, True),       # igemm_c5, three batches of two images (= one tile each)
+    ("conv", 256, 256, 2, 16, 0, 3, 3, False),      # a two-image tile would hold two batches: no epilogue
     ("deconv", 256, 128, 2, 16, 1, 4, 2, True),     # igemm_tc5, double-buffered window, two BatchNorm batches
     ("deconv", 256, 256, 2, 8, 1, 4, 2, True),      # igemm_tc5, two images per tile
     ("deconv", 256, 256, 2, 8, 1, 6, 2, False),     # a tile would hold images of two batches: no epilogue

@@ -271,10 +271,20 @@ int fmri_igemm_ep(const void* in, const void* w, void* out, const float* bias, c
         q.fdTPI = make_fastdiv((uint32_t)(q.tiles_y * q.tiles_x));
         q.fdTX = make_fastdiv((uint32_t)q.tiles_x);
         q.st = se;
-        // statistics: one row per tile; groups must not share a tile
+        // persistent blocks: tpb consecutive tiles each when that makes whole rounds of 2 blocks per CU (FMRI_C5_TPB overrides)
+        static const char* tpb_env = getenv("FMRI_C5_TPB");
+        static const int tpb_force = tpb_env ? atoi(tpb_env) : 0;
+        const int ncol = copad / 128;
+        q.tpb = tpb_force > 0 ? tpb_force : (q.ntiles * ncol) / 512;      // whole rounds only: fewer, longer blocks leave CUs idle
+        if (q.tpb < 1) q.tpb = 1;
+        // statistics: one row per block; statistics groups must not share a tile, nor a block
+        const int tpg5 = se.group_n > 0 ? (se.group_n / ipb) * q.tiles_y * q.tiles_x : q.ntiles;
+        if (se.part && se.group_n > 0) {
+            if (se.group_n % ipb) q.st.part = nullptr;
+            else while (tpg5 % q.tpb) --q.tpb;
+        }
         if (se.part) {
-            if (se.group_n > 0 && (se.group_n % ipb)) q.st.part = nullptr;
-            q.st.tpg[0] = se.group_n > 0 ? (se.group_n / ipb) * q.tiles_y * q.tiles_x : q.ntiles;
+            q.st.tpg[0] = (tpg5 + q.tpb - 1) / q.tpb;
             if (q.st.tpg[0] > se.rows_cap) q.st.part = nullptr;
         }
         q.bb = bb;
@@ -371,7 +381,12 @@ int fmri_igemm_ep(const void* in, const void* w, void* out, const float* bias, c
         q.ntiles = N * q.tiles_y * q.tiles_x;
         if (q.ntiles < 1) ok = false;
         const int begin = q.ntiles < 256 ? q.ntiles : 256;                          // one persistent block per CU
-        if (ok) return igemm_tc32_launch(q, begin, S(stream));
+        q.relu_y = (ep && ep->act_y) ? (const half_t*)ep->act_y : nullptr;
+        if (ok) {
+            const int r = igemm_tc32_launch(q, begin, S(stream));
+            if (r == OK && ep_done && q.relu_y) *ep_done |= FMRI_EP_ACT_APPLIED;
+            return r;
+        }
     }
     // unit-stride sampling, Ci % 64 == 0 -> window-resident kernel (csrc/igemm_win.hip); FMRI_WIN=off disables
     static const char* win_env = getenv("FMRI_WIN");

@@ -209,9 +209,10 @@ struct C5Args {
     int32_t Kpad, nsub;                          // nsub = Ci / 32
     int32_t pw16;                                // 1: tiles of 8 x 16 pixels of one image, 0: 8 x 8 pixels of two images
     int32_t tiles_x, tiles_y, ntiles;
+    int32_t tpb;                                 // consecutive tiles per block (grid.x = ceil(ntiles / tpb))
     uint32_t in_bytes, w_bytes;                  // buffer descriptor ranges (in_bytes < 2^31)
     FastDiv fdTPI, fdTX;
-    StatEpi st;
+    StatEpi st;                                  // one row per BLOCK; tpg[0] = blocks per statistics group
     BnBwdEpi bb;
 };
 
@@ -257,6 +258,7 @@ struct Tc32Args {
     int32_t N, Hi, Wi, Ho, Wo;
     int32_t CoStore, Co, act;
     int32_t tiles_y, tiles_x, ntiles;  // 8 x 16 tiles of class-grid positions (all four classes per tile)
+    const half_t* relu_y;  // null, or [N][Ho][Wo][CoStore]: out = (relu_y > 0) ? result : 0 (ReLU backward of the layer below)
     Tc32Class cls[4];
 };
 

@@ -84,17 +84,25 @@ __global__ __launch_bounds__(256, 2) void igemm_c5_kernel(const C5Args a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bx, by;
     xcd_tile(bx, by);
-    if (bx >= a.ntiles) return;
+    // the block's contiguous tile range (persistent over tpb tiles: the next tile's window and weights are prefetched
+    // behind the current tile's last steps, the store epilogue overlaps the other resident block's MFMAs)
+    const int tile0 = bx * a.tpb;
+    if (tile0 >= a.ntiles) return;
+    const int tile1 = tile0 + a.tpb < a.ntiles ? tile0 + a.tpb : a.ntiles;
     const int co0 = by * BN;
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
 
-    // ---- tile -> (image group, tile row, tile column)
+    // ---- tile -> (image group, tile origin)
     const int tpi = a.tiles_y * a.tiles_x;
-    const int grp = (int)fd_div((uint32_t)bx, a.fdTPI);
-    const int trem = bx - grp * tpi;
-    const int tyi = (int)fd_div((uint32_t)trem, a.fdTX);
-    const int txi = trem - tyi * a.tiles_x;
-    const int y0 = tyi * PH, x0 = txi * PW;
+    int grp, y0, x0;                      // of the tile being computed (epilogue)
+    auto tile_geom = [&](int tile, int& g, int& yy, int& xx) __attribute__((always_inline)) {
+        g = (int)fd_div((uint32_t)tile, a.fdTPI);
+        const int trem = tile - g * tpi;
+        const int tyi = (int)fd_div((uint32_t)trem, a.fdTX);
+        yy = tyi * PH;
+        xx = (trem - tyi * a.tiles_x) * PW;
+    };
+    tile_geom(tile0, grp, y0, x0);
 
     v4i srd_in, srd_w;
     srd_in.x = (int)(uint32_t)(uintptr_t)a.in;
@@ -111,9 +119,9 @@ __global__ __launch_bounds__(256, 2) void igemm_c5_kernel(const C5Args a) {
     // Column position ii < PW + 2: input column 2*x0 - 2 + 2*ii; else 2*x0 - 1 + 2*(ii - PW - 2).  Row j of phase rp:
     // input row 2*y0 - 2 + rp + 2*j (the odd phase has PH + 1 rows).
     uint32_t soff0[NSL], soff1[NSL];
+    uint32_t wstat[NSL];                  // tile-independent part: column term | row << 8 | image << 12 | cc << 13 | valid << 15
 #pragma unroll
     for (int e = 0; e < NSL; ++e) {
-        soff0[e] = soff1[e] = 0x80000000u;                 // out of range -> the DMA writes zeros
         const int q = e * 256 + tid;
         const int p = q >> 2;
         const int ip = p / IMG;
@@ -122,16 +130,27 @@ __global__ __launch_bounds__(256, 2) void igemm_c5_kernel(const C5Args a) {
         const int ii = rem - j * ROW;
         const int cp = ii >= PW + 2 ? 1 : 0;
         const int m = ii - cp * (PW + 2);
-        const int n = grp * IPB + ip;
-        const int ix = 2 * x0 - 2 + 2 * m + cp;
-        const int iy = 2 * y0 - 2 + 2 * j;
         const int cc = (q & 3) ^ (((ii >> 2) & 1) << 1);
-        if (ip < IPB && j < PH + 2 && n < a.N && (unsigned)ix < (unsigned)a.Wi) {
-            const uint32_t o = (uint32_t)((((n * a.Hi + iy) * a.Wi + ix) * a.Ci + cc * 8) * 2);
-            if ((unsigned)iy < (unsigned)a.Hi) soff0[e] = o;
-            if (j < PH + 1 && (unsigned)(iy + 1) < (unsigned)a.Hi) soff1[e] = o + (uint32_t)(a.Wi * a.Ci * 2);
-        }
+        const int valid = (ip < IPB && j < PH + 2) ? 1 : 0;
+        wstat[e] = (uint32_t)((2 * m + cp) | (j << 8) | ((ip & 1) << 12) | (cc << 13) | (valid << 15));
     }
+    auto tile_offsets = [&](int g, int yy, int xx) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < NSL; ++e) {
+            soff0[e] = soff1[e] = 0x80000000u;             // out of range -> the DMA writes zeros
+            const uint32_t ws = wstat[e];
+            const int j = (ws >> 8) & 15, ip = (ws >> 12) & 1, cc = (ws >> 13) & 3;
+            const int n = g * IPB + ip;
+            const int ix = 2 * xx - 2 + (int)(ws & 255);
+            const int iy = 2 * yy - 2 + 2 * j;
+            if ((ws >> 15) && n < a.N && (unsigned)ix < (unsigned)a.Wi) {
+                const uint32_t o = (uint32_t)((((n * a.Hi + iy) * a.Wi + ix) * a.Ci + cc * 8) * 2);
+                if ((unsigned)iy < (unsigned)a.Hi) soff0[e] = o;
+                if (j < PH + 1 && (unsigned)(iy + 1) < (unsigned)a.Hi) soff1[e] = o + (uint32_t)(a.Wi * a.Ci * 2);
+            }
+        }
+    };
+    tile_offsets(grp, y0, x0);
     const uint32_t lds_wave = lds0 + wave * 1024;
     // slices [lo, hi) of sub-chunk `sub`, phase RP, into window buffer RP
     auto load_slices = [&](auto RP_, int sub, auto LO_, auto HI_) __attribute__((always_inline)) {
@@ -230,52 +249,53 @@ __global__ __launch_bounds__(256, 2) void igemm_c5_kernel(const C5Args a) {
     // Window traffic: steps 0-5 bring this sub-chunk's odd-row window (buffer 1, first read in step 7); steps 8-11 the
     // next sub-chunk's even-row window (buffer 0, last read in step 7).
     const int nsub = a.nsub;
-    auto run_sub = [&](auto P_, int sub) __attribute__((always_inline)) {
+    // `more`: another (tile, sub-chunk) follows; `nsubi` = its sub-chunk index; `ng/ny/nx` = geometry of the next tile
+    // when this is the last sub-chunk of a tile that has a successor (switch: the window offsets are recomputed in step 6,
+    // after this tile's last odd-row slice has been issued)
+    // `landed`: the DMA this sub-chunk's first step waits for was already waited for in front of the previous tile's
+    // store epilogue, so that the stores (which count in vmcnt too) get this step to complete instead of stalling it
+    auto run_sub = [&](auto P_, int sub, bool more, int nsubi, bool switch_tile, int ng, int ny, int nx, bool landed)
+                       __attribute__((always_inline)) {
         constexpr int P = decltype(P_)::value;
-        const bool last_sub = sub + 1 >= nsub;
         static_for_c<0, 13>([&](auto T_) __attribute__((always_inline)) {
             constexpr int t = decltype(T_)::value;
             constexpr int stg = (P + t) & 1;
             // window slices issued behind the weight tiles of the PREVIOUS step
             constexpr int prev_n = (t >= 1 && t <= 6) ? 1 : ((t == 9 || t == 10) ? 2 : ((t == 11 || t == 12) ? 1 : 0));
-            constexpr bool prev_cond = t >= 9;             // ... only when another sub-chunk follows
-            if constexpr (prev_n == 0) wait_vmc<0>();
-            else if constexpr (prev_cond) { if (!last_sub) wait_vmc<prev_n>(); else wait_vmc<0>(); }
+            constexpr bool prev_cond = t >= 9;             // ... only when another (tile, sub-chunk) follows
+            if constexpr (t == 0) { if (!landed) wait_vmc<0>(); }
+            else if constexpr (prev_n == 0) wait_vmc<0>();
+            else if constexpr (prev_cond) { if (more) wait_vmc<prev_n>(); else wait_vmc<0>(); }
             else wait_vmc<prev_n>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             // next step's weight tiles
             if constexpr (t < 12) load_w(std::integral_constant<int, stg ^ 1>{}, std::integral_constant<int, 2 * t + 2>{}, sub);
-            else if (!last_sub) load_w(std::integral_constant<int, stg ^ 1>{}, std::integral_constant<int, 0>{}, sub + 1);
-            // window slices
+            else if (more) load_w(std::integral_constant<int, stg ^ 1>{}, std::integral_constant<int, 0>{}, nsubi);
+            // window slices (a whole window in one step instead: 6 % faster at Ci = 32, whose windows miss L2, and 4 %
+            // slower at Ci >= 128, where the burst delays the weight tiles)
             if constexpr (t <= 5) {
                 load_slices(std::integral_constant<int, 1>{}, sub, std::integral_constant<int, t>{}, std::integral_constant<int, t + 1>{});
+            } else if constexpr (t == 6) {
+                if (switch_tile) tile_offsets(ng, ny, nx);
             } else if constexpr (t == 8 || t == 9) {
-                if (!last_sub)
-                    load_slices(std::integral_constant<int, 0>{}, sub + 1, std::integral_constant<int, (t - 8) * 2>{},
+                if (more)
+                    load_slices(std::integral_constant<int, 0>{}, nsubi, std::integral_constant<int, (t - 8) * 2>{},
                                 std::integral_constant<int, (t - 8) * 2 + 2>{});
             } else if constexpr (t == 10 || t == 11) {
-                if (!last_sub)
-                    load_slices(std::integral_constant<int, 0>{}, sub + 1, std::integral_constant<int, t - 6>{},
+                if (more)
+                    load_slices(std::integral_constant<int, 0>{}, nsubi, std::integral_constant<int, t - 6>{},
                                 std::integral_constant<int, t - 5>{});
             }
             compute(std::integral_constant<int, 2 * t>{}, std::integral_constant<int, stg>{});
         });
     };
 
-    // prologue: even-row window of sub-chunk 0 and the first weight tiles
-    load_slices(std::integral_constant<int, 0>{}, 0, std::integral_constant<int, 0>{}, std::integral_constant<int, NSL>{});
-    load_w(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, 0);
-    for (int sub = 0; sub < nsub; sub += 2) {
-        run_sub(std::integral_constant<int, 0>{}, sub);
-        if (sub + 1 < nsub) run_sub(std::integral_constant<int, 1>{}, sub + 1);
-    }
-
     // ---- epilogue: D[i = co][j = tile pixel] -> NHWC fp16 (no bias / activation: BatchNorm or a data gradient follows)
-    float vsum = 0.f, vsq = 0.f;
+    float vsum = 0.f, vsq = 0.f;         // over all tiles of the block
     const int sgrp = (STATS != 0 && a.st.group_n > 0) ? (grp * IPB) / a.st.group_n : 0;     // statistics group of the tile
-    {
+    auto epilogue = [&]() __attribute__((always_inline)) {
         int64_t opix[TM];
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
@@ -336,9 +356,42 @@ __global__ __launch_bounds__(256, 2) void igemm_c5_kernel(const C5Args a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+    };
+
+    // prologue: even-row window of the first tile's sub-chunk 0 and the first weight tiles
+    load_slices(std::integral_constant<int, 0>{}, 0, std::integral_constant<int, 0>{}, std::integral_constant<int, NSL>{});
+    load_w(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, 0);
+    // (tile, sub-chunk) pairs in one sequence, two per iteration: 13 steps per sub-chunk, so the ring stage parity
+    // alternates along the sequence whatever nsub is
+    int tile = tile0, sub = 0;
+    bool landed = false;
+    int ng = 0, ny = 0, nx = 0;
+    if (tile + 1 < tile1) tile_geom(tile + 1, ng, ny, nx);
+    auto one = [&](auto P_) __attribute__((always_inline)) {
+        const bool next_tile = tile + 1 < tile1;
+        const bool last_sub = sub + 1 >= nsub;
+        run_sub(P_, sub, !last_sub || next_tile, last_sub ? 0 : sub + 1, last_sub && next_tile, ng, ny, nx, landed);
+        ++sub;
+        landed = false;
+        if (last_sub) {
+            if (next_tile) { wait_vmc<0>(); landed = true; }     // the next tile's first window and weights
+            epilogue();
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+            grp = ng; y0 = ny; x0 = nx;
+            sub = 0;
+            ++tile;
+            if (tile + 1 < tile1) tile_geom(tile + 1, ng, ny, nx);
+        }
+    };
+    while (tile < tile1) {
+        one(std::integral_constant<int, 0>{});
+        if (tile < tile1) one(std::integral_constant<int, 1>{});
     }
     if constexpr (STATS != 0) {
-        // one row per tile; tiles of one statistics group are contiguous
+        // one row per block; the blocks of one statistics group are contiguous (tpg[0] = blocks per group)
         const int prow = bx - sgrp * a.st.tpg[0];
         stat_store<TN, WM, WN>(vsum, vsq, lane, wm, wn, co0, (float*)smem,
                                a.st.part + ((size_t)sgrp * a.st.rows_cap + prow) * 2 * a.st.C, a.st.C);
@@ -353,13 +406,13 @@ static int launch_c5(const C5Args& a, int copad, hipStream_t st) {
     // raising the dynamic-LDS limit is idempotent; every call sets it (no library-global state)
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return E_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3(a.ntiles, copad / 128, 1), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3((a.ntiles + a.tpb - 1) / a.tpb, copad / 128, 1), dim3(256), lds, st, a);
     return hipGetLastError() == hipSuccess ? OK : E_LAUNCH;
 }
 
 // k5 s2 p2, Ci % 32 == 0, 128-channel tiles, no bias / activation; pw16 selects the tile shape
 int igemm_c5_launch(const C5Args& a, int copad, hipStream_t st) {
-    if (a.nsub < 1 || (copad & 127) || a.ntiles < 1) return E_UNSUPPORTED;
+    if (a.nsub < 1 || (copad & 127) || a.ntiles < 1 || a.tpb < 1) return E_UNSUPPORTED;
     if (a.pw16) {
         if (!a.st.part) return launch_c5<16, 0>(a, copad, st);
         return a.bb.x ? launch_c5<16, 2>(a, copad, st) : launch_c5<16, 1>(a, copad, st);

@@ -133,14 +133,25 @@ __device__ __forceinline__ void tc32_role(const Tc32Args& a, char* smem, int h, 
 #pragma unroll
                 for (int tn = 0; tn < 2; ++tn) *(f4*)(dst + tn * 4) = acc[tn][1 - h];
             }
+            const int x = txi * 16 + frow;
+            const int y = tyi * 8 + 2 * q + h;
+            const bool inside = y < c.Yc && x < c.Xc;
+            const int64_t opix = ((int64_t)(n * a.Ho + (2 * y + CY)) * a.Wo + (2 * x + CX)) * a.CoStore;
+            // ReLU backward of the layer below (relu_y = its saved output, geometry of `out`): the mask values are in
+            // flight during the exchange
+            h4 mk[2];
+            if (a.relu_y) {
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+                    mk[tn] = (inside && tn * 16 + fq * 4 < a.CoStore) ? *(const h4*)(a.relu_y + opix + tn * 16 + fq * 4)
+                                                                       : (h4)(half_t)0.f;
+            }
             if (PHASES == 2 && q == 1 && more) { stash(cur ^ 1, 0); fetch(tnext, 1); }
             if (q == 3 && more) stash(cur ^ 1, PHASES - 1);
             __syncthreads();
             const float* src = xch + h * 512 + lane * 8;
-            const int x = txi * 16 + frow;
-            const int y = tyi * 8 + 2 * q + h;
-            if (y < c.Yc && x < c.Xc) {
-                half_t* orow = a.out + ((int64_t)(n * a.Ho + (2 * y + CY)) * a.Wo + (2 * x + CX)) * a.CoStore;
+            if (inside) {
+                half_t* orow = a.out + opix;
 #pragma unroll
                 for (int tn = 0; tn < 2; ++tn) {
                     const int co = tn * 16 + fq * 4;
@@ -156,6 +167,7 @@ __device__ __forceinline__ void tc32_role(const Tc32Args& a, char* smem, int h, 
                         } else {
                             f = 0.f;
                         }
+                        if (a.relu_y && !((float)mk[tn][rg] > 0.f)) f = 0.f;
                         hv[rg] = (half_t)f;
                     }
                     *(h4*)(orow + co) = hv;

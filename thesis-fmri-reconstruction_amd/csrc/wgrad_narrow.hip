@@ -10,7 +10,7 @@
 // into its private LDS slice (double buffered -- no block barrier anywhere, only the wave's own vmcnt), reads both
 // with transposing LDS reads (the MFMA K index is the pixel) and accumulates the whole 32 x 208 result in registers
 // (2 x 13 MFMA tiles; one N tile = two taps x 8 channels, lanes of the second tap read at their own window
-// offset).  P and Q are each read from HBM once.  Waves add their result into the fp32 output at the end.
+// offset; the unused 26th tap multiplies by ones: output column 200 = sum_m P[m][a]).  P and Q are each read from HBM once.  Waves add their result into the fp32 output at the end.
 #include "kernels.h"
 
 namespace fmri {
@@ -18,7 +18,7 @@ namespace fmri {
 __global__ __launch_bounds__(256) void wgrad_narrow_kernel(const WgradNarrowArgs a) {
     constexpr int WW = 12, WPIX = WW * WW;          // Q window of an 8x8 tile (5x5 taps)
     constexpr int P_BYTES = 64 * 64;                // 64 pixels x 32 channels
-    constexpr int W_BYTES = 4 * 1024;               // 144 pixels x 16 B; bytes 2304.. stay zero (the 26th tap reads there)
+    constexpr int W_BYTES = 4 * 1024;               // 144 pixels x 16 B; bytes 2304.. hold ones (the 26th tap reads there)
     constexpr int SLICE = P_BYTES + W_BYTES;        // per stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -28,9 +28,10 @@ __global__ __launch_bounds__(256) void wgrad_narrow_kernel(const WgradNarrowArgs
     const int gw = blockIdx.x * 4 + wave;           // global wave id
     const int nw = gridDim.x * 4;
 
-    // zero the tail of both window buffers once (read by the lanes of the non-existent 26th tap)
+    // the tail of both window buffers holds ONES (fp16 1.0): the lanes of the non-existent 26th tap read there, so
+    // columns 200 .. 207 of the result are the column sums of P (flip = 0: the bias gradient of the layer)
     for (int b = 0; b < 2; ++b)
-        for (int o = WPIX * 16 + lane * 4; o < W_BYTES; o += 256) *(int*)(mine + b * SLICE + P_BYTES + o) = 0;
+        for (int o = WPIX * 16 + lane * 4; o < W_BYTES; o += 256) *(int*)(mine + b * SLICE + P_BYTES + o) = 0x3C003C00;
 
     const int tpi = a.tiles_y * a.tiles_x;
     auto stage_load = [&](int buf, int t) {
@@ -129,23 +130,23 @@ __global__ __launch_bounds__(256) void wgrad_narrow_kernel(const WgradNarrowArgs
     // ---- block reduction in LDS (ds_add_f32), then one global atomic per output element and block.
     // D[i = a][j = column of the N tile]: lane owns column (lane & 15) = tap parity * 8 + b, rows (lane >> 4) * 4 ..
     __syncthreads();                                 // every wave is done with its staging slices
-    float* red = (float*)smem;                       // [32][200]
-    for (int i = threadIdx.x; i < 32 * 200; i += 256) red[i] = 0.f;
+    float* red = (float*)smem;                       // [32][201]: 200 weight columns + sum_m P[m][a]
+    for (int i = threadIdx.x; i < 32 * 201; i += 256) red[i] = 0.f;
     __syncthreads();
     const int col16 = lane & 15;
 #pragma unroll
     for (int j = 0; j < 13; ++j) {
         const int tap = 2 * j + (col16 >> 3);
-        if (tap >= 25) continue;
+        if (tap > 25 || (tap == 25 && (col16 & 7))) continue;
         const int col = tap * 8 + (col16 & 7);
 #pragma unroll
         for (int ta = 0; ta < 2; ++ta)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) atomicAdd(red + (ta * 16 + (lane >> 4) * 4 + r) * 200 + col, acc[ta][j][r]);
+            for (int r = 0; r < 4; ++r) atomicAdd(red + (ta * 16 + (lane >> 4) * 4 + r) * 201 + col, acc[ta][j][r]);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 32 * 200; i += 256) {
-        const int row = i / 200, col = i - row * 200;
+    for (int i = threadIdx.x; i < 32 * 201; i += 256) {
+        const int row = i / 201, col = i - row * 201;
         // blocks are spread over nslabs partial matrices (summed by fmri_unpack_grad): few adders per address
         atomicAdd(a.out + (int64_t)(blockIdx.x % a.nslabs) * a.slab_stride + (int64_t)row * a.ldo + col, red[i]);
     }

@@ -496,23 +496,37 @@ class DiscriminatorNet:
         _, hi, wi, _ = a0.shape
         full = slice(0, n3)
         need = [full if s["train"] else (img_rows if (img_rows is not None and s["img"]) else None) for s in streams]
+        # conv0's ReLU backward rides in the epilogue of conv1's data gradient where its kernel has one (act_applied),
+        # and the bias gradient comes out of the weight-gradient kernel: no pass over the 64 x 64 x 32 cotangent
+        masked = [False] * S
         if all(nd == full for nd in need):
             dact = self.convs[0].dgrad(d, hi, wi)
             dacts = [rows(dact, si) for si in range(S)]
         else:
-            dacts = [None if nd is None else self.convs[0].dgrad(rows(d, si)[nd], hi, wi) for si, nd in enumerate(need)]
+            dacts = []
+            for si, nd in enumerate(need):
+                if nd is None:
+                    dacts.append(None)
+                    continue
+                dacts.append(self.convs[0].dgrad(rows(d, si)[nd], hi, wi, relu_y=a0[nd]))
+                masked[si] = self.convs[0].act_applied
         outs = []
         for si, s in enumerate(streams):
             if need[si] is None:
                 outs.append(None)
                 continue
-            colsum = None
-            if s["train"]:
-                colsum = torch.empty(2 * self.c0.coutp, dtype=torch.float32, device=d.device)
-            dpre = act_backward(a0[need[si]], dacts[si], ACT_RELU, colsum)
-            if s["train"]:
-                self.c0.bg.add_(colsum[:self.c0.cout], alpha=1.0 / s["scale"])
-                self.c0.wgrad(ctx["x"], dpre, s["scale"])
+            if masked[si]:
+                dpre = dacts[si]
+                if s["train"]:
+                    self.c0.wgrad(ctx["x"], dpre, s["scale"], bias_too=True)
+            else:
+                colsum = None
+                if s["train"]:
+                    colsum = torch.empty(2 * self.c0.coutp, dtype=torch.float32, device=d.device)
+                dpre = act_backward(a0[need[si]], dacts[si], ACT_RELU, colsum)
+                if s["train"]:
+                    self.c0.bg.add_(colsum[:self.c0.cout], alpha=1.0 / s["scale"])
+                    self.c0.wgrad(ctx["x"], dpre, s["scale"])
             if img_rows is not None and s["img"]:
                 _, xh, xw, _ = ctx["x"].shape
                 sub = dpre[img_rows] if need[si] == full else dpre

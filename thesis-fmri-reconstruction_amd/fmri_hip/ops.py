@@ -219,7 +219,7 @@ def igemm_kernel_label(N, Hi, Wi, Ci, Ho, Wo, CoStore, Co, k, stride, pad, mode,
 
 
 def run_igemm(x, pw: PackedWeight, out, bias, N, Hi, Wi, Ci, Ho, Wo, CoStore, Co, k, stride, pad, mode, act, out_f32,
-              splits, slab_stride, tile, flops=0.0, stats=None, bn_bwd=None) -> int:
+              splits, slab_stride, tile, flops=0.0, stats=None, bn_bwd=None, act_y=None) -> int:
     """``stats`` = (partial-row tensor [groups][rows_cap][2][CoStore] fp32, rows_cap, images per group or 0): ask the
     kernel for the BatchNorm statistics of its output (fmri_igemm_ep).  ``bn_bwd`` = dict(x, gamma, beta, relu, groups =
     [(first image of x, BNSaved), ...]): the BatchNorm-BACKWARD form of that epilogue (masked cotangent + sum g,
@@ -231,6 +231,11 @@ def run_igemm(x, pw: PackedWeight, out, bias, N, Hi, Wi, Ci, Ho, Wo, CoStore, Co
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     ep, done = None, ctypes.c_int(0)
+    if stats is None and act_y is not None:
+        # ReLU backward of the layer below in the epilogue (fmri_epilogue.act_y); bit EP_ACT_APPLIED of the result
+        e = lib.Epilogue()
+        e.act_y = _P(act_y)
+        ep = ctypes.byref(e)
     if stats is not None:
         e = lib.Epilogue(stats[0].data_ptr(), int(stats[1]), int(stats[2]))
         if bn_bwd is not None:
@@ -256,6 +261,10 @@ _EPI_STATS = os.environ.get("FMRI_EPI_STATS") != "off"
 # default.  Measured on the B = 256 Stage-I step it removes 0.34 ms of reduction kernels but the epilogues' reads of the
 # saved forward tile (8 bytes per lane, latency exposed once per parity class) cost the data-gradient kernels 0.59 ms.
 _EPI_BWD = os.environ.get("FMRI_EPI_BWD") == "on"
+
+# ReLU backward of a bias + ReLU layer in the epilogue of the data gradient above it (fmri_epilogue.act_y), bias
+# gradient out of the narrow weight-gradient kernel's spare column: on/off
+_EPI_ACT = os.environ.get("FMRI_EPI_ACT") != "off"
 
 # window-resident wgrad kernel: on/off, resident-block target (2 per CU), largest split count still written as slabs
 _WW_ON = os.environ.get("FMRI_WGRAD_WIN") != "off"
@@ -347,6 +356,7 @@ def run_wgrad(P, Q, N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad, flip=0):
         out = torch.zeros(nslabs, apad, ldo, dtype=torch.float32, device=P.device)
         lib.call("fmri_wgrad", _P(P), _P(Q), _P(out), _P(zero_page(P.device)), N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad,
                  flip, apad, ba, ldo, nslabs, 3)
+        out._fmri_colsum = True            # column 200 of every slab row a holds sum_m P[m][a]
         return out, ldo
     tiles = (ldo // 128) * (apad // ba)
     steps = (N * Yc * Xc + 63) // 64
@@ -449,8 +459,12 @@ class ConvLayer:
         return 2.0 * N * pix * self.cin * self.cout * self.k * self.k
 
     def dgrad(self, dy: torch.Tensor, hi: int, wi: int, out: Optional[torch.Tensor] = None,
-              bn_bwd: Optional[dict] = None) -> torch.Tensor:
+              bn_bwd: Optional[dict] = None, relu_y: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Cotangent w.r.t. the layer input (same scale as dy).
+
+        ``relu_y``: the saved ReLU output this layer consumed (geometry of the result): ask the kernel's epilogue for the
+        ReLU backward as well (fmri_epilogue.act_y).  ``self.act_applied`` tells whether it did -- if not, the result is
+        the plain data gradient and ``act_backward`` has to follow.
 
         ``bn_bwd`` = dict(bn=<BatchNorm whose (ReLU'd) output is this layer's input>, x=<its saved forward input>,
         groups=[(first image of x, BNSaved), ...]): the rows of ``dy`` are len(groups) equal blocks (cotangent streams /
@@ -479,22 +493,25 @@ class ConvLayer:
         if self.kind == "conv":
             mode = MODE_TCONV2 if self.stride == 2 else MODE_CONV_FLIP
             r = run_igemm(dy, self.pw_d, out, None, N, Ho, Wo, self.coutp, hi, wi, self.cinp, self.cin, self.k,
-                          self.stride, self.pad, mode, ACT_NONE, False, 1, 0, self.t_in, fl, stats=stats, bn_bwd=bb)
+                          self.stride, self.pad, mode, ACT_NONE, False, 1, 0, self.t_in, fl, stats=stats, bn_bwd=bb,
+                          act_y=relu_y if _EPI_ACT else None)
         else:
             r = run_igemm(dy, self.pw_d, out, None, N, Ho, Wo, self.coutp, hi, wi, self.cinp, self.cin, self.k, 2,
                           self.pad, MODE_CONV, ACT_NONE, False, 1, 0, self.t_in, fl, stats=stats, bn_bwd=bb)
-        self._bwd_rows = r if stats is not None else 0
+        self._bwd_rows = (r & ~lib.EP_ACT_APPLIED) if stats is not None else 0
+        self.act_applied = bool(r & lib.EP_ACT_APPLIED)
         return out
 
     def take_bwd_stats(self):
         """(rows tensor [G][cap][2][cinp], valid rows per group) of the last ``dgrad(..., bn_bwd=...)``, or None."""
         return (self._bwd_part, self._bwd_rows) if getattr(self, "_bwd_rows", 0) > 0 else None
 
-    def wgrad(self, x: torch.Tensor, dy: torch.Tensor, scale: float):
-        """weight.grad += (1/scale) * dW(x, dy)  (on the side stream: ops.join_side() before the gradient is read)."""
-        side_run(x.device, lambda: self._wgrad(x, dy, scale), x, dy)
+    def wgrad(self, x: torch.Tensor, dy: torch.Tensor, scale: float, bias_too: bool = False):
+        """weight.grad += (1/scale) * dW(x, dy)  (on the side stream: ops.join_side() before the gradient is read).
+        ``bias_too`` (kind='conv', stride 1, cin < cout): bias.grad += (1/scale) * sum_pixels(dy) as well."""
+        side_run(x.device, lambda: self._wgrad(x, dy, scale, bias_too), x, dy)
 
-    def _wgrad(self, x: torch.Tensor, dy: torch.Tensor, scale: float):
+    def _wgrad(self, x: torch.Tensor, dy: torch.Tensor, scale: float, bias_too: bool = False):
         N, Hi, Wi, _ = x.shape
         _, Ho, Wo, _ = dy.shape
         if self.kind == "conv" and self.stride == 1 and self.cinp > self.coutp:
@@ -511,6 +528,12 @@ class ConvLayer:
         else:
             packed, ldo = run_wgrad(x, dy, N, Hi, Wi, self.cinp, Ho, Wo, self.coutp, self.k, 2, self.pad)
         unpack_grad(packed, self.wg, self.gspec, ldo, 1.0 / scale)
+        if bias_too:
+            # bias.grad += (1/scale) * sum over pixels of dy: the narrow kernel's spare column, else a reduction
+            if getattr(packed, "_fmri_colsum", False):
+                self.bg.add_(packed[:, :self.cout, self.k * self.k * self.cinp].sum(0), alpha=1.0 / scale)
+            else:
+                self.bg.add_(dy.reshape(-1, self.coutp)[:, :self.cout].float().sum(0), alpha=1.0 / scale)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -91,11 +91,20 @@ def pmc_traffic(label):
                 kernels = json.load(f)["kernels"]
         except (OSError, ValueError, KeyError):
             continue
+        tot = cnt = 0
         for kname, v in kernels.items():
             n = kname.replace(" ", "")
             n = n[4:] if n.startswith("void") else n
-            if n.split("(")[0] == want:
+            n = n.split("(")[0]
+            if n == want:
                 return v["bytes_per_launch"], name
+            # a label without the epilogue template argument (igemm_c5_kernel<16>) covers every epilogue variant of the
+            # kernel (<16,0>, <16,1>, ...): launch-weighted mean, like the HIP-event timing of that label
+            if want.endswith(">") and n.startswith(want[:-1] + ","):
+                tot += v["bytes_per_launch"] * v["launches"]
+                cnt += v["launches"]
+        if cnt:
+            return int(tot / cnt), name
     return None, None
 
 

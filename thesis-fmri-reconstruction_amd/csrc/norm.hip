@@ -564,10 +564,10 @@ int bn_stats_finalize_launch(const half_t* x, int M, int C, float* sums, float* 
                        beta, eps, momentum, updates, rm, rv, mean, rstd, scale, shift, nbt);
     return LAUNCH_OK();
 }
-// Statistics rows of a contraction's epilogue (StatEpi): part [rows][2][C] -> sums (+ finalize).  More than 256 rows are
+// Statistics rows of a contraction's epilogue (StatEpi): part [rows][2][C] -> sums (+ finalize).  More than 512 rows are
 // folded in two stages through `scratch` (FOLD_STAGE_ROWS x 2C floats).
 static const float* fold_stage1(const float* part, int& rows, int n, float* scratch, hipStream_t st) {
-    if (rows <= 256) return part;
+    if (rows <= 512) return part;        // one 1024-thread block per 32 channels folds 512 rows in 8 four-deep iterations
     const int per = (rows + FOLD_STAGE_ROWS - 1) / FOLD_STAGE_ROWS;
     const int ny = (rows + per - 1) / per;
     hipLaunchKernelGGL(fold_rows_kernel, dim3((n + 31) / 32, ny), dim3(1024), 0, st, part, rows, n, per, scratch,
@@ -596,7 +596,7 @@ int bn_bwd_fold_launch(const float* part, int rows, int rows_cap, int C, int G, 
     const int n = 2 * C;
     int64_t gstride = (int64_t)rows_cap * n;
     const float* src = part;
-    if (rows > 256) {
+    if (rows > 512) {
         const int per = (rows + FOLD_STAGE_ROWS - 1) / FOLD_STAGE_ROWS;
         const int ny = (rows + per - 1) / per;
         hipLaunchKernelGGL(fold_rows_kernel, dim3((n + 31) / 32, ny, G), dim3(1024), 0, st, part, rows, n, per, scratch,

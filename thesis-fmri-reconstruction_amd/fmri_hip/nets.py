@@ -476,8 +476,17 @@ class DiscriminatorNet:
             if li > 0:
                 # the data gradient's epilogue masks with block li-1's ReLU and reduces its BatchNorm backward sums, one
                 # statistics group per cotangent stream (all read the same saved forward tensor)
-                dact = self.convs[li].dgrad(d, hi, wi, bn_bwd=_bwd_epi(bn=self.bns[li - 1], x=ctx["raws"][li - 1],
-                                                                       groups=[(0, ctx["svs"][li - 1])] * S))
+                epi = _bwd_epi(bn=self.bns[li - 1], x=ctx["raws"][li - 1], groups=[(0, ctx["svs"][li - 1])] * S)
+                ztail = getattr(dfeat16, "_fmri_zero_tail", 0) if (li == 2 and dfeat16 is not None and S > 1) else 0
+                if ztail and epi is None and d.shape[0] == S * n3:
+                    # stream B enters at conv3's raw output with exact zeros on the sampled images' rows -- the last rows
+                    # of the stack: conv3's data gradient (per image) skips them, its result there is zero
+                    live = d.shape[0] - ztail
+                    dact = torch.empty(d.shape[0], hi, wi, self.convs[li].cinp, dtype=torch.float16, device=d.device)
+                    self.convs[li].dgrad(d[:live], hi, wi, out=dact[:live])
+                    dact[live:].zero_()
+                else:
+                    dact = self.convs[li].dgrad(d, hi, wi, bn_bwd=epi)
                 stat = self.convs[li].take_bwd_stats()
                 dn = torch.empty_like(dact)
                 if S == 2 and not streams[1]["train"]:

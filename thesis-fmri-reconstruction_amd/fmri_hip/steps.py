@@ -274,6 +274,7 @@ class _GanStepBase:
         stack = torch.empty((2 * feat.shape[0],) + tuple(feat.shape[1:]), dtype=feat.dtype, device=dev)
         dfeat16 = stack[feat.shape[0]:]
         dfeat16._fmri_stack = stack
+        dfeat16._fmri_zero_tail = B          # the rows of the sampled images are exact zeros (fmri_feat_mse_bwd)
         lib.call("fmri_feat_mse_bwd", _P(feat), B, feat[0].numel(), _P(dfeat16), self.sc.b, _P(self._slot(S_NB)))
         return dlogit16, dfeat16
 

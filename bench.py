@@ -129,7 +129,7 @@ def build_stage1(dev, B, rank, dist_on, sync_bn):
     xs = [_images(np.random.RandomState(1234 + 97 * i + rank), B, 64, dev) for i in range(NBATCH)]
     nz = [_noise(np.random.RandomState(1236 + 97 * i + rank), 2, B, cfg.latent_dim, dev) for i in range(NBATCH)]
     return st, (lambda i: st.step(xs[i % NBATCH], nz[i % NBATCH][0], nz[i % NBATCH][1])), stage1_step_flops(cfg), \
-        (xs[0], nz[0][0], nz[0][1])
+        [xs, [n[0] for n in nz], [n[1] for n in nz]]
 
 
 def build_stage2(dev, B, rank, dist_on, sync_bn):
@@ -146,7 +146,7 @@ def build_stage2(dev, B, rank, dist_on, sync_bn):
     def run(i):
         j = i % NBATCH
         return st.step(fm[j], xs[j], nz[j][0], nz[j][1], nz[j][2])
-    return st, run, stage2_step_flops(cfg, V), None
+    return st, run, stage2_step_flops(cfg, V), [fm, xs, [n[0] for n in nz], [n[1] for n in nz], [n[2] for n in nz]]
 
 
 def build_dual1(dev, B, rank, dist_on, sync_bn):
@@ -161,7 +161,7 @@ def build_dual1(dev, B, rank, dist_on, sync_bn):
     def run(i):
         j = i % NBATCH
         return st.step(xs[j], nz[j][0], nz[j][1], nz[j][2])
-    return st, run, dual1_step_flops(cfg), None
+    return st, run, dual1_step_flops(cfg), [xs, [n[0] for n in nz], [n[1] for n in nz], [n[2] for n in nz]]
 
 
 def build_stage3_px128(dev, B, rank, dist_on, sync_bn):
@@ -178,7 +178,7 @@ def build_stage3_px128(dev, B, rank, dist_on, sync_bn):
           for i in range(NBATCH)]
     f = forward_flops(cfg, V)
     return st, (lambda i: st.step(xs[i % NBATCH], fmri=fm[i % NBATCH])), f["C"] + f["E"] + 3.0 * f["D"] + 8.0 * f["W"], \
-        None
+        [xs, None, fm]
 
 
 WORKLOADS = {
@@ -301,7 +301,7 @@ def main():
 
     metric, unit, desc, wl_batch, builder = WORKLOADS[a.workload]
     B = a.batch or wl_batch
-    st, run_i, flop_per_sample, static = builder(dev, B, rank, world > 1 or force_dist, a.sync_bn)
+    st, run_i, flop_per_sample, rot = builder(dev, B, rank, world > 1 or force_dist, a.sync_bn)
 
     def barrier():
         if world > 1:
@@ -316,39 +316,36 @@ def main():
             log("first step done")
     barrier()
     log("warm-up done")
-    # Launch modes.  eager: every launch issued from Python, over NBATCH rotating synthetic batches.  For the headline
-    # workload the step can also be recorded into HIP graphs (graph: one-stream full step; hybrid: recorded forward +
-    # eager two-stream backward): the recorded inputs are static buffers, refreshed from the rotating batches by three
-    # device copies per step inside the timed region.  In multi-process runs the RCCL collectives stay eager calls
+    # Launch modes.  eager: every launch issued from Python, over NBATCH rotating synthetic batches.  The step can also be
+    # recorded into HIP graphs (graph: one-stream full step; hybrid, headline workload only: recorded forward + eager
+    # two-stream backward): the recorded inputs are static buffers, refreshed from the rotating batches by one device
+    # copy per input and step inside the timed region.  In multi-process runs the RCCL collectives stay eager calls
     # between the graph segments.  A short probe picks the fastest mode, the same on every rank.
     modes = {"eager": run_i}
     single = world == 1 and not force_dist
-    if a.workload == "stage1" and not a.eager:
-        sx, se, sz = (t.clone() for t in static)
-        # the rotating batches (same seeds as the builder's) that feed the static input buffers of the recorded modes
-        rs_x = [_images(np.random.RandomState(1234 + 97 * i + rank), B, 64, dev) for i in range(NBATCH)]
-        rs_n = [_noise(np.random.RandomState(1236 + 97 * i + rank), 2, B, 128, dev) for i in range(NBATCH)]
+    if not a.eager and hasattr(st, "capture"):
+        sbuf = [None if r is None else r[0].clone() for r in rot]
 
         def staged(replay):
             def run(i):
                 j = i % NBATCH
-                sx.copy_(rs_x[j])
-                se.copy_(rs_n[j][0])
-                sz.copy_(rs_n[j][1])
+                for buf, r in zip(sbuf, rot):
+                    if buf is not None:
+                        buf.copy_(r[j])
                 return replay()
             return run
         try:
-            g = st.capture(sx, se, sz)
+            g = st.capture(*sbuf)
             modes["graph"] = staged(g)
             modes["graph"](0)
             log("step captured into HIP graph(s)")
         except Exception as e:               # capture is an optimisation: fall back to eager launches
             log(f"graph capture failed ({type(e).__name__}: {e}); continuing with eager launches")
             modes.pop("graph", None)
-        if (single or not a.sync_bn) and ops._SIDE["on"] and not a.graph:
+        if (a.workload == "stage1" and (single or not a.sync_bn) and ops._SIDE["on"] and not a.graph):
             # hybrid: recorded forward + eagerly issued two-stream backward (half the Python work of a step)
             try:
-                h = st.capture_forward(sx, se, sz)
+                h = st.capture_forward(*sbuf)
                 modes["hybrid"] = staged(h)
                 modes["hybrid"](0)
             except Exception as e:

@@ -226,6 +226,23 @@ int fmri_gan_head_bwd_parts(const float* logit, int ldl, int B, void* dlogit, in
                             int parts, void* stream);
 int fmri_wae_logloss(const float* logit, int ldl, int n, int one_minus, float w, float* total, float* prob,
                      void* dlogit, int ldg, float gscale, void* stream);
+/* ---- the WAE latent discriminator (models/vae_gan.py:499-529: Linear(z,H) ReLU [Linear(H,H) ReLU] x 3 Linear(H,1),
+ * sigmoid left to fmri_wae_logloss) as one launch forward and one for the backward chain (H = 512, Zp a multiple of 64
+ * <= 256; anything else: FMRI_E_UNSUPPORTED, use fmri_igemm layer by layer).
+ * fmri_mlp_fwd: z16 [M][Zp] fp16; w5[i] = layer i's packed fp16 weights in the forward orientation ([rows_pad][kp5[i]],
+ *   row = output feature: what fmri_pack_weight produces for fmri_igemm), bias5[i] fp32 (may be NULL); hs4[i] receives
+ *   the hidden activations h_{i+1} [M][H] fp16 (the backward pass needs them), logit [M] fp32 the pre-sigmoid output.
+ * fmri_mlp_bwd: dlogit16 [M][ldl] (column 0) -> delta4[i] = cotangent of the pre-activation of h_{i+1} ([M][H] fp16:
+ *   the P operands of the layers' fmri_wgrad calls), dbias5[i] += inv_scale * column sums (NULL dbias5 or entry: skip),
+ *   dz32 [M][Z] fp32 = inv_scale * (delta1 . W0) (NULL: skip).  w4row = row 0 of the output layer's forward-orientation
+ *   matrix; wd4[i] = layer i's packed weights in the data-gradient orientation ([rows_pad][kpd4[i]], row = input
+ *   feature); wd4[0] is read only when dz32 is given.  Replaces the autograd data path of
+ *   train/train_wae_stage1.py:278-303. */
+int fmri_mlp_fwd(const void* z16, int M, int Zp, int H, const void* const* w5, const int* kp5, const float* const* bias5,
+                 void* const* hs4, float* logit, void* stream);
+int fmri_mlp_bwd(const void* dlogit16, int ldl, int M, int Zp, int Z, int H, const void* const* hs4, const void* w4row,
+                 const void* const* wd4, const int* kpd4, void* const* delta4, float* const* dbias5, float* dz32,
+                 float inv_scale, void* stream);
 /* scal slots: in [0..5] bce_o,bce_p,bce_s,kl,mse,nle and [9] dl2; out [6..8] loss_encoder/discriminator/decoder,
  * [10] nA = 1/rms(d bce/d logit), [11] nB = 1/rms(d mse/d feature), [12] nA/nB, [13] 1.0; flags = {train_dis, train_dec} */
 int fmri_compose_gate(float* scal, int* flags, float batch, float nfeat, float lambda_mse, float equilibrium,

@@ -233,3 +233,116 @@ def test_dual_stage1_batch128_first_step_matches_oracle():
     for k in GAN_KEYS + WAE_KEYS[1:]:
         print(k, logs[k], ref["logs"][k], _rel(logs[k], ref["logs"][k]))
         assert _rel(logs[k], ref["logs"][k]) < 1e-3, (k, logs[k], ref["logs"][k])
+
+
+@pytest.mark.parametrize("M,train,need_dz", [(8, True, False), (256, True, False), (77, False, True), (512, True, True)])
+def test_latent_discriminator_fused_kernels(M, train, need_dz):
+    """csrc/mlp.hip (one launch forward, one for the backward data path) against a torch fp32 MLP on the same
+    fp16-rounded weights, and against the layer-by-layer engine path it replaces (FMRI_MLP=off)."""
+    from fmri_hip import nets, ops
+    from fmri_hip.params import ArchConfig
+    cfg = ArchConfig.px64()
+    torch.manual_seed(M)
+    wd = nets.WaeDiscriminatorNet(cfg, DEV)
+    wd.group.load_recipe(np.random.RandomState(3), True)
+    for idx in (0, 2, 4, 6, 8):                          # the reference initialises these biases to zero: perturb them
+        wd.group.views[f"main.{idx}.bias"].normal_(0.0, 0.05)
+    wd.group.version += 1
+    z = (torch.randn(M, cfg.latent_dim, device=DEV) * 0.7).half()
+    dlog = torch.zeros(M, 8, dtype=torch.float16, device=DEV)
+    dlog[:, 0] = (torch.randn(M, device=DEV) * 0.5).half()
+    scale = 4.0
+
+    def run(fused):
+        nets._MLP_ON = fused
+        wd.group.zero_grad()
+        logit, ctx = wd.forward(z)
+        assert bool(ctx.get("fused")) == fused
+        dz = wd.backward(ctx, dlog, scale, train, need_dz)
+        torch.cuda.synchronize()
+        grads = {k: v.clone() for k, v in wd.group.grads.items()}
+        return logit.clone(), None if dz is None else dz.clone(), grads, [h.clone() for h in ctx["hs"][1:]]
+    try:
+        lf, dzf, gf, hf = run(True)
+        lu, dzu, gu, hu = run(False)
+    finally:
+        nets._MLP_ON = True
+
+    # torch fp32 reference on the fp16-rounded weights and activations rounded to fp16 between the layers
+    Ws = [wd.group.views[f"main.{i}.weight"].half().float() for i in (0, 2, 4, 6, 8)]
+    bs = [wd.group.views[f"main.{i}.bias"].float() for i in (0, 2, 4, 6, 8)]
+    h = z.float()
+    hs = []
+    for j in range(4):
+        h = torch.relu(h @ Ws[j].t() + bs[j]).half().float()
+        hs.append(h)
+    ref_logit = h @ Ws[4].t() + bs[4]
+    assert _terr(lf, ref_logit) < 2e-3 and _terr(lu, ref_logit) < 2e-3
+    for a, b in zip(hf, hs):
+        assert _terr(a, b) < 2e-3
+    # backward reference
+    d = dlog[:, :1].float() @ Ws[4]
+    d = d * (hs[3] > 0)
+    gref = {"main.8.weight": dlog[:, :1].float().t() @ hs[3], "main.8.bias": dlog[:, 0].float().sum().reshape(1)}
+    xs = [z.float()] + hs
+    for j in (3, 2, 1, 0):
+        d16 = d.half().float()
+        gref[f"main.{2 * j}.weight"] = d16.t() @ xs[j]
+        gref[f"main.{2 * j}.bias"] = d16.sum(0)
+        d = d16 @ Ws[j]
+        if j > 0:
+            d = d * (hs[j - 1] > 0)
+    if need_dz:
+        assert _terr(dzf, d / scale) < 3e-3 and _terr(dzu, d / scale) < 3e-3
+    if train:
+        for k, ref in gref.items():
+            assert _terr(gf[k] * scale, ref) < 4e-3, k
+            assert _terr(gf[k], gu[k]) < 4e-3, k
+    else:
+        assert all(float(v.abs().max()) == 0.0 for v in gf.values())
+
+
+@pytest.mark.parametrize("stage", [1, 3])
+def test_wae_step_recorded_into_a_hip_graph_equals_eager_steps(stage):
+    """WaeStep.capture: the whole step (Adam with its step count on the device) replayed from a HIP graph follows the
+    eagerly issued steps -- same losses and parameters after 2 warm-up + 3 replayed steps."""
+    from fmri_hip.params import ArchConfig
+    from fmri_hip.wae_steps import WaeStep
+    cfg, V, B = ArchConfig.px64(), 512, 8
+    rs = np.random.RandomState(11)
+    x = torch.tanh(torch.from_numpy(rs.standard_normal((B, 3, 64, 64)).astype(np.float32))).to(DEV)
+    zf = torch.from_numpy(rs.standard_normal((B, cfg.latent_dim)).astype(np.float32)).to(DEV)
+    fm = torch.from_numpy(rs.standard_normal((B, V)).astype(np.float32)).to(DEV)
+    args = (x, zf) if stage == 1 else (x, None, fm)
+
+    def make():
+        st = WaeStep(cfg, DEV, stage, V if stage > 1 else 0)
+        st.load_recipe(5, False if stage == 1 else None)
+        return st
+    a, b = make(), make()
+    s0 = {k: v.clone() for k, v in a.state_dict().items()}
+    for _ in range(5):
+        a.step(*args)
+    run = b.capture(*args)            # two eager warm-up steps inside
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    la, lb = a.logs(), b.logs()
+    for k in WAE_KEYS:
+        assert _rel(lb[k], la[k]) < 2e-3, (k, lb[k], la[k])
+    sa, sb = a.state_dict(), b.state_dict()
+    # Adam's first steps are sign-like (+-lr per element) and elements with near-zero gradients flip with the run-to-run
+    # spread of the fp32 atomics: the five-step UPDATES of every large tensor must point the same way
+    for k in sa:
+        if not sa[k].dtype.is_floating_point or sa[k].numel() < 1024 or "running" in k:
+            continue
+        ua, ub = (sa[k] - s0[k]).double().reshape(-1), (sb[k] - s0[k]).double().reshape(-1)
+        if float(ua.norm()) == 0.0:
+            assert float(ub.norm()) == 0.0, k
+            continue
+        cos = float((ua @ ub) / (ua.norm() * ub.norm() + 1e-30))
+        assert cos > 0.9, (k, cos)
+    for k in sa:
+        if "running" in k:
+            assert _terr(sb[k], sa[k]) < 6e-2, k       # batch statistics of 8 samples after diverging sign-like steps
+    assert all(int(sa[k]) == int(sb[k]) for k in sa if "num_batches" in k)

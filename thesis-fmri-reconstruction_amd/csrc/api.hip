@@ -780,6 +780,39 @@ int fmri_wae_logloss(const float* logit, int ldl, int n, int one_minus, float w,
     if (!logit) return FMRI_E_BADARG;
     return wae_logloss_launch(logit, ldl, n, one_minus, w, total, prob, (half_t*)dlogit, ldg, gscale, S(stream));
 }
+int fmri_mlp_fwd(const void* z16, int M, int Zp, int H, const void* const* w5, const int* kp5, const float* const* bias5,
+                 void* const* hs4, float* logit, void* stream) {
+    if (!z16 || !w5 || !kp5 || !bias5 || !hs4 || !logit || M < 1) return FMRI_E_BADARG;
+    MlpFwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.z = (const half_t*)z16; a.M = M; a.Zp = Zp; a.H = H; a.logit = logit;
+    for (int i = 0; i < 5; ++i) {
+        if (!w5[i] || kp5[i] < (i == 0 ? Zp : H)) return FMRI_E_BADARG;
+        a.w[i] = (const half_t*)w5[i]; a.kp[i] = kp5[i]; a.bias[i] = bias5[i];
+    }
+    for (int i = 0; i < 4; ++i) {
+        if (!hs4[i]) return FMRI_E_BADARG;
+        a.hs[i] = (half_t*)hs4[i];
+    }
+    return mlp_fwd_launch(a, S(stream));
+}
+int fmri_mlp_bwd(const void* dlogit16, int ldl, int M, int Zp, int Z, int H, const void* const* hs4, const void* w4row,
+                 const void* const* wd4, const int* kpd4, void* const* delta4, float* const* dbias5, float* dz32,
+                 float inv_scale, void* stream) {
+    if (!dlogit16 || !hs4 || !w4row || !wd4 || !kpd4 || !delta4 || M < 1 || ldl < 1 || Z > Zp) return FMRI_E_BADARG;
+    MlpBwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.dlogit = (const half_t*)dlogit16; a.ldl = ldl; a.M = M; a.Zp = Zp; a.H = H; a.Z = Z;
+    a.w4 = (const half_t*)w4row; a.dz = dz32; a.inv_scale = inv_scale;
+    for (int i = 0; i < 4; ++i) {
+        if (!hs4[i] || !delta4[i]) return FMRI_E_BADARG;
+        if ((i > 0 || dz32) && (!wd4[i] || kpd4[i] < H)) return FMRI_E_BADARG;
+        a.hs[i] = (const half_t*)hs4[i]; a.delta[i] = (half_t*)delta4[i];
+        a.wd[i] = (const half_t*)wd4[i]; a.kpd[i] = kpd4[i];
+    }
+    for (int i = 0; i < 5; ++i) a.dbias[i] = dbias5 ? dbias5[i] : nullptr;
+    return mlp_bwd_launch(a, S(stream));
+}
 int fmri_compose_gate(float* scal, int* flags, float batch, float nfeat, float lambda_mse, float equilibrium,
                       float margin, int gate_on, int force_dis, int force_dec, void* stream) {
     if (!scal || !flags) return FMRI_E_BADARG;

@@ -216,6 +216,31 @@ struct C5Args {
     BnBwdEpi bb;
 };
 
+// fused latent-discriminator MLP (mlp.hip): z -> H -> H -> H -> H -> 1, ReLU between the layers
+struct MlpFwdArgs {
+    const half_t* z;           // [M][Zp]
+    int32_t M, Zp, H, pad0;
+    const half_t* w[5];        // forward-orientation packed weights of layers 0..4: [rows_pad][kp], row = output feature
+    int32_t kp[5], pad1;
+    const float* bias[5];      // may be null
+    half_t* hs[4];             // hidden activations h1..h4 [M][H] (saved for the backward pass)
+    float* logit;              // [M]
+};
+
+struct MlpBwdArgs {
+    const half_t* dlogit;      // [M][ldl], column 0
+    int32_t ldl, M, Zp, H, Z, pad0;
+    const half_t* hs[4];
+    const half_t* w4;          // row 0 of the output layer's forward-orientation matrix: [H]
+    const half_t* wd[4];       // data-gradient orientation of layers 0..3: [rows_pad][kpd], row = input feature
+    int32_t kpd[4];
+    half_t* delta[4];          // cotangents of the pre-activations of h1..h4: [M][H]
+    float* dbias[5];           // += inv_scale * column sums (null: skip)
+    float* dz;                 // [M][Z] fp32, null: skip
+    float inv_scale;
+    int32_t pad1;
+};
+
 // weight-gradient implicit GEMM (wgrad.hip):
 //   dW[a][tap*Bc + b] (+)= sum_m P[m][a] * Q[n, y*s+dy(tap), x*s+dx(tap), b],  m = (n, y, x)
 struct WgradArgs {

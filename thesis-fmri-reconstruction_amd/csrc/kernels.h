@@ -40,6 +40,8 @@ int igemm_tc32_launch(const Tc32Args& a, int nblocks, hipStream_t st);
 int igemm_tc5_launch(const Tc5Args& a, int bn_tile, int copad, hipStream_t st);
 int igemm_tc5b_launch(const Tc5Args& a, int bn_tile, int copad, hipStream_t st);
 int igemm_c5_launch(const C5Args& a, int copad, hipStream_t st);
+int mlp_fwd_launch(const MlpFwdArgs& a, hipStream_t st);
+int mlp_bwd_launch(const MlpBwdArgs& a, hipStream_t st);
 int igemm_narrow_launch(const NarrowArgs& a, int ci, int co_tiles, bool flip, hipStream_t st);
 int wgrad_launch(const WgradArgs& a, int apad, int ba_tile, hipStream_t st);
 int wgrad_win_launch(const WgradWinArgs& a, int apad, hipStream_t st);

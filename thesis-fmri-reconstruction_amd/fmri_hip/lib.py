@@ -60,6 +60,8 @@ _SIGS = {
     "fmri_gan_head_parts": [_p, _i, _i, _p, _p, _i, _p],
     "fmri_gan_head_bwd_parts": [_p, _i, _i, _p, _i, _f, _p, _i, _p],
     "fmri_wae_logloss": [_p, _i, _i, _i, _f, _p, _p, _p, _i, _f, _p],
+    "fmri_mlp_fwd": [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p],
+    "fmri_mlp_bwd": [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _f, _p],
     "fmri_compose_gate": [_p, _p, _f, _f, _f, _f, _f, _i, _i, _i, _p],
     "fmri_axpby_f16": [_p, _p, _p, _l, _f, _f, _p, _p],
     "fmri_axpby2_f16": [_p, _p, _p, _l, _f, _f, _p, _p, _p],

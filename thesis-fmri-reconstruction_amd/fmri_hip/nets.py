@@ -12,6 +12,8 @@ from __future__ import annotations
 
 from typing import List, Optional
 
+import os
+
 import torch
 
 from . import lib
@@ -73,6 +75,9 @@ class FusedHeads:
             dh, _ = self.dense.dgrad(dhead16)
             return dh
         return None
+
+
+_MLP_ON = os.environ.get("FMRI_MLP") != "off"        # fused latent-discriminator kernels (csrc/mlp.hip)
 
 
 def _bwd_epi(**kw):
@@ -566,7 +571,33 @@ class WaeDiscriminatorNet:
     def all_bns(self):
         return []
 
+    # The fused kernels (csrc/mlp.hip: one launch forward, one for the backward data path) take this network's own
+    # packed weights; FMRI_MLP=off (or a width they do not cover) keeps the layer-by-layer path below.
+    def _fused_ok(self, z16) -> bool:
+        dims = [l.n_out for l in self.layers]
+        return (_MLP_ON and len(self.layers) == 5 and dims[:4] == [512] * 4 and dims[4] == 1
+                and z16.shape[1] % 64 == 0 and 64 <= z16.shape[1] <= 256)
+
+    @staticmethod
+    def _ptrs(tensors):
+        import ctypes
+        arr = (ctypes.c_void_p * len(tensors))()
+        for i, t in enumerate(tensors):
+            arr[i] = None if t is None else t.data_ptr()
+        return arr
+
     def forward(self, z16: torch.Tensor):
+        if self._fused_ok(z16):
+            import ctypes
+            M, Zp = z16.shape
+            dev = z16.device
+            ws = [l.pw_f.get() for l in self.layers]
+            kps = (ctypes.c_int * 5)(*[l.pw_f.kpads[0] for l in self.layers])
+            hbuf = torch.empty(4, M, 512, dtype=torch.float16, device=dev)
+            logit32 = torch.empty(M, 1, dtype=torch.float32, device=dev)
+            lib.call("fmri_mlp_fwd", _P(z16), M, Zp, 512, self._ptrs(ws), kps, self._ptrs([l.b for l in self.layers]),
+                     self._ptrs([hbuf[i] for i in range(4)]), _P(logit32))
+            return logit32, dict(hs=[z16] + [hbuf[i] for i in range(4)], fused=True)
         hs = [z16]
         h = z16
         for l in self.layers[:-1]:
@@ -584,6 +615,8 @@ class WaeDiscriminatorNet:
         return out
 
     def _backward(self, ctx, dlogit16, scale, train: bool, need_dz: bool):
+        if ctx.get("fused"):
+            return self._backward_fused(ctx, dlogit16, scale, train, need_dz)
         d = dlogit16
         hs = ctx["hs"]
         for j in range(4, -1, -1):
@@ -599,3 +632,26 @@ class WaeDiscriminatorNet:
             dn, _ = l.dgrad(d)
             d = act_backward(hs[j], dn, ACT_RELU)
         return None
+
+    def _backward_fused(self, ctx, dlogit16, scale, train: bool, need_dz: bool):
+        """One launch for the data path (cotangents of the four hidden pre-activations, bias gradients, dz); the five
+        weight gradients -- reductions over all rows -- are fmri_wgrad launches on the side stream."""
+        import ctypes
+        hs = ctx["hs"]
+        z16 = hs[0]
+        M, Zp = z16.shape
+        dev = z16.device
+        Z = self.layers[0].k_in
+        dbuf = torch.empty(4, M, 512, dtype=torch.float16, device=dev)
+        dz32 = torch.empty(M, Z, dtype=torch.float32, device=dev) if need_dz else None
+        wds = [(self.layers[i].pw_d.get() if (i > 0 or need_dz) else None) for i in range(4)]
+        kpd = (ctypes.c_int * 4)(*[self.layers[i].pw_d.kpads[0] for i in range(4)])
+        dbias = self._ptrs([l.bg for l in self.layers]) if train else None
+        lib.call("fmri_mlp_bwd", _P(dlogit16), dlogit16.shape[1], M, Zp, Z, 512, self._ptrs(hs[1:5]),
+                 _P(self.layers[4].pw_f.get()), self._ptrs(wds), kpd, self._ptrs([dbuf[i] for i in range(4)]), dbias,
+                 _P(dz32), 1.0 / scale)
+        if train:
+            deltas = [dbuf[0], dbuf[1], dbuf[2], dbuf[3], dlogit16]
+            for j in range(5):
+                self.layers[j].wgrad(hs[j], deltas[j], scale)
+        return dz32

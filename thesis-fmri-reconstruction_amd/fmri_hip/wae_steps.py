@@ -25,7 +25,8 @@ from . import lib
 from .nets import CognitiveEncoderNet, DecoderNet, EncoderNet, WaeDiscriminatorNet
 from .ops import images_to_nhwc, nhwc_to_images, pad8, require_gpu, rows_to_f16
 from .params import ArchConfig
-from .steps import S_ESQ, S_NA, S_NB, S_NE, GanHyper, Scales, Stage1Step, _attach_reducers, _Dist, _Optim
+from .steps import (S_ESQ, S_NA, S_NB, S_NE, GanHyper, Scales, Stage1Step, _attach_reducers, _Dist, _GanStepBase,
+                    _Optim)
 
 _P = lib.ptr
 
@@ -209,6 +210,12 @@ class WaeStep(_LatentDiscPhase):
             self.opt_dec.step()
         self.fw = dict(B=B, y=y, head32=head32, Z=Z)
         return self.scal
+
+    # HIP-graph recording of the whole step (Adam's step count and learning rates live on the device): the WAE steps are
+    # ~300 launches of a few microseconds each -- eagerly issued they are bound by the host, replayed by the GPU
+    capture = _GanStepBase.capture
+    _capture = _GanStepBase._capture
+    _versioned = _GanStepBase._versioned
 
     def _renorm(self, x32: torch.Tensor, scale: float, rows_global: int):
         n = x32.numel()

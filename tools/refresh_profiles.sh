@@ -1,12 +1,18 @@
 #!/bin/bash
-# refresh of the judged artefacts: GPU tests, bench line, rocprof kernel table of the same command, PMC traffic
-R=$PWD
-timeout -k 10 600 python -m pytest tests -q -m gpu > gpurun_out/gpu_tests.log 2>&1; tail -3 gpurun_out/gpu_tests.log
-python bench.py --steps 20 --warmup 5 > gpurun_out/bench.json 2> gpurun_out/bench.err; cat gpurun_out/bench.json
-cd /tmp && export TMPDIR=/tmp; cd $R
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_final -o x -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --eager --serial > gpurun_out/bench_rocprof.json 2> gpurun_out/bench_rocprof.err
-cp $(find $R/gpurun_out/prof_final -name "*kernel_stats.csv" | head -1) gpurun_out/final_kernel_stats.csv
-for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$c -o x -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --eager --serial > gpurun_out/pmc_$c.log 2>&1
+# refresh of the judged artefacts (run on the GPU box from the repo root): GPU tests, the default bench line, the other
+# workloads' lines, the rocprofv3 kernel table of the same command (one stream), PMC passes, per-layer microbenchmarks.
+# Results land in gpurun_out/final/; copy what is to be judged into profiles/ (named per round).
+R=${GRAFT_REPO_ROOT:-$PWD}
+OUT=$R/gpurun_out/final
+mkdir -p $OUT
+cd $R
+timeout -k 10 700 python -m pytest tests -q -m gpu > $OUT/gpu_tests.log 2>&1; tail -3 $OUT/gpu_tests.log
+timeout -k 10 400 python bench.py > $OUT/bench_stage1.json 2> $OUT/bench_stage1.err; cut -c1-200 $OUT/bench_stage1.json
+for w in stage2 dual1 stage3_px128; do
+  timeout -k 10 300 python bench.py --workload $w --steps 100 --warmup 20 > $OUT/bench_$w.json 2> $OUT/bench_$w.err
 done
-hipcc --offload-arch=gfx950 -O3 -o gpurun_out/mfma_peak tools/probes/mfma_peak.hip && timeout -k 5 120 gpurun_out/mfma_peak > gpurun_out/mfma_peak.log; cat gpurun_out/mfma_peak.log
+timeout -k 10 200 python tools/microbench_igemm.py > $OUT/microbench_igemm.log 2>&1
+timeout -k 10 300 python tools/time_other_steps.py > $OUT/other_steps.log 2>&1
+bash tools/prof_stats.sh final/prof > /dev/null 2>&1
+bash tools/pmc_passes.sh final/pmc > $OUT/pmc.log 2>&1
+ls $OUT $OUT/prof $OUT/pmc

@@ -416,7 +416,8 @@ def main():
         label, (ms, fl, nl) = max(by.items(), key=lambda kv: kv[1][0]) if by else ("none", (0.0, 0.0, 0))
         nl = max(nl, 1)
         achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        traffic, traffic_src = pmc_traffic(label)
+        # the committed PMC passes are of the Stage-I workload: no traffic figure for the other workloads
+        traffic, traffic_src = pmc_traffic(label) if a.workload == "stage1" else (None, None)
         finite = all(np.isfinite(v) for v in logs.values() if isinstance(v, float))
         out = {
             "metric": metric, "value": round(value, 1), "unit": unit,

@@ -49,6 +49,11 @@ def zero_page(device) -> torch.Tensor:
 def require_gpu(t: torch.Tensor):
     if not t.is_cuda:
         raise RuntimeError("fmri_hip: the HIP engine needs tensors on an MI355X device (no CPU fallback)")
+    # every launch goes to the CURRENT device's current stream (lib.stream): a tensor of another device would be
+    # addressed from the wrong GPU and lose its stream ordering
+    if t.device.index != torch.cuda.current_device():
+        raise RuntimeError(f"fmri_hip: tensor on {t.device} but the current device is cuda:{torch.cuda.current_device()}"
+                           " -- call torch.cuda.set_device() (or use `with torch.cuda.device(...)`) first")
 
 
 # ------------------------------------------------------------------------------------------------

@@ -359,7 +359,11 @@ def test_recorded_step_follows_hyper_parameter_schedule():
         flags.append((la["train_dis"], la["train_dec"]))
         assert (la["train_dis"], la["train_dec"]) == (lb["train_dis"], lb["train_dec"]), it
         for k in ("loss_encoder", "loss_decoder", "loss_discriminator", "kl"):
-            assert _rel(la[k], lb[k]) < (1e-5 if it == 0 else 5e-3), (it, k, la[k], lb[k])
+            # loss_decoder = lambda * mse - (1 - lambda) * loss_discriminator cancels to ~1e-3 under this schedule: its
+            # error is measured on the scale of its terms, not of the remainder
+            floor = 1e-2 * abs(lb["loss_discriminator"]) if k == "loss_decoder" else 0.0
+            err = abs(la[k] - lb[k]) / max(abs(lb[k]), floor, 1e-12)
+            assert err < (1e-5 if it == 0 else 5e-3), (it, k, la[k], lb[k])
         if it == 0:
             _same_update(a.state_dict(), b.state_dict(), "replay vs eager")
     assert flags[1] == (False, True), flags

@@ -12,7 +12,9 @@ H = 64
 for N in (64, 128, 256, 512, 768, 1536):
     dy = torch.randn(N, 32, 32, 128, device="cuda").half()
     x = torch.empty(N, H, H, 32, device="cuda").half()
-    f = lambda: L.dgrad(dy, H, H, out=x)
+    y0 = torch.relu(torch.randn(N, H, H, 32, device="cuda")).half()
+    masked = os.environ.get("MASK") == "1"
+    f = (lambda: L.dgrad(dy, H, H, out=x, relu_y=y0)) if masked else (lambda: L.dgrad(dy, H, H, out=x))
     for _ in range(3): f()
     torch.cuda.synchronize(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()

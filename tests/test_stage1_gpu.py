@@ -485,3 +485,47 @@ def test_stage1_full_batch_two_steps_match_oracle():
                     f.write(line + "\n")
             worst[(s, k)] = r
             assert r < (LOSS_RTOL if s == 0 else (1e-2 if k == "kl" else 3e-3)), (s, k, eng[s]["logs"][k], ref["logs"][k])
+
+
+def test_decoder_fc_running_statistics_lazy_shadow_round_trips():
+    """decoder.fc.1 (the (C,H,W)-permuted BatchNorm1d) keeps its running statistics in engine order inside the fused steps
+    and writes them back only when the state dict is read: state_dict() before any step returns what was loaded, after
+    steps (eager and replayed from a HIP graph) what an eagerly synchronised BatchNorm holds, and load_state_dict() in
+    between reaches the next step."""
+    from oracle import vaegan_oracle as O
+    from fmri_hip.params import ArchConfig
+    from fmri_hip.steps import Stage1Step
+    B = 4
+    data = O.synth_batch(B, O.ArchCfg.px64(), seed=1234, steps=1)
+    x, e, zp = data["x"].to(DEV), data["noise"][0, 0].to(DEV), data["noise"][0, 1].to(DEV)
+    a = Stage1Step(ArchConfig.px64(), DEV)
+    a.load_recipe(0, True)
+    keys = ("decoder.fc.1.running_mean", "decoder.fc.1.running_var")
+    sd0 = a.state_dict()
+    assert float(sd0[keys[0]].abs().max()) == 0.0 and float((sd0[keys[1]] - 1.0).abs().max()) == 0.0   # as loaded
+    b = Stage1Step(ArchConfig.px64(), DEV)
+    b.load_state_dict(sd0)
+    b.dec.fc_bn._lazy = False                         # reference behaviour: synchronised around every call
+    a.step(x, e, zp)
+    b.step(x, e, zp)
+    sa, sb = a.state_dict(), b.state_dict()
+    for k in keys:
+        assert _tensor_err(sa[k], sb[k]) < 1e-5, k
+    # an outside write of the buffers reaches the next step
+    sd = a.state_dict()
+    sd[keys[0]] = torch.full_like(sd[keys[0]], 3.0)
+    a.load_state_dict(sd)
+    b.load_state_dict(sd)
+    run = a.capture(x, e, zp, warmup=1)
+    run()
+    from fmri_hip import ops
+    side_was, ops._SIDE["on"] = ops._SIDE["on"], False
+    try:
+        b.step(x, e, zp)
+        b.step(x, e, zp)
+    finally:
+        ops._SIDE["on"] = side_was
+    torch.cuda.synchronize()
+    sa, sb = a.state_dict(), b.state_dict()
+    for k in keys:
+        assert _tensor_err(sa[k], sb[k]) < 2e-2, (k, _tensor_err(sa[k], sb[k]))

@@ -93,6 +93,8 @@ def refresh_net(net):
     repack_group(net.group)
     for bn in net.all_bns():
         bn._params()
+        if getattr(bn, "_lazy", False):
+            bn._running_in()             # reloads only after an outside write of the buffers (load_state_dict)
     heads = getattr(net, "heads", None)
     if heads is not None:
         heads.refresh()

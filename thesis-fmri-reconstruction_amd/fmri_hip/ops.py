@@ -673,17 +673,44 @@ class BatchNorm:
             self._v = self.group.version
         return self.gamma_e, self.beta_e, self.rm_e, self.rv_e
 
+    # Running statistics of a (C,H,W)-permuted BatchNorm1d: by default the engine-order copies are refreshed from / written
+    # back to the reference-order buffers around every call (4 tiny launches per call: what a module whose buffers alias
+    # them needs).  ``enable_lazy_running`` (fused step classes) makes the engine-order copies the live ones: they are
+    # loaded when the buffers were written from outside (FlatGroup.buf_version) and written back when somebody reads the
+    # buffers (FlatGroup.flush_hooks, i.e. state_dict()).
+    def enable_lazy_running(self):
+        if self.perm and not getattr(self, "_lazy", False):
+            self._lazy, self._run_v, self._run_dirty = True, -1, False
+            self.group.flush_hooks.append(self.flush_running)
+
     def _running_in(self):
         if self.perm:
+            if getattr(self, "_lazy", False):
+                if self._run_v == self.group.buf_version:
+                    return
+                self._run_v, self._run_dirty = self.group.buf_version, False
             c0, hw = self.perm
             lib.call("fmri_permute_chw", _P(self.rm), _P(self.rm_e), c0, hw, 1, 1.0, 0)
             lib.call("fmri_permute_chw", _P(self.rv), _P(self.rv_e), c0, hw, 1, 1.0, 0)
 
     def _running_out(self):
         if self.perm:
+            if getattr(self, "_lazy", False):
+                self._run_dirty = True
+                return
             c0, hw = self.perm
             lib.call("fmri_permute_chw", _P(self.rm_e), _P(self.rm), c0, hw, 0, 1.0, 0)
             lib.call("fmri_permute_chw", _P(self.rv_e), _P(self.rv), c0, hw, 0, 1.0, 0)
+
+    def flush_running(self):
+        """Lazy mode: write the engine-order running_mean / running_var back to the reference-order buffers.  Done whenever
+        the engine-order copies are the loaded, current ones -- a replayed HIP graph updates them without passing through
+        ``_running_out``, so there is no reliable dirty flag."""
+        if self.perm and getattr(self, "_lazy", False) and self._run_v == self.group.buf_version:
+            c0, hw = self.perm
+            lib.call("fmri_permute_chw", _P(self.rm_e), _P(self.rm), c0, hw, 0, 1.0, 0)
+            lib.call("fmri_permute_chw", _P(self.rv_e), _P(self.rv), c0, hw, 0, 1.0, 0)
+            self._run_dirty = False
 
     def forward(self, raw: torch.Tensor, relu: bool = True, updates: int = 1, out: Optional[torch.Tensor] = None,
                 stat_acc: Optional[torch.Tensor] = None):

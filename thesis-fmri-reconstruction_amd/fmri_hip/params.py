@@ -185,9 +185,13 @@ class FlatGroup:
         self.opt_state: Dict[str, torch.Tensor] = {}
         self.opt_steps = 0
         self.version = 0      # bumped whenever ``data`` changes -> packed fp16 copies are stale
+        self.buf_version = 0  # bumped whenever ``bufs`` are written from outside (load_state_dict)
+        self.flush_hooks = [] # callables bringing ``bufs`` up to date before they are read (lazy engine-order shadows)
 
     # ---- state dict ------------------------------------------------------------------------
     def state_dict(self, prefix: str = "") -> Dict[str, torch.Tensor]:
+        for h in self.flush_hooks:
+            h()
         out = {}
         for k, _, _ in self.spec:
             out[prefix + k] = (self.views[k] if k in self.views else self.bufs[k]).detach().clone()
@@ -209,6 +213,7 @@ class FlatGroup:
                 raise ValueError(f"shape mismatch for {name}: {tuple(src.shape)} vs {tuple(dst.shape)}")
             dst.copy_(src.to(device=self.device, dtype=dst.dtype))
         self.version += 1
+        self.buf_version += 1
 
     def load_recipe(self, rs: np.random.RandomState, perturb: bool = False):
         sd = {k: torch.from_numpy(v) for k, v in recipe_fill(self.spec, rs, perturb).items()}

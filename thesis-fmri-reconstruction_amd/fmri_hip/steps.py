@@ -352,6 +352,8 @@ class _GanStepBase:
                   if o is not None]
 
         def run():
+            for h in getattr(self, "_pre_replay", []):
+                h()
             replay()
             for g in groups:
                 g.version += 1
@@ -378,6 +380,8 @@ class Stage1Step(_GanStepBase):
         self.cfg = cfg
         self.enc = EncoderNet(cfg, device)
         self.dec = DecoderNet(cfg, device, self.enc.size)
+        self.dec.fc_bn.enable_lazy_running()
+        self._pre_replay = [self.dec.fc_bn._running_in]      # reloads after an outside write of the buffers only
         self.dis = DiscriminatorNet(cfg, device)
         self._init_common(device, hp, scales, distributed, sync_bn, (self.enc, self.dec, self.dis))
         self.mode = mode
@@ -654,6 +658,8 @@ class CognitiveStep(_GanStepBase):
         self.cfg, self.stage, self.n_voxels = cfg, stage, n_voxels
         self.cog = CognitiveEncoderNet(cfg, n_voxels, device)
         self.dec = DecoderNet(cfg, device, cfg.encoder_channels[2])
+        self.dec.fc_bn.enable_lazy_running()
+        self._pre_replay = [self.dec.fc_bn._running_in]      # reloads after an outside write of the buffers only
         self.dis = DiscriminatorNet(cfg, device)
         self.teacher_enc = EncoderNet(cfg, device) if stage == 2 else None
         nets = [self.cog, self.dec, self.dis] + ([self.teacher_enc] if stage == 2 else [])

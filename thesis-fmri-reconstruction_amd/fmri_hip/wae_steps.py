@@ -95,6 +95,8 @@ class WaeStep(_LatentDiscPhase):
         self.img_enc = EncoderNet(cfg, device)                       # Stage I: trained; II/III: Stage-I teacher
         self.cog = CognitiveEncoderNet(cfg, n_voxels, device) if stage > 1 else None
         self.dec = DecoderNet(cfg, device, self.img_enc.size)
+        self.dec.fc_bn.enable_lazy_running()
+        self._pre_replay = [self.dec.fc_bn._running_in]
         self.wd = WaeDiscriminatorNet(cfg, device)
         self.scal = torch.zeros(32, dtype=torch.float32, device=device)
         self.dd = _Dist(distributed, sync_bn)

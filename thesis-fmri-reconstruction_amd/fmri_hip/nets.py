@@ -26,12 +26,24 @@ _P = lib.ptr
 
 
 class FusedHeads:
-    """l_mu | l_var as one N = 2z GEMM (models/vae_gan.py:84-85,91-92): weights are concatenated into a
-    scratch fp32 matrix that is refreshed whenever the master parameters change."""
+    """l_mu | l_var as one N = 2z GEMM (models/vae_gan.py:84-85,91-92).  The group lays the two heads out side by side
+    (FlatGroup.heads_adjacent), so the concatenated weight / bias and their gradients are views of the flat buffers: no
+    copies, the weight gradient accumulates in place, the fp16 copies are part of the group's batched repack.  (Groups
+    with another layout fall back to concatenated scratch copies refreshed when the masters change.)"""
 
     def __init__(self, group: FlatGroup, k_in: int, z: int):
         self.group, self.z, self.k_in = group, z, k_in
         dev = group.device
+        self.direct = bool(getattr(group, "heads_adjacent", False))
+        if self.direct:
+            ow, ob = group.offsets["l_mu.weight"], group.offsets["l_mu.bias"]
+            assert group.offsets["l_var.weight"] == ow + z * k_in and group.offsets["l_var.bias"] == ob + z
+            self.wcat = group.data[ow:ow + 2 * z * k_in].view(2 * z, k_in)
+            self.gw = group.grad[ow:ow + 2 * z * k_in].view(2 * z, k_in)
+            self.bcat = group.data[ob:ob + 2 * z]
+            self.gb = group.grad[ob:ob + 2 * z]
+            self.dense = DenseLayer(group, (self.wcat, self.gw), (self.bcat, self.gb), k_in, 2 * z)
+            return
         self.wcat = torch.empty(2 * z, k_in, dtype=torch.float32, device=dev)
         self.bcat = torch.empty(2 * z, dtype=torch.float32, device=dev)
         self.gw = torch.zeros(2 * z, k_in, dtype=torch.float32, device=dev)
@@ -42,10 +54,14 @@ class FusedHeads:
     def refresh(self):
         """Bring the concatenated scratch weights and their fp16 GEMM copies up to date now (instead of lazily at the
         next forward)."""
+        if self.direct:
+            return                                   # views of the masters; packed with the group
         self._sync()
         repack_group(self._vg)
 
     def _sync(self):
+        if self.direct:
+            return
         if self._v != self.group.version:
             v = self.group.views
             z = self.z
@@ -61,6 +77,13 @@ class FusedHeads:
         return head32                                   # [B, 2z] fp32 (mu | logvar), bias added
 
     def backward(self, h16, dhead16, scale, need_dgrad=True):
+        if self.direct:
+            self.dense.wgrad(h16, dhead16, scale)        # side stream, accumulates into the flat gradient buffer
+            self.dense.bias_grad(dhead16, scale)
+            if need_dgrad:
+                dh, _ = self.dense.dgrad(dhead16)
+                return dh
+            return None
         self._sync()
         g = self.group.grads
         z = self.z

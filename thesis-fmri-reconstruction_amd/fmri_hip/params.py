@@ -161,8 +161,17 @@ class FlatGroup:
         self.device = torch.device(device)
         self.pkeys = [k for k, _, kind in spec if kind in ("w", "wn", "b", "gamma", "beta")]
         sizes = {k: int(np.prod(s)) if len(s) else 1 for k, s, _ in spec}
+        # Memory order = spec order, except that the two latent heads sit side by side (l_mu.weight | l_var.weight, then
+        # l_mu.bias | l_var.bias): the fused N = 2z head GEMM then works on VIEWS of the masters and their gradients
+        # (nets.FusedHeads) instead of concatenated copies.  Keys and state-dict order are untouched.
+        order = list(self.pkeys)
+        heads = ["l_mu.weight", "l_var.weight", "l_mu.bias", "l_var.bias"]
+        self.heads_adjacent = (all(h in sizes for h in heads) and sizes[heads[0]] == sizes[heads[1]]
+                               and sizes[heads[0]] % 4 == 0 and sizes[heads[2]] == sizes[heads[3]] and sizes[heads[2]] % 4 == 0)
+        if self.heads_adjacent:
+            order = [k for k in order if k not in heads] + heads
         self.offsets, off = {}, 0
-        for k in self.pkeys:
+        for k in order:
             self.offsets[k] = off
             off += (sizes[k] + 3) // 4 * 4          # keep every view 16-byte aligned
         self.numel = off

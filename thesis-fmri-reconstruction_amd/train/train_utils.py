@@ -4,8 +4,16 @@ Drop-in for the two metric modules of ``train/train_utils.py`` that the training
 per-epoch validation (``PearsonCorrelation`` :267-292, ``StructuralSimilarity`` :295-420): same class names,
 constructor and ``forward`` signatures, same values -- computed by HIP kernels (csrc/metrics.hip) on device
 tensors without a host round trip.  Everything else of that module (plots, image dumps, the ``evaluate`` loop)
-is outside the accelerated path.
+is outside the accelerated path and is FORWARDED: a name this module does not define (``evaluate``,
+``objective_assessment``, ``EarlyStopping`` ... -- e.g. ``from train.train_utils import evaluate`` at
+train/train_vgan_stage1.py:25, inference/inference_gan.py:24) is looked up in the ``train/train_utils.py`` this
+one shadows, i.e. the next one on the ``train`` package's search path (train/__init__.py extends it over
+``sys.path``).  That file is executed from where it lies on first use; nothing of it is copied here.
 """
+import importlib.util
+import os
+import sys
+
 import torch
 from torch import nn
 
@@ -58,3 +66,42 @@ class StructuralSimilarity(nn.Module):
         if full:
             return out[0], out[1]
         return out[0]
+
+
+_SHADOWED = None
+
+
+def _shadowed_module():
+    """The train/train_utils.py of the project this package overlays (loaded once, on first use)."""
+    global _SHADOWED
+    if _SHADOWED is None:
+        import train as _pkg
+        here = os.path.abspath(__file__)
+        for d in list(_pkg.__path__):
+            cand = os.path.join(d, "train_utils.py")
+            if os.path.isfile(cand) and os.path.abspath(cand) != here:
+                spec = importlib.util.spec_from_file_location("train._shadowed_train_utils", cand)
+                mod = importlib.util.module_from_spec(spec)
+                sys.modules[spec.name] = mod
+                try:
+                    spec.loader.exec_module(mod)
+                except BaseException:
+                    sys.modules.pop(spec.name, None)
+                    raise
+                _SHADOWED = mod
+                break
+        else:
+            _SHADOWED = False
+    return _SHADOWED
+
+
+def __getattr__(name):
+    if name.startswith("__"):
+        raise AttributeError(name)
+    mod = _shadowed_module()
+    if mod and hasattr(mod, name):
+        return getattr(mod, name)
+    raise AttributeError(
+        f"module 'train.train_utils' has no attribute {name!r}: the MI355X engine defines only PearsonCorrelation and "
+        f"StructuralSimilarity, and no other train/train_utils.py follows it on sys.path" if not mod else
+        f"module 'train.train_utils' has no attribute {name!r} (neither the engine's nor {mod.__file__})")

@@ -237,7 +237,10 @@ int fmri_wae_logloss(const float* logit, int ldl, int n, int one_minus, float w,
  *   dz32 [M][Z] fp32 = inv_scale * (delta1 . W0) (NULL: skip).  w4row = row 0 of the output layer's forward-orientation
  *   matrix; wd4[i] = layer i's packed weights in the data-gradient orientation ([rows_pad][kpd4[i]], row = input
  *   feature); wd4[0] is read only when dz32 is given.  Replaces the autograd data path of
- *   train/train_wae_stage1.py:278-303. */
+ *   train/train_wae_stage1.py:278-303.  Determinism: delta4 and dz32 are plain stores (bit-reproducible); the five
+ *   dbias5 vectors are accumulated with fp32 atomics across the 32-row blocks, so their last bits depend on the
+ *   arrival order of the blocks (run-to-run spread ~1e-7 relative; every other gradient of the engine is reduced in a
+ *   fixed order). */
 int fmri_mlp_fwd(const void* z16, int M, int Zp, int H, const void* const* w5, const int* kp5, const float* const* bias5,
                  void* const* hs4, float* logit, void* stream);
 int fmri_mlp_bwd(const void* dlogit16, int ldl, int M, int Zp, int Z, int H, const void* const* hs4, const void* w4row,

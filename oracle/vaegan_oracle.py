@@ -360,6 +360,37 @@ def cognitive_forward(P: State, fmri: Tensor, image: Tensor, noise: Tensor, cfg:
                 mus=mu, log_variances=logvar)
 
 
+def cognitive_forward_wae(P: State, fmri: Tensor, image: Tensor, z_p: Tensor, cfg: ArchCfg):
+    """VaeGanCognitive.forward (train, mode='wae'), models/vae_gan.py:379-395: no reparameterisation -- the decoder
+    takes the means; the teacher's image encoder (``teacher_net.encoder.``) runs in train mode too (its BatchNorm
+    statistics are batch statistics, its running statistics are updated).  Only random draw: z_p."""
+    mu, logvar = cognitive_encoder_fwd(P, "encoder.", fmri)
+    x_tilde = decoder_fwd(P, "decoder.", mu, cfg)
+    mu_t, _ = encoder_fwd(P, "teacher_net.encoder.", image, cfg)
+    gt_x = decoder_fwd(P, "decoder.", mu_t, cfg)
+    x_p = decoder_fwd(P, "decoder.", z_p, cfg)
+    disc_layer = discriminator_fwd(P, "discriminator.", gt_x, x_tilde, x_p, "REC", cfg)
+    disc_class = discriminator_fwd(P, "discriminator.", gt_x, x_tilde, x_p, "GAN", cfg)
+    return dict(gt_x=gt_x, x_tilde=x_tilde, disc_class=disc_class, disc_layer=disc_layer, mus=mu, log_variances=logvar)
+
+
+def wae_cognitive_eval(P: State, fmri: Tensor, cfg: ArchCfg):
+    """WaeGanCognitive.forward in eval mode (models/vae_gan.py:568-571): decoder(encoder(fmri).mu), running statistics."""
+    mu, _ = cognitive_encoder_fwd(P, "encoder.", fmri, train=False)
+    return decoder_fwd(P, "decoder.", mu, cfg, train=False)
+
+
+def dcgan_forward(P: State, x: Tensor, z_p: Tensor, cfg: ArchCfg, train: bool = True):
+    """DCGan.forward (models/vae_gan.py:602-622).  Train: the generated batch takes BOTH the 'predicted' and the
+    'sampled' slot of the discriminator; eval / sample=None: decoder(z_p)."""
+    if not train:
+        return dict(x_p=decoder_fwd(P, "decoder.", z_p, cfg, train=False))
+    x_tilde = decoder_fwd(P, "decoder.", z_p, cfg)
+    disc_layer = discriminator_fwd(P, "discriminator.", x, x_tilde, x_tilde, "REC", cfg)
+    disc_class = discriminator_fwd(P, "discriminator.", x, x_tilde, x_tilde, "GAN", cfg)
+    return dict(gt_x=x, x_tilde=x_tilde, disc_class=disc_class, disc_layer=disc_layer)
+
+
 # ----------------------------------------------------------------------------------------------
 # optimizers (functional restatement of torch.optim.RMSprop / Adam as the scripts configure them)
 # ----------------------------------------------------------------------------------------------

@@ -662,6 +662,52 @@ def case_eval(name, cfg, B, seed):
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
 
 
+def case_surface(name, cfg, B, V, seed):
+    """Forward fingerprints of the wrapper classes no training script of the reference drives through ``forward``
+    on the hot path: ``VaeGanCognitive(mode='wae')`` (models/vae_gan.py:379-387), ``WaeGanCognitive`` eval
+    (:564-571), ``DCGan`` train / eval (:602-622).  The only random draw of these paths is ``z_p = torch.randn`` on
+    the HOST (then ``.to(device)``), so the drop-in modules reproduce them under the same ``torch.manual_seed``."""
+    vg = load_reference(cfg)
+    data = O.synth_batch(B, cfg, n_voxels=V, seed=1234, steps=1)
+    x, fmri = data["x"], data["fmri"]
+    out = {"meta/case": np.array("surface"), "meta/B": B, "meta/V": V, "meta/seed": seed,
+           "meta/image_size": cfg.image_size, "meta/torch_seed": 21}
+    # --- VaeGanCognitive(mode='wae'), train mode, with the Stage-I teacher
+    model = build_cognitive(vg, cfg, V, seed, True, 2)
+    model.mode = "wae"
+    torch.manual_seed(21)
+    gt_x, x_tilde, disc_class, disc_layer, mus, lv = model({"fmri": fmri, "image": x})
+    pack(out, "cogwae", {k: O.tensor_summary(v.detach()) for k, v in dict(
+        gt_x=gt_x, x_tilde=x_tilde, disc_class=disc_class, disc_layer=disc_layer, mus=mus, log_variances=lv).items()})
+    keys, summ = summarize_state(model.state_dict())       # running statistics after the forward's BN updates
+    out["cogwae/state_keys"], out["cogwae/state_sum"] = np.array(keys), summ
+    # --- WaeGanCognitive: keys + eval forward = decoder(encoder(fmri).mu)
+    _, wmodel = build_wae_cognitive(vg, cfg, V, seed)
+    out["waecog/state_keys"] = np.array(list(wmodel.state_dict().keys()))
+    wmodel.eval()
+    with torch.no_grad():
+        xw = wmodel(fmri)
+    out["waecog/x_tilde"] = O.tensor_summary(xw)
+    assert all(not p.requires_grad for p in wmodel.decoder.parameters())        # the constructor freezes the decoder
+    # --- DCGan: train forward (4-tuple) and eval forward
+    teacher = vg.VaeGan(device="cpu", z_size=cfg.latent_dim)
+    teacher.load_state_dict(O.fill_state(O.vaegan_spec(cfg), seed, True))
+    dc = vg.DCGan(device="cpu", decoder=teacher.decoder, discriminator=teacher.discriminator, z_size=cfg.latent_dim)
+    out["dcgan/state_keys"] = np.array(list(dc.state_dict().keys()))
+    dc.train()
+    torch.manual_seed(22)
+    g, xt, dcl, dly = dc(x)
+    pack(out, "dcgan", {k: O.tensor_summary(v.detach()) for k, v in dict(gt_x=g, x_tilde=xt, disc_class=dcl,
+                                                                         disc_layer=dly).items()})
+    dc.eval()
+    torch.manual_seed(23)
+    with torch.no_grad():
+        out["dcgan/eval_x_p"] = O.tensor_summary(dc(x))
+        out["dcgan/gen5"] = O.tensor_summary(dc(None, 5))
+    print(name, float(x_tilde.norm()), float(xw.norm()), float(xt.norm()))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+
+
 def load_reference_data_loader():
     """Import the reference's ``data_preprocessing.data_loader`` (for its ``rand_shift`` and ``GreyToColor``).  Its
     top-level imports of packages that are not installed here and that those two never touch (nibabel, skimage) are
@@ -759,3 +805,5 @@ if __name__ == "__main__":
         case_eval("eval_b4", O.ArchCfg.px64(), B=4, seed=9)
     if want("ingest"):
         case_ingest("ingest")
+    if want("surface_b4"):
+        case_surface("surface_b4", O.ArchCfg.px64(), B=4, V=4096, seed=12)

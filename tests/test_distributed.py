@@ -400,7 +400,7 @@ def _worker_other(rank, world, port, kind, q):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["stage2", "stage3", "wae1", "wae2", "dual1"])
+@pytest.mark.parametrize("kind", ["stage2", "stage3", "wae1", "wae2", "wae3", "dual1"])
 def test_two_rank_other_steps_equal_single_process_global_batch(kind):
     """CognitiveStep (Stage II / III), WaeStep and DualStage1Step with distributed=True on two half batches (asynchronous
     per-sub-network gradient reductions, global-batch BatchNorm statistics, summed loss scalars) against the same step in

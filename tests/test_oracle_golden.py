@@ -235,3 +235,52 @@ def test_eval_forward_matches_reference(golden_dir):
         x_p = O.decoder_fwd(P, "decoder.", data["noise"][0, 1], cfg, train=False)
     for k, v in dict(mus=mus, log_variances=lv, x_tilde=x_tilde, x_p=x_p).items():
         _check_summ(g[f"fw/{k}"], O.tensor_summary(v), f"eval fw {k}")
+
+
+def surface_states(cfg, V, seed):
+    """Recipe weights of the three wrappers of tests/golden/make_golden.py::case_surface (oracle key layout)."""
+    tsd = O.fill_state(O.vaegan_spec(cfg), seed, True)
+    csd = O.fill_state(O.cognitive_encoder_spec(cfg, V), seed + 100, True)
+    cog = dict(csd)
+    cog.update({k: v for k, v in tsd.items() if k.startswith(("decoder.", "discriminator."))})
+    for k, v in tsd.items():
+        cog["teacher_net." + k] = cog[k] if k.startswith(("decoder.", "discriminator.")) else v
+    wsd = O.fill_state(O.encoder_spec(cfg) + O.decoder_spec(cfg) + O.wae_discriminator_spec(cfg), seed, True)
+    wae = dict(csd)
+    wae.update({k: v for k, v in wsd.items() if k.startswith("decoder.")})
+    wae.update(O.fill_state(O.wae_discriminator_spec(cfg), seed + 200, True))
+    dcg = {k: v.clone() for k, v in tsd.items() if k.startswith(("decoder.", "discriminator."))}
+    return cog, wae, dcg
+
+
+def test_wrapper_forwards_match_reference(golden_dir):
+    """VaeGanCognitive(mode='wae') train forward, WaeGanCognitive eval forward, DCGan train / eval forward
+    (models/vae_gan.py:379-387, :564-571, :602-622) against the reference's own outputs."""
+    cfg = O.ArchCfg.px64()
+    g = _load(golden_dir, "surface_b4")
+    B, V, seed = int(g["meta/B"]), int(g["meta/V"]), int(g["meta/seed"])
+    data = O.synth_batch(B, cfg, n_voxels=V, seed=1234, steps=1)
+    cog, wae, dcg = surface_states(cfg, V, seed)
+    torch.manual_seed(int(g["meta/torch_seed"]))
+    fw = O.cognitive_forward_wae(cog, data["fmri"], data["x"], torch.randn(B, cfg.latent_dim), cfg)
+    for k, v in fw.items():
+        _check_summ(g[f"cogwae/{k}"], O.tensor_summary(v), f"cogwae {k}")
+    keys = [str(k) for k in g["cogwae/state_keys"]]
+    for i, k in enumerate(keys):
+        _check_summ(g["cogwae/state_sum"][i], O.tensor_summary(cog[k].float()), f"cogwae state {k}")
+    _check_summ(g["waecog/x_tilde"], O.tensor_summary(O.wae_cognitive_eval(wae, data["fmri"], cfg)), "waecog eval")
+    spec_keys = lambda spec: [k for k, _, _ in spec]
+    assert [str(k) for k in g["waecog/state_keys"]] == spec_keys(O.cognitive_encoder_spec(cfg, V)) + \
+        spec_keys(O.wae_discriminator_spec(cfg)) + spec_keys(O.decoder_spec(cfg))
+    assert [str(k) for k in g["dcgan/state_keys"]] == spec_keys(O.decoder_spec(cfg)) + spec_keys(O.discriminator_spec(cfg))
+    torch.manual_seed(22)
+    fw = O.dcgan_forward(dcg, data["x"], torch.randn(B, cfg.latent_dim), cfg)
+    for k, v in fw.items():
+        _check_summ(g[f"dcgan/{k}"], O.tensor_summary(v), f"dcgan {k}")
+    torch.manual_seed(23)
+    _check_summ(g["dcgan/eval_x_p"],
+                O.tensor_summary(O.dcgan_forward(dcg, None, torch.randn(B, cfg.latent_dim), cfg, train=False)["x_p"]),
+                "dcgan eval")
+    _check_summ(g["dcgan/gen5"],
+                O.tensor_summary(O.dcgan_forward(dcg, None, torch.randn(5, cfg.latent_dim), cfg, train=False)["x_p"]),
+                "dcgan gen")

@@ -346,12 +346,7 @@ int fmri_igemm_ep(const void* in, const void* w, void* out, const float* bias, c
         }
         if (!q.st.part) q.bb.x = nullptr;       // no statistics rows: plain output (*ep_done = 0 tells the caller)
         if (ok && q.ntiles > 0) {
-            // FMRI_TC5B=on: the 8-wave two-tile form (csrc/igemm_tc5b.hip) where it applies
-            static const char* tc5b_env = getenv("FMRI_TC5B");
-            static const bool use_tc5b = tc5b_env && !strcmp(tc5b_env, "on");
-            int r = E_UNSUPPORTED;
-            if (use_tc5b) r = igemm_tc5b_launch(q, bn_tile, copad, S(stream));
-            if (r == E_UNSUPPORTED) r = igemm_tc5_launch(q, bn_tile, copad, S(stream));
+            const int r = igemm_tc5_launch(q, bn_tile, copad, S(stream));
             if (r == OK && ep_done && q.st.part) *ep_done = q.st.tpg[0];
             if (r != E_UNSUPPORTED) return r;
         }

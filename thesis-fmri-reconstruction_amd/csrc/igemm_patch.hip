@@ -278,11 +278,8 @@ __global__ __launch_bounds__(512) void igemm_patch_kernel(const PatchArgs a) {
 template <int BN, int WM, int WN>
 static int launch_patch(const PatchArgs& a, int max_tiles, int copad, int lds, hipStream_t st) {
     auto kern = igemm_patch_kernel<BN, WM, WN>;
-    static bool attr_done = false;     // raising the dynamic-LDS limit is idempotent; racing threads are harmless
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
+    // raising the dynamic-LDS limit is idempotent; every call sets it (no library-global state)
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return E_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(max_tiles, copad / BN, a.ncls), dim3(512), lds, st, a);
     return hipGetLastError() == hipSuccess ? OK : E_LAUNCH;
 }

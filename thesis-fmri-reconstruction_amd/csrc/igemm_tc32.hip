@@ -192,11 +192,8 @@ __global__ __launch_bounds__(512) void igemm_tc32_kernel(const Tc32Args a) {
 }
 
 int igemm_tc32_launch(const Tc32Args& a, int nblocks, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)igemm_tc32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TC32_LDS);
-        attr_done = true;
-    }
+    // raising the dynamic-LDS limit is idempotent; every call sets it (no library-global state)
+    if (hipFuncSetAttribute((const void*)igemm_tc32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TC32_LDS) != hipSuccess) return E_LAUNCH;
     hipLaunchKernelGGL(igemm_tc32_kernel, dim3(nblocks), dim3(512), TC32_LDS, st, a);
     return hipGetLastError() == hipSuccess ? OK : E_LAUNCH;
 }

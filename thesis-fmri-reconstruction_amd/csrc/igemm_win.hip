@@ -268,11 +268,8 @@ __global__ __launch_bounds__(256, 2) void igemm_win_kernel(const WinArgs a) {
 template <int BN, int WM, int WN>
 static int launch_win(const WinArgs& a, int max_tiles, int copad, int lds, hipStream_t st) {
     auto kern = igemm_win_kernel<BN, WM, WN>;
-    static bool attr_done = false;     // raising the dynamic-LDS limit is idempotent; racing threads are harmless
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        attr_done = true;
-    }
+    // raising the dynamic-LDS limit is idempotent; every call sets it (no library-global state)
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) return E_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(max_tiles, copad / BN, a.ncls), dim3(256), lds, st, a);
     return hipGetLastError() == hipSuccess ? OK : E_LAUNCH;
 }

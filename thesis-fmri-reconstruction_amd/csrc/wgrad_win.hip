@@ -238,12 +238,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_win_kernel(const WgradWinArgs a)
 int wgrad_win_launch(const WgradWinArgs& a, int apad, hipStream_t st) {
     dim3 grid((a.Bc / 32) * a.a_tiles * 4 * a.splits);
     const int lds = 3 * (64 * 256 + 7 * 1024);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)wgrad_win_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute((const void*)wgrad_win_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_done = true;
-    }
+    // raising the dynamic-LDS limit is idempotent; every call sets it (no library-global state)
+    if (hipFuncSetAttribute((const void*)wgrad_win_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return E_LAUNCH;
+    if (hipFuncSetAttribute((const void*)wgrad_win_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return E_LAUNCH;
     if (a.slab_stride != 0) hipLaunchKernelGGL(wgrad_win_kernel<true>, grid, dim3(256), lds, st, a);
     else hipLaunchKernelGGL(wgrad_win_kernel<false>, grid, dim3(256), lds, st, a);
     return hipGetLastError() == hipSuccess ? OK : E_LAUNCH;

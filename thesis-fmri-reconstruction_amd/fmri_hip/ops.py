@@ -520,6 +520,9 @@ class ConvLayer:
         N, Hi, Wi, _ = x.shape
         _, Ho, Wo, _ = dy.shape
         if self.kind == "conv" and self.stride == 1 and self.cinp > self.coutp:
+            if bias_too:
+                raise NotImplementedError("ConvLayer.wgrad(bias_too=True) on the role-exchanged branch (cin > cout): "
+                                          "reduce the bias gradient with act_backward(colsum=...) as DecoderNet does")
             # exchange the roles (dW[co][ci][k] = sum_m' X[m'][ci] * dY[m' + pad - k][co]) so that the gathered
             # operand is the narrow one: rows ci, columns (tap, co)
             packed, ldo = run_wgrad(x, dy, N, Hi, Wi, self.cinp, Ho, Wo, self.coutp, self.k, 1, self.pad, flip=1)

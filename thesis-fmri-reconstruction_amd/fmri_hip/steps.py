@@ -297,8 +297,9 @@ class _GanStepBase:
         Every launch of a step is enqueue-only and nothing inside a step synchronises with the host (the equilibrium
         gate, the stream normalisation and the optimizer gating all live on the device), so the ~370 launches of a
         step can be replayed as one graph: the step time then no longer depends on how fast the host can issue them.
-        Inputs are read from ``static_inputs`` at every replay -- copy each new batch into those tensors.  RMSprop
-        steps only (Adam's bias correction is a host-side scalar per step).  In a data-parallel run the collectives
+        Inputs are read from ``static_inputs`` at every replay -- copy each new batch into those tensors.  Learning
+        rates, lambda, margin, equilibrium and beta are device-resident (``set_lr`` / ``set_hyper``): a replayed step follows
+        their schedules (Adam's step count of the WAE steps lives on the device too, ``wae_steps``).  In a data-parallel run the collectives
         are kept out of the graphs (see _SegmentRecorder)."""
         # The weight-gradient side stream (ops.side_run) is switched off while recording: a replayed HIP graph runs
         # its parallel branches no faster than a chain (measured 8.8 ms chained, 9.0-9.5 ms with the fork/join
@@ -483,9 +484,13 @@ class Stage1Step(_GanStepBase):
         if early:
             ops.side_run(dev, lambda: self._apply_one(self.opt_dec, self.dec, self.flags[1:2], S_GDEC))
         dhead32 = torch.empty(B, 2 * Z, dtype=torch.float32, device=dev)
-        # KL weight: 1, or beta / batch for 'beta-vae' (train_vgan_stage1.py:360-362)
-        klw = hp.beta / float(B * self.dd.world) if self.mode == "beta-vae" else 1.0
-        lib.call("fmri_latent_bwd", _P(fw["head32"]), _P(fw["eps"]), _P(dz), Z, 1.0, klw, _P(self._slot(S_NB)), B, Z,
+        # KL weight: 1, or beta / batch for 'beta-vae' (train_vgan_stage1.py:360-362).  The gate kernel writes it to
+        # the device slot S_KLW from the device-resident hyper-parameters, so that a recorded (HIP-graph) step follows
+        # set_hyper(beta=...) in the encoder GRADIENT as well as in the logged loss: weight = S_KLW * nB on the device
+        kl_dev = self._slot(S_NB)
+        if self.mode == "beta-vae":
+            kl_dev = torch.mul(self._slot(S_KLW), self._slot(S_NB))
+        lib.call("fmri_latent_bwd", _P(fw["head32"]), _P(fw["eps"]), _P(dz), Z, 1.0, 1.0, _P(kl_dev), B, Z,
                  1.0, None, _P(dhead32), 1)                              # = nB * dhead_true
         if extra_dmu is not None:
             dhead32[:, :Z].addcmul_(extra_dmu, self._slot(S_NB))            # carried at the same device factor nB

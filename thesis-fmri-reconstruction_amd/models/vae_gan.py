@@ -262,9 +262,11 @@ class _Block(_EngineBacked):
     Decoder / Discriminator), whose autograd bridges cover whole sub-networks."""
 
     def _forward(self, ten):
-        if torch.is_grad_enabled() and (ten.requires_grad or any(p.requires_grad for p in self.parameters())):
-            # forward values are exact; make it explicit that no graph is recorded
-            ten = ten.detach()
+        if torch.is_grad_enabled() and ten.requires_grad:
+            # a caller differentiating THROUGH a lone block would silently get no gradient: refuse instead
+            raise RuntimeError(f"{type(self).__name__} called on its own is forward-only on the HIP engine (no autograd "
+                               "graph is recorded); differentiate through Encoder / Decoder / Discriminator, or wrap "
+                               "the call in torch.no_grad() / detach the input")
         act, raw = self._engine().forward(ten)
         self._engine_params_changed()
         return act, raw

@@ -5,12 +5,28 @@
 set -e
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/$1; shift
-mkdir -p $OUT
+mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-B="$R/bench.py --steps 3 --warmup 2 --eager --serial --no-cpu-baseline --no-hbm-rows $@"
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma -o x -- python3 $B > $OUT/mfma.json 2> $OUT/mfma.err
-python3 $R/tools/pmc_mfma.py $(find $OUT/mfma -name "*counter_collection.csv" | head -1) > $OUT/pmc_mfma.json
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o x -- python3 $B > $OUT/fetch.json 2> $OUT/fetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o x -- python3 $B > $OUT/write.json 2> $OUT/write.err
-python3 $R/tools/pmc_traffic.py $(find $OUT/fetch -name "*counter_collection.csv" | head -1) $(find $OUT/write -name "*counter_collection.csv" | head -1) > $OUT/pmc_traffic.json
-rm -rf $OUT/mfma $OUT/fetch $OUT/write
+B=("$R/bench.py" --steps 3 --warmup 2 --eager --serial --no-cpu-baseline --no-hbm-rows "$@")
+
+# one counter pass: <name> <counters...>; prints the path of its counter CSV, or fails with the run's stderr
+pass() {
+    local name=$1; shift
+    rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$OUT/$name" -o x -- python3 "${B[@]}" \
+        > "$OUT/$name.json" 2> "$OUT/$name.err" || { echo "pass $name failed:" >&2; tail -20 "$OUT/$name.err" >&2; return 1; }
+    local csv
+    csv=$(find "$OUT/$name" -name "*counter_collection.csv" | head -1)
+    if [ -z "$csv" ]; then
+        echo "pass $name wrote no counter CSV:" >&2; tail -20 "$OUT/$name.err" >&2
+        rm -rf "$OUT/$name"
+        return 1
+    fi
+    echo "$csv"
+}
+
+mfma=$(pass mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE)
+python3 "$R/tools/pmc_mfma.py" "$mfma" > "$OUT/pmc_mfma.json"
+fetch=$(pass fetch FETCH_SIZE)
+write=$(pass write WRITE_SIZE)
+python3 "$R/tools/pmc_traffic.py" "$fetch" "$write" > "$OUT/pmc_traffic.json"
+rm -rf "$OUT/mfma" "$OUT/fetch" "$OUT/write"

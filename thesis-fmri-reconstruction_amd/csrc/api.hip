@@ -378,9 +378,9 @@ int fmri_igemm_ep(const void* in, const void* w, void* out, const float* bias, c
         const int begin = q.ntiles < 256 ? q.ntiles : 256;                          // one persistent block per CU
         q.relu_y = (ep && ep->act_y) ? (const half_t*)ep->act_y : nullptr;
         if (ok) {
-            const int r = igemm_tc32_launch(q, begin, S(stream));
+            const int r = igemm_tc32_launch(q, begin, S(stream));       // E_UNSUPPORTED: bias / activation epilogue
             if (r == OK && ep_done && q.relu_y) *ep_done |= FMRI_EP_ACT_APPLIED;
-            return r;
+            if (r != E_UNSUPPORTED) return r;
         }
     }
     // unit-stride sampling, Ci % 64 == 0 -> window-resident kernel (csrc/igemm_win.hip); FMRI_WIN=off disables

@@ -143,10 +143,33 @@ def check(code, what=""):
         raise RuntimeError(f"fmri_hip: {what} failed: {msg} ({code})")
 
 
+# bench.py sets PROFILE to a list: every entry-point call is then bracketed by HIP events on the stream it is launched
+# on and recorded as (entry point, note, start event, end event).  ``note(...)`` attaches what the caller knows about the
+# NEXT call -- the kernel the library routes the geometry to, its algorithmic FLOPs and bytes -- so that bench.py can
+# group launches into kernel families and price them against their rooflines.
+PROFILE = None
+_NOTE = None
+
+
+def note(**kw):
+    global _NOTE
+    if PROFILE is not None:
+        _NOTE = kw
+
+
 def call(name, *args):
     """Invoke an entry point on torch's current stream and raise on error."""
+    global _NOTE
     lib = load()
-    code = getattr(lib, name)(*args, stream())
+    if PROFILE is None:
+        code = getattr(lib, name)(*args, stream())
+    else:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        code = getattr(lib, name)(*args, stream())
+        e1.record()
+        PROFILE.append((name, _NOTE, e0, e1))
+        _NOTE = None
     if code != 0:
         check(code, name)
 

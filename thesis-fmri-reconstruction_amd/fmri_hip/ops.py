@@ -178,11 +178,6 @@ def _choose_splits(blocks: int, ksteps: int) -> int:
     return (ksteps + per - 1) // per
 
 
-# bench.py sets PROFILE to a list: every fmri_igemm launch is then bracketed by HIP events on the launch stream and
-# recorded as (kernel label, start, end, algorithmic flops); bench.py reports the label with the largest total time.
-PROFILE = None
-
-
 def igemm_kernel_label(N, Hi, Wi, Ci, Ho, Wo, CoStore, Co, k, stride, pad, mode, out_f32, splits, tile,
                        bias_none=True, act=0) -> str:
     """Name of the kernel instantiation csrc/api.hip::fmri_igemm routes this geometry to (mirrors its rules)."""
@@ -231,10 +226,12 @@ def run_igemm(x, pw: PackedWeight, out, bias, N, Hi, Wi, Ci, Ho, Wo, CoStore, Co
     sum g*xhat rows).  Returns the number of rows written per group (0: the kernel behind this geometry has no such
     epilogue -- the output is then the plain contraction)."""
     w = pw.get()
-    prof = PROFILE is not None and flops > 0.0
-    if prof:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+    if lib.PROFILE is not None:
+        # algorithmic bytes: the input once, the output once, the weights once
+        lib.note(kernel=igemm_kernel_label(N, Hi, Wi, Ci, Ho, Wo, CoStore, Co, k, stride, pad, mode, out_f32, splits, tile,
+                                           bias is None, act),
+                 flops=flops, bytes=2.0 * N * Hi * Wi * Ci + (4.0 if out_f32 else 2.0) * N * Ho * Wo * CoStore * splits
+                 + 2.0 * w.numel())
     ep, done = None, ctypes.c_int(0)
     if stats is None and act_y is not None:
         # ReLU backward of the layer below in the epilogue (fmri_epilogue.act_y); bit EP_ACT_APPLIED of the result
@@ -252,11 +249,6 @@ def run_igemm(x, pw: PackedWeight, out, bias, N, Hi, Wi, Ci, Ho, Wo, CoStore, Co
     lib.call("fmri_igemm_ep", _P(x), _P(w), _P(out), _P(bias), _P(zero_page(x.device)), N, Hi, Wi, Ci, Ho, Wo,
              CoStore, Co, k, stride, pad, mode, act, 1 if out_f32 else 0, splits, slab_stride, tile, w.numel(), ep,
              ctypes.byref(done))
-    if prof:
-        e1.record()
-        PROFILE.append((igemm_kernel_label(N, Hi, Wi, Ci, Ho, Wo, CoStore, Co, k, stride, pad, mode, out_f32, splits,
-                                           tile, bias is None, act),
-                        e0, e1, flops))
     return int(done.value)
 
 
@@ -332,11 +324,18 @@ def join_side(device=None):
     _SIDE["pending"].clear()
 
 
-def run_wgrad(P, Q, N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad, flip=0):
-    """Returns the packed fp32 gradient [apad][ldo]."""
+def run_wgrad(P, Q, N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad, flip=0, flops=0.0):
+    """Returns the packed fp32 gradient [apad][ldo].  ``flops``: algorithmic FLOPs of the layer's weight gradient (for
+    the profiling hook of lib.call; 0 = 2 * rows * A * Bc * k^2 of the padded operands)."""
     ba = tile_for(A)
     apad = ceil_to(A, ba)
     ldo = ceil_to(k * k * Bc, 128)
+    if lib.PROFILE is not None:
+        fl = flops or 2.0 * N * Yc * Xc * A * Bc * k * k
+        nb = 2.0 * N * Yc * Xc * A + 2.0 * N * Hq * Wq * Bc + 4.0 * apad * ldo
+        note = lambda kern: lib.note(kernel=kern, flops=fl, bytes=nb)
+    else:
+        note = lambda kern: None
     if stride == 2 and not flip and ba == 128 and Bc % 32 == 0 and Yc * Xc > 1 and k == 5 and pad == 2 and _WW_ON:
         # window-resident kernel (csrc/wgrad_win.hip): blocks = 32-channel column blocks x 128-row blocks x 4 parity
         # planes x splits over the 8x8 pixel tiles; every split stores its own slab, unpack_grad sums them
@@ -349,6 +348,7 @@ def run_wgrad(P, Q, N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad, flip=0):
             out = torch.empty(nslabs, apad, ldo, dtype=torch.float32, device=P.device)
         else:
             out = torch.zeros(apad, ldo, dtype=torch.float32, device=P.device)
+        note("fmri::wgrad_win_kernel")
         lib.call("fmri_wgrad", _P(P), _P(Q), _P(out), _P(zero_page(P.device)), N, Yc, Xc, A, Hq, Wq, Bc, k, stride,
                  pad, flip, apad, ba, ldo, splits, 2 if slabs else 1)
         return out, ldo
@@ -359,6 +359,7 @@ def run_wgrad(P, Q, N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad, flip=0):
         # layer, a loss on the B-image decoder layer
         nslabs = 1
         out = torch.zeros(nslabs, apad, ldo, dtype=torch.float32, device=P.device)
+        note("fmri::wgrad_narrow_kernel")
         lib.call("fmri_wgrad", _P(P), _P(Q), _P(out), _P(zero_page(P.device)), N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad,
                  flip, apad, ba, ldo, nslabs, 3)
         out._fmri_colsum = True            # column 200 of every slab row a holds sum_m P[m][a]
@@ -373,6 +374,7 @@ def run_wgrad(P, Q, N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad, flip=0):
         out = torch.zeros(apad, ldo, dtype=torch.float32, device=P.device)
     else:
         out = torch.empty(apad, ldo, dtype=torch.float32, device=P.device)
+    note("fmri::wgrad_kernel")
     lib.call("fmri_wgrad", _P(P), _P(Q), _P(out), _P(zero_page(P.device)), N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad,
              flip, apad, ba, ldo, splits, 1 if splits > 1 else 0)
     return out, ldo
@@ -525,16 +527,19 @@ class ConvLayer:
                                           "reduce the bias gradient with act_backward(colsum=...) as DecoderNet does")
             # exchange the roles (dW[co][ci][k] = sum_m' X[m'][ci] * dY[m' + pad - k][co]) so that the gathered
             # operand is the narrow one: rows ci, columns (tap, co)
-            packed, ldo = run_wgrad(x, dy, N, Hi, Wi, self.cinp, Ho, Wo, self.coutp, self.k, 1, self.pad, flip=1)
+            packed, ldo = run_wgrad(x, dy, N, Hi, Wi, self.cinp, Ho, Wo, self.coutp, self.k, 1, self.pad, flip=1,
+                                    flops=self._flops(N, Hi, Wi, Ho, Wo))
             kk = self.k * self.k
             spec = PackSpec(sa=kk, sta=0, A=self.cin, TA=1, sb=self.cin * kk, stb=1, B=self.cout, KW=self.k,
                             TH=self.k, TW=self.k)
             unpack_grad(packed, self.wg, spec, ldo, 1.0 / scale)
             return
         if self.kind == "conv":
-            packed, ldo = run_wgrad(dy, x, N, Ho, Wo, self.coutp, Hi, Wi, self.cinp, self.k, self.stride, self.pad)
+            packed, ldo = run_wgrad(dy, x, N, Ho, Wo, self.coutp, Hi, Wi, self.cinp, self.k, self.stride, self.pad,
+                                    flops=self._flops(N, Hi, Wi, Ho, Wo))
         else:
-            packed, ldo = run_wgrad(x, dy, N, Hi, Wi, self.cinp, Ho, Wo, self.coutp, self.k, 2, self.pad)
+            packed, ldo = run_wgrad(x, dy, N, Hi, Wi, self.cinp, Ho, Wo, self.coutp, self.k, 2, self.pad,
+                                    flops=self._flops(N, Hi, Wi, Ho, Wo))
         unpack_grad(packed, self.wg, self.gspec, ldo, 1.0 / scale)
         if bias_too:
             # bias.grad += (1/scale) * sum over pixels of dy: the narrow kernel's spare column, else a reduction
@@ -626,7 +631,7 @@ class DenseLayer:
 
     def _wgrad(self, x: torch.Tensor, dy: torch.Tensor, scale: float):
         M = x.shape[0]
-        packed, ldo = run_wgrad(dy, x, M, 1, 1, self.np_, 1, 1, self.kp, 1, 1, 0)
+        packed, ldo = run_wgrad(dy, x, M, 1, 1, self.np_, 1, 1, self.kp, 1, 1, 0, flops=2.0 * M * self.k_in * self.n_out)
         unpack_grad(packed, self.wg, self.gspec, ldo, 1.0 / scale)
 
     def bias_grad(self, dy: torch.Tensor, scale: float):
@@ -749,8 +754,10 @@ class BatchNorm:
                 lib.call("fmri_bn_finalize", _P(sums), C, count, *fin)
         elif self.reducer is None:
             # no statistics exchange: the fold of the partial sums finalizes (one launch less on the critical path)
+            lib.note(bytes=2.0 * M * C)
             lib.call("fmri_bn_stats_finalize", _P(x2), M, C, _P(sums), _P(ws), ws.numel(), count, *fin)
         else:
+            lib.note(bytes=2.0 * M * C)
             lib.call("fmri_bn_stats", _P(x2), M, C, _P(sums), _P(ws), ws.numel())
             count *= self.reducer(sums)
             lib.call("fmri_bn_finalize", _P(sums), C, count, *fin)
@@ -759,6 +766,7 @@ class BatchNorm:
             self._running_out()
         if out is None:
             out = torch.empty_like(raw)
+        lib.note(bytes=4.0 * M * C)
         lib.call("fmri_bn_apply", _P(x2), _P(out), M, C, _P(sv.scale), _P(sv.shift), 1 if relu else 0)
         return out, sv
 
@@ -808,6 +816,7 @@ class BatchNorm:
             self._fold_bwd(stat, stat_group, 1, sums, param_scale, 0)
         else:
             ws = _reduce_ws(M, C, raw.device)
+            lib.note(bytes=4.0 * M * C)
             lib.call("fmri_bn_bwd_reduce", _P(x2), _P(g2), M, C, _P(sv.mean), _P(sv.rstd), _P(gamma), _P(beta),
                      1 if relu else 0, _P(sums), _P(ws), ws.numel(), _P(self.gbeta) if direct else None,
                      _P(self.ggamma) if direct else None, (1.0 / param_scale) if direct else 0.0)
@@ -817,6 +826,7 @@ class BatchNorm:
             self.reducer(sums)
         if out is None:
             out = torch.empty_like(dy)
+        lib.note(bytes=6.0 * M * C)
         lib.call("fmri_bn_bwd_apply", _P(x2), _P(g2), _P(out), M, C, sv.count, _P(sv.mean), _P(sv.rstd), _P(gamma),
                  _P(beta), 1 if relu else 0, _P(sums))
         return out, sums
@@ -841,6 +851,7 @@ class BatchNorm:
             self._fold_bwd(stat, stat_group, 2, sums, param_scale, int(param_stream))
         else:
             ws = torch.empty(2 * lib.load().fmri_bn_ws_floats(M, C), dtype=torch.float32, device=raw.device)
+            lib.note(bytes=6.0 * M * C)
             lib.call("fmri_bn_bwd_reduce2", _P(x2), _P(g2), M, C, _P(sv.mean), _P(sv.rstd), _P(gamma), _P(beta),
                      1 if relu else 0, _P(sums), _P(ws), ws.numel(), _P(self.gbeta) if pg else None,
                      _P(self.ggamma) if pg else None, (1.0 / param_scale) if pg else 0.0, int(param_stream))
@@ -850,6 +861,7 @@ class BatchNorm:
             self.reducer(sums)
         if out is None:
             out = torch.empty_like(dy2)
+        lib.note(bytes=10.0 * M * C)
         lib.call("fmri_bn_bwd_apply2", _P(x2), _P(g2), _P(out), M, C, sv.count, _P(sv.mean), _P(sv.rstd), _P(gamma),
                  _P(beta), 1 if relu else 0, _P(sums))
         return out, sums
@@ -908,6 +920,7 @@ def act_backward(y: torch.Tensor, dy: torch.Tensor, act: int, colsum: Optional[t
     M = y.numel() // C
     if out is None:
         out = torch.empty_like(dy)
+    lib.note(bytes=6.0 * M * C)
     if colsum is not None:
         assert colsum.numel() >= 2 * C
         ws = _reduce_ws(M, C, y.device)

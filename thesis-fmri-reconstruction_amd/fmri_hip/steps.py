@@ -90,12 +90,14 @@ class _Optim:
     def step(self, flag: Optional[torch.Tensor] = None, clamp: float = 0.0, gdev: Optional[torch.Tensor] = None):
         g = self.g
         if self.kind == "rmsprop":
+            lib.note(bytes=20.0 * g.numel)       # read p, g, v; write p, v
             lib.call("fmri_rmsprop_dev", _P(g.data), _P(g.grad), _P(self.s1), g.numel, _P(self.lr_dev), self.alpha,
                      self.eps, 1.0, _P(gdev), clamp, _P(flag))
         else:
             self.t += 1
             b1, b2 = self.betas
             lib.call("fmri_counter_inc", _P(self.t_dev))
+            lib.note(bytes=28.0 * g.numel)       # read p, g, m, v; write p, m, v
             lib.call("fmri_adam_dev", _P(g.data), _P(g.grad), _P(self.s1), _P(self.s2), g.numel, _P(self.lr_dev), b1, b2,
                      self.eps, _P(self.t_dev), 1.0, _P(gdev), clamp, _P(flag))
         g.version += 1

@@ -70,8 +70,17 @@ __global__ __launch_bounds__(256, 2) void igemm_narrow_kernel(const NarrowArgs a
     }
 
     const int tiles_x = a.tiles_x, tpi = a.tiles_y * a.tiles_x;
+    // Round 3: window loads and output stores go through buffer descriptors (out-of-image pixels / outside lanes carry the
+    // out-of-range offset 0x80000000: the load returns zeros, the store is dropped), so the tile loop has no exec-mask
+    // branches around memory instructions -- with them the compiler drained the whole VMEM queue (`s_waitcnt vmcnt(0)`)
+    // in front of the stash, i.e. waited for the tile's just-issued stores every iteration.  The stash now also sits in
+    // FRONT of the stores, and the activation is one wave-uniform switch per tile instead of one per fragment.
+    const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.in, 0, (int)((uint32_t)a.N * (uint32_t)a.H * (uint32_t)a.W * (uint32_t)(CI * 2)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_out = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.out, 0, (int)((uint32_t)a.N * (uint32_t)a.H * (uint32_t)a.W * (uint32_t)(a.CoStore * 2)), 0x00020000);
     h8 stg[NU];
-    auto fetch = [&](int t) {
+    auto fetch = [&](int t) __attribute__((always_inline)) {
         const int n = t / tpi;
         const int r = t - n * tpi;
         const int tyi = r / tiles_x, txi = r - tyi * tiles_x;
@@ -81,11 +90,12 @@ __global__ __launch_bounds__(256, 2) void igemm_narrow_kernel(const NarrowArgs a
             const int j = upix[e] / WW, i = upix[e] - j * WW;
             const int iy = y0 + j, ix = x0 + i;
             const bool ok = upix[e] < NPIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            const half_t* src = a.in + ((int64_t)(n * a.H + iy) * a.W + ix) * CI + ((e * 256 + tid) % UPP) * 8;
-            stg[e] = ok ? *(const h8*)src : (h8)(half_t)0.f;
+            const uint32_t off = ok ? (uint32_t)((((n * a.H + iy) * a.W + ix) * CI + ((e * 256 + tid) % UPP) * 8) * 2)
+                                    : 0x80000000u;
+            stg[e] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, (int)off, 0, 0));
         }
     };
-    auto stash = [&](int buf) {
+    auto stash = [&](int buf) __attribute__((always_inline)) {
         char* dst = smem + buf * WBYTES;
 #pragma unroll
         for (int e = 0; e < NU; ++e)
@@ -98,8 +108,9 @@ __global__ __launch_bounds__(256, 2) void igemm_narrow_kernel(const NarrowArgs a
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
             const int co = tn * 16 + fq * 4 + rg;
-            bv[tn][rg] = (a.bias && co < a.Co) ? a.bias[co] : 0.f;
+            bv[tn][rg] = (a.bias && co < a.Co) ? a.bias[co] : 0.f;        // zeros without a bias: added unconditionally
         }
+    typedef uint32_t u2v __attribute__((ext_vector_type(2)));
 
     int t = blockIdx.x;
     if (t >= a.ntiles) return;
@@ -107,6 +118,7 @@ __global__ __launch_bounds__(256, 2) void igemm_narrow_kernel(const NarrowArgs a
     stash(0);
     __syncthreads();
     int cur = 0;
+#pragma unroll 1
     for (; t < a.ntiles; t += gridDim.x) {
         const int tn_ = t + gridDim.x;
         const bool more = tn_ < a.ntiles;
@@ -138,8 +150,44 @@ __global__ __launch_bounds__(256, 2) void igemm_narrow_kernel(const NarrowArgs a
                 for (int tn = 0; tn < TN; ++tn)
                     acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][tn], af[tm], acc[tn][tm], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        // next tile's window -> the other LDS buffer (nobody reads it: its tile finished before the last barrier); in
+        // front of this tile's stores, so that the wait for the window loads does not cover them
+        if (more) stash(cur ^ 1);
 
         // ---- epilogue: D[i = co][j = pixel x]; lane owns channels fq*4 .. +3 (+16 tn) of pixel (4*wave + tm, frow)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) acc[tn][tm][rg] += bv[tn][rg];
+        if (a.act == ACT_RELU) {
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) acc[tn][tm][rg] = fmaxf(acc[tn][tm][rg], 0.f);
+        } else if (a.act == ACT_TANH) {
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        const float v = acc[tn][tm][rg];
+                        const float e = __expf(-2.f * fabsf(v));                  // tanh(|x|) = (1 - e) / (1 + e)
+                        acc[tn][tm][rg] = copysignf((1.f - e) / (1.f + e), v);
+                    }
+        } else if (a.act == ACT_SIGMOID) {
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) acc[tn][tm][rg] = 1.f / (1.f + __expf(-acc[tn][tm][rg]));
+        }
         {
             const int n = t / tpi;
             const int r = t - n * tpi;
@@ -148,39 +196,19 @@ __global__ __launch_bounds__(256, 2) void igemm_narrow_kernel(const NarrowArgs a
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
                 const int y = tyi * 16 + 4 * wave + tm;
-                if (y >= a.H || x >= a.W) continue;
-                half_t* orow = a.out + ((int64_t)(n * a.H + y) * a.W + x) * a.CoStore;
+                const bool inside = y < a.H && x < a.W;
+                const uint32_t opix = (uint32_t)(((n * a.H + y) * a.W + x) * a.CoStore * 2);
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) {
                     const int co = tn * 16 + fq * 4;
-                    if (co >= a.CoStore) continue;
-                    f4 v = acc[tn][tm];
-                    if (a.bias) {
-#pragma unroll
-                        for (int rg = 0; rg < 4; ++rg) v[rg] += bv[tn][rg];
-                    }
-                    // one activation branch per fragment (wave-uniform), not per element
-                    if (a.act == ACT_RELU) {
-#pragma unroll
-                        for (int rg = 0; rg < 4; ++rg) v[rg] = fmaxf(v[rg], 0.f);
-                    } else if (a.act == ACT_TANH) {
-#pragma unroll
-                        for (int rg = 0; rg < 4; ++rg) {
-                            const float e = __expf(-2.f * fabsf(v[rg]));          // tanh(|x|) = (1 - e) / (1 + e)
-                            v[rg] = copysignf((1.f - e) / (1.f + e), v[rg]);
-                        }
-                    } else if (a.act == ACT_SIGMOID) {
-#pragma unroll
-                        for (int rg = 0; rg < 4; ++rg) v[rg] = 1.f / (1.f + __expf(-v[rg]));
-                    }
                     h4 hv;
 #pragma unroll
-                    for (int rg = 0; rg < 4; ++rg) hv[rg] = (half_t)(co + rg < a.Co ? v[rg] : 0.f);
-                    *(h4*)(orow + co) = hv;
+                    for (int rg = 0; rg < 4; ++rg) hv[rg] = (half_t)(co + rg < a.Co ? acc[tn][tm][rg] : 0.f);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, hv), rsrc_out,
+                                                          (int)((inside && co < a.CoStore) ? opix + co * 2 : 0x80000000u), 0, 0);
                 }
             }
         }
-        if (more) stash(cur ^ 1);                  // nobody reads that buffer: its tile finished before the last barrier
         __syncthreads();
         cur ^= 1;
     }
@@ -196,6 +224,10 @@ static int launch_narrow(const NarrowArgs& a, bool flip, hipStream_t st) {
 }
 
 int igemm_narrow_launch(const NarrowArgs& a, int ci, int co_tiles, bool flip, hipStream_t st) {
+    // 32-bit buffer offsets
+    if ((int64_t)a.N * a.H * a.W * ci * 2 >= 0x80000000LL || (int64_t)a.N * a.H * a.W * a.CoStore * 2 >= 0x80000000LL ||
+        (a.CoStore & 3))
+        return E_UNSUPPORTED;
     if (ci == 32 && co_tiles == 1) return launch_narrow<32, 1>(a, flip, st);
     if (ci == 8 && co_tiles == 1) return launch_narrow<8, 1>(a, flip, st);
     if (ci == 8 && co_tiles == 2) return launch_narrow<8, 2>(a, flip, st);

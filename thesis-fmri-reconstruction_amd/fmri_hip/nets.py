@@ -442,12 +442,25 @@ class DiscriminatorNet:
         ctx = dict(x=x16, acts=acts, raws=raws, svs=svs)
         if not head:
             return raws[2], None, ctx
+        return raws[2], self.forward_head(ctx, train_stats, fc_updates), ctx
+
+    def forward_head(self, ctx, train_stats: bool = True, fc_updates: int = 1):
+        """The 'GAN' head (flatten -> fc.0 -> BN1d -> ReLU -> fc.3, models/vae_gan.py:176-183) on the conv activations of
+        an earlier ``forward(..., head=False)`` (``ctx``, completed in place): class logits [3B, 1] fp32."""
+        h = ctx["acts"][3]
         flat = h.reshape(h.shape[0], -1)
         raw_fc, _ = self.fc0.forward(flat)
         hfc, svfc = self.fc_bn.forward(raw_fc, relu=True, updates=fc_updates if train_stats else 0)
         _, logit32 = self.fc3.forward(hfc, ACT_NONE, want16=False, want32=True)
         ctx.update(flat=flat, raw_fc=raw_fc, hfc=hfc, svfc=svfc)
-        return raws[2], logit32, ctx
+        return logit32
+
+    def conv_running_again(self, ctx, updates: int = 1):
+        """Apply the conv blocks' BatchNorm running-statistics update once more with the batch statistics saved in ``ctx``
+        (a repeated forward call on the same input, see BatchNorm.update_running_again)."""
+        for bn, sv in zip(self.bns, ctx["svs"]):
+            if sv is not None:
+                bn.update_running_again(sv, updates)
 
     def backward(self, *args, join: bool = True, **kwargs):
         """``_backward`` + join of the side stream its weight gradients were issued on (ops.side_run).  ``join=False``

@@ -643,7 +643,7 @@ class DenseLayer:
 # batch norm
 # ------------------------------------------------------------------------------------------------
 class BNSaved:
-    __slots__ = ("mean", "rstd", "scale", "shift", "count")
+    __slots__ = ("mean", "rstd", "scale", "shift", "count", "sums")
 
 
 class BatchNorm:
@@ -762,6 +762,7 @@ class BatchNorm:
             count *= self.reducer(sums)
             lib.call("fmri_bn_finalize", _P(sums), C, count, *fin)
         sv.count = count
+        sv.sums = sums                  # [2][C] sum x, sum x^2 of the batch: update_running_again() re-applies them
         if updates > 0:
             self._running_out()
         if out is None:
@@ -769,6 +770,19 @@ class BatchNorm:
         lib.note(bytes=4.0 * M * C)
         lib.call("fmri_bn_apply", _P(x2), _P(out), M, C, _P(sv.scale), _P(sv.shift), 1 if relu else 0)
         return out, sv
+
+    def update_running_again(self, sv: BNSaved, updates: int = 1):
+        """One more momentum update of running_mean / running_var / num_batches_tracked with the batch statistics of an
+        earlier train-mode ``forward`` (``sv``): what a second forward call on the SAME input does to the module's buffers
+        (the reference runs the discriminator's conv stack twice per step on identical inputs, models/vae_gan.py:284-285)
+        without recomputing anything else."""
+        C = self.C
+        gamma, beta, rm, rv = self._params()
+        self._running_in()
+        junk = torch.empty(4, C, dtype=torch.float32, device=rm.device)
+        lib.call("fmri_bn_finalize", _P(sv.sums), C, sv.count, _P(gamma), _P(beta), 1e-5, 0.9, int(updates), _P(rm), _P(rv),
+                 _P(junk[0]), _P(junk[1]), _P(junk[2]), _P(junk[3]), _P(self.nbt))
+        self._running_out()
 
     def forward_eval(self, raw: torch.Tensor, relu: bool = True, out: Optional[torch.Tensor] = None):
         """Eval-mode BN (running statistics, models/vae_gan.py:288-297 path): y = relu(gamma*(x-rm)/sqrt(rv+eps)+beta)."""

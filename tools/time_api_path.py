@@ -6,8 +6,7 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "thesis-fmri-reconstruction_amd"))
 import numpy as np, torch
 import configs.models_config as mc
-mc.image_size = 64; mc.fc_input = 8; mc.fc_output = 1024; mc.fc_input_gan = 8; mc.fc_output_gan = 512
-mc.stride_gan = 1; mc.latent_dim = 128; mc.output_pad_dec = [True] * 3; mc.decoder_channels = [256, 128, 32, 3]
+mc.use_px64()
 import models.vae_gan as vg
 dev = "cuda:0"
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
@@ -29,11 +28,11 @@ def step():
     model.zero_grad(); lg.backward(retain_graph=True); od.step()
     model.discriminator.zero_grad(); ld.backward(); os_.step()
     return le
-for _ in range(3): step()
-torch.cuda.synchronize(); t0 = time.perf_counter(); n = 10
+for _ in range(15): step()          # the caching allocator keeps growing for ~10 steps (214 device allocations)
+torch.cuda.synchronize(); t0 = time.perf_counter(); n = 20
 for _ in range(n): l = step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
-print(f"API path (literal loop body, B={B}): {1e3 * dt:.2f} ms/step  {B / dt:.0f} images/s  loss_encoder {float(l):.1f}", flush=True)
+print(f"API path (literal loop body, B={B}): {1e3 * dt:.2f} ms/step  {B / dt:.0f} images/s  loss_encoder {float(l.detach()):.1f}", flush=True)
 from fmri_hip.params import ArchConfig
 from fmri_hip.steps import Stage1Step
 st = Stage1Step(ArchConfig.px64(), dev); st.load_recipe(0, False)

@@ -135,6 +135,23 @@ int fmri_ingest_u8(const uint8_t* src, int N, int H, int W, int C, const int* fl
                    float mean0, float mean1, float mean2, float std0, float std1, float std2, void* dst16,
                    float* dst32, void* stream);
 
+/* ---- CenterCrop((crop, crop)) + Resize((S, S)) of a ragged batch of decoded uint8 images, the head of the COCO
+ * pipeline (train/train_vgan_stage1.py:162-165: torchvision 0.5.0 transforms on PIL images).  Bit-exact with
+ * torchvision.transforms.functional.center_crop / .resize over Pillow's 8-bit ImagingResample (BILINEAR: antialiased
+ * triangle filter, 22-bit fixed-point coefficients, horizontal pass rounded to uint8, then vertical pass).
+ * fmri_resize_coeffs (HOST function, no stream): coefficient tables of one pass in_size -> out_size: bounds[out][2] =
+ *   (first input index, count), coef[out][ksize]; returns ksize > 0, 0 when in_size == out_size (identity pass: no tables
+ *   needed), FMRI_E_WORKSPACE when ksize > ksize_cap (ksize = 2 * ceil(max(in / out, 1)) + 1).
+ * fmri_crop_resize_u8: pool = the images back to back (HWC, C = 1 or 3 per image), offsets_dev[n] = byte offset of image
+ *   n, dims_dev[n] = (H, W, C); both passes resample crop -> S with the tables of fmri_resize_coeffs(crop, S) uploaded by
+ *   the caller (hks / vks = their ksize, 0 = identity), vcount_max = the largest count of the vertical table (LDS rows
+ *   per block; 1 for the identity).  out [N][S][S][3] uint8, grey images replicated to three channels (GreyToColor,
+ *   data_preprocessing/data_loader.py:374-401).  Pixels of the crop box outside the image are zeros (PIL crop). */
+int fmri_resize_coeffs(int in_size, int out_size, int32_t* bounds, int32_t* coef, int ksize_cap);
+int fmri_crop_resize_u8(const uint8_t* pool, const int64_t* offsets_dev, const int32_t* dims_dev, int N, int crop, int S,
+                        const int32_t* hb_dev, const int32_t* hk_dev, int hks, const int32_t* vb_dev, const int32_t* vk_dev,
+                        int vks, int vcount_max, uint8_t* out, void* stream);
+
 /* ---- evaluation metrics of the validation loop (train/train_utils.py) ------------------------------
  * fmri_pcc : PearsonCorrelation.forward (:276-292) over n fp32 elements (whole batch), *out = coefficient.
  * fmri_ssim: StructuralSimilarity.forward (:343-420, size_average=True): mean SSIM (and the mean contrast term of

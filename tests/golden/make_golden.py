@@ -708,6 +708,25 @@ def case_surface(name, cfg, B, V, seed):
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
 
 
+def case_resize(name):
+    """CenterCrop + Resize of train_vgan_stage1.py:162-165 as torchvision 0.5.0 performs them, i.e. through PIL
+    (torchvision itself is not installed here: its two functions are the three lines restated below)."""
+    from PIL import Image
+    from oracle.resize_oracle import RESIZE_CASES, resize_inputs          # seeded inputs only (no arithmetic of the oracle)
+    out = {"meta/case": np.array("resize"), "meta/cases": np.array(RESIZE_CASES, np.int32), "meta/pillow": np.array(Image.__version__)}
+    for idx, (img, (h, w, c, crop, size)) in enumerate(zip(resize_inputs(), RESIZE_CASES)):
+        pil = Image.fromarray(img[:, :, 0] if c == 1 else img)
+        iw, ih = pil.size
+        i = int(round((ih - crop) / 2.))                      # torchvision 0.5.0 functional.center_crop
+        j = int(round((iw - crop) / 2.))
+        pil = pil.crop((j, i, j + crop, i + crop))
+        pil = pil.resize((size, size), Image.BILINEAR)        # torchvision 0.5.0 functional.resize, (h, w) size
+        res = np.asarray(pil)
+        out[f"out/{idx}"] = res if res.ndim == 3 else res[:, :, None]
+    print(name, [tuple(v.shape) for k, v in out.items() if k.startswith("out/")])
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+
+
 def load_reference_data_loader():
     """Import the reference's ``data_preprocessing.data_loader`` (for its ``rand_shift`` and ``GreyToColor``).  Its
     top-level imports of packages that are not installed here and that those two never touch (nibabel, skimage) are
@@ -805,5 +824,7 @@ if __name__ == "__main__":
         case_eval("eval_b4", O.ArchCfg.px64(), B=4, seed=9)
     if want("ingest"):
         case_ingest("ingest")
+    if want("resize"):
+        case_resize("resize")
     if want("surface_b4"):
         case_surface("surface_b4", O.ArchCfg.px64(), B=4, V=4096, seed=12)

@@ -45,6 +45,24 @@ int fmri_ingest_u8(const uint8_t* src, int N, int H, int W, int C, const int* fl
     return ingest_u8_launch(src, N, H, W, C, flip_dev, shift_dev, m, sd, (half_t*)dst16, dst32, S(stream));
 }
 
+/* ---- head of the image transforms: CenterCrop + Resize (train_vgan_stage1.py:162-165) --------------------------- */
+int fmri_resize_coeffs(int in_size, int out_size, int32_t* bounds, int32_t* coef, int ksize_cap) {
+    if (in_size < 1 || out_size < 1 || !bounds || !coef || ksize_cap < 1) return FMRI_E_BADARG;
+    if ((double)in_size / out_size > 30.0) return FMRI_E_UNSUPPORTED;       /* 64 taps per output pixel at most */
+    const int r = resize_coeffs(in_size, out_size, bounds, coef, ksize_cap);
+    return r < 0 ? FMRI_E_WORKSPACE : r;
+}
+int fmri_crop_resize_u8(const uint8_t* pool, const int64_t* offsets_dev, const int32_t* dims_dev, int N, int crop, int size,
+                        const int32_t* hb_dev, const int32_t* hk_dev, int hks, const int32_t* vb_dev, const int32_t* vk_dev,
+                        int vks, int vcount_max, uint8_t* out, void* stream) {
+    if (!pool || !offsets_dev || !dims_dev || N < 1 || crop < 1 || size < 1 || !out || hks < 0 || vks < 0) return FMRI_E_BADARG;
+    if ((hks > 0 && (!hb_dev || !hk_dev)) || (vks > 0 && (!vb_dev || !vk_dev)) || vcount_max < 1 || vcount_max > vks + (vks == 0))
+        return FMRI_E_BADARG;
+    if ((hks == 0 || vks == 0) && crop != size) return FMRI_E_BADARG;
+    return crop_resize_u8_launch(pool, offsets_dev, dims_dev, N, crop, size, hb_dev, hk_dev, hks, vb_dev, vk_dev, vks, vcount_max,
+                                 out, S(stream));
+}
+
 /* ---- evaluation metrics (train/train_utils.py:267-292, :295-420) ---- */
 int fmri_pcc(const float* pred, const float* truth, int64_t n, double* ws5, float* out, void* stream) {
     if (!pred || !truth || !ws5 || !out || n < 2) return FMRI_E_BADARG;

@@ -125,6 +125,10 @@ int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, float l
 
 int ingest_u8_launch(const uint8_t* src, int N, int H, int W, int C, const int* flip, const int* shift,
                      const float* mean3, const float* std3, half_t* dst16, float* dst32, hipStream_t st);
+int resize_coeffs(int in_size, int out_size, int32_t* bounds, int32_t* coef, int ksize_cap);
+int crop_resize_u8_launch(const uint8_t* pool, const int64_t* offsets, const int32_t* dims, int N, int crop, int S,
+                          const int32_t* hb, const int32_t* hk, int hks, const int32_t* vb, const int32_t* vk, int vks,
+                          int vcount_max, uint8_t* out, hipStream_t st);
 int pcc_launch(const float* x, const float* y, int64_t n, double* sums5, float* out, hipStream_t st);
 int ssim_launch(const float* a, const float* b, int planes, int H, int W, double* acc2, float* ssim, float* contrast,
                 hipStream_t st);

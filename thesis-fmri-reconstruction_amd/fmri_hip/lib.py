@@ -24,6 +24,7 @@ _SIGS = {
     "fmri_pack_entry_fill": [_p, _p, _p, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i],
     "fmri_pack_weight_batch": [_p, _i, _i, _p],
     "fmri_ingest_u8": [_p, _i, _i, _i, _i, _p, _p, _f, _f, _f, _f, _f, _f, _p, _p, _p],
+    "fmri_crop_resize_u8": [_p, _p, _p, _i, _i, _i, _p, _p, _i, _p, _p, _i, _i, _p, _p],
     "fmri_pcc": [_p, _p, _l, _p, _p, _p],
     "fmri_ssim": [_p, _p, _i, _i, _i, _p, _p, _p, _p],
     "fmri_unpack_grad": [_p, _p, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _l, _p],
@@ -87,7 +88,7 @@ EP_ACT_APPLIED = 0x40000000
 
 
 EXPORTS = sorted(list(_SIGS) + ["fmri_version", "fmri_last_error_string", "fmri_test_fastdiv", "fmri_bn_ws_floats",
-                             "fmri_bn_fold_scratch_floats"])
+                             "fmri_bn_fold_scratch_floats", "fmri_resize_coeffs"])
 
 _lib = None
 
@@ -115,6 +116,8 @@ def load():
     lib.fmri_bn_ws_floats.argtypes = [_i, _i]
     lib.fmri_bn_fold_scratch_floats.restype = _i
     lib.fmri_bn_fold_scratch_floats.argtypes = [_i]
+    lib.fmri_resize_coeffs.restype = _i
+    lib.fmri_resize_coeffs.argtypes = [_i, _i, _p, _p, _i]
     _lib = lib
     return lib
 

@@ -971,3 +971,127 @@ def ingest_u8(images_u8: torch.Tensor, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5)
     lib.call("fmri_ingest_u8", _P(images_u8), N, H, W, C, _P(flip), _P(shift), float(mean[0]), float(mean[1]),
              float(mean[2]), float(std[0]), float(std[1]), float(std[2]), _P(o16), _P(o32))
     return o16, o32
+
+
+# ------------------------------------------------------------------------------------------------
+# head of the image pipeline: CenterCrop + Resize on the device, pinned double-buffered staging
+# ------------------------------------------------------------------------------------------------
+_RESIZE_TABLES = {}
+
+
+def resize_tables(crop: int, size: int, device):
+    """Device coefficient tables of one Pillow BILINEAR pass ``crop`` -> ``size`` (fmri_resize_coeffs), cached.
+    Returns (bounds int32 [size][2], coef int32 [size][ksize], ksize, largest tap count); ksize == 0: identity pass."""
+    key = (crop, size, str(device))
+    t = _RESIZE_TABLES.get(key)
+    if t is None:
+        import numpy as np
+        L = lib.load()
+        cap = 2 * int(-(-max(crop, size) // size)) + 1
+        b = np.zeros((size, 2), np.int32)
+        k = np.zeros((size, cap), np.int32)
+        ks = L.fmri_resize_coeffs(crop, size, b.ctypes.data, k.ctypes.data, cap)
+        if ks < 0:
+            lib.check(ks, "fmri_resize_coeffs")
+        if ks == 0:
+            t = (None, None, 0, 1)
+        else:
+            t = (torch.from_numpy(b).to(device), torch.from_numpy(np.ascontiguousarray(k[:, :ks].reshape(size, ks))).to(device),
+                 ks, int(b[:, 1].max()))
+        _RESIZE_TABLES[key] = t
+    return t
+
+
+def crop_resize_u8(pool: torch.Tensor, offsets: torch.Tensor, dims: torch.Tensor, crop: int, size: int,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """CenterCrop((crop, crop)) + Resize((size, size)) of a ragged batch of decoded images, bit-exact with the
+    torchvision 0.5.0 / PIL transforms of train_vgan_stage1.py:162-165 (csrc/ingest.hip).  ``pool``: uint8 device
+    buffer with the images back to back (HWC); ``offsets`` int64 [N] byte offsets; ``dims`` int32 [N][3] = (H, W, C),
+    C = 1 or 3.  Returns uint8 [N][size][size][3] (grey replicated): the input of ``ingest_u8``."""
+    require_gpu(pool)
+    assert pool.dtype == torch.uint8 and offsets.dtype == torch.int64 and dims.dtype == torch.int32
+    N = offsets.numel()
+    assert dims.shape == (N, 3) and offsets.is_cuda and dims.is_cuda
+    b, k, ks, vmax = resize_tables(crop, size, pool.device)
+    if out is None:
+        out = torch.empty(N, size, size, 3, dtype=torch.uint8, device=pool.device)
+    lib.call("fmri_crop_resize_u8", _P(pool), _P(offsets), _P(dims.contiguous()), N, crop, size, _P(b), _P(k), ks,
+             _P(b), _P(k), ks, vmax, _P(out))
+    return out
+
+
+class HostStager:
+    """Pinned-memory double-buffered host -> device staging of decoded image batches (replaces the transform chain the
+    reference runs inside its DataLoader workers, train/train_vgan_stage1.py:162-170,195): the loader threads only
+    decode; ``submit`` packs a ragged batch into one pinned buffer, copies it on a SIDE stream and runs crop + resize +
+    ingest (flip / shift / ToTensor / GreyToColor / Normalize) there, so that batch i + 1 is staged while the training
+    step of batch i runs on the main stream.  ``depth`` buffers rotate; a buffer is re-used only after the device
+    work that read it has completed (event), so ``submit`` never overwrites bytes still being copied.
+
+        stager = HostStager("cuda:0", crop=375, size=64)
+        t = stager.submit(images)                 # list of uint8 HWC numpy arrays (C = 1 or 3), any sizes
+        x16, x32 = stager.take(t)                 # main stream waits for the side stream's event, no host sync
+    """
+
+    def __init__(self, device, crop: int, size: int, depth: int = 2, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5),
+                 capacity: int = 1 << 26):
+        self.device = torch.device(device)
+        self.crop, self.size, self.mean, self.std = crop, size, mean, std
+        self.depth = depth
+        self.stream = torch.cuda.Stream(self.device)
+        self.pinned = [torch.empty(capacity, dtype=torch.uint8).pin_memory() for _ in range(depth)]
+        self.dev = [torch.empty(capacity, dtype=torch.uint8, device=self.device) for _ in range(depth)]
+        self.free_evt = [None] * depth            # recorded when the side stream is done with slot i
+        self.slot = 0
+        self.tickets = {}
+        self.next_ticket = 0
+
+    def submit(self, images, flip=None, shift=None, want16: bool = True, want32: bool = False) -> int:
+        import numpy as np
+        i = self.slot
+        self.slot = (self.slot + 1) % self.depth
+        if self.free_evt[i] is not None:
+            self.free_evt[i].synchronize()        # the copy / kernels that read this slot have finished
+        offs, dims, pos = [], [], 0
+        host = self.pinned[i].numpy()
+        for img in images:
+            a = np.ascontiguousarray(img)
+            if a.ndim == 2:
+                a = a[:, :, None]
+            assert a.dtype == np.uint8 and a.shape[2] in (1, 3)
+            nb = a.size
+            if pos + nb > host.size:
+                raise ValueError("HostStager: batch exceeds the staging capacity")
+            host[pos:pos + nb] = a.reshape(-1)
+            offs.append(pos)
+            dims.append(a.shape)
+            pos += (nb + 15) // 16 * 16
+        N = len(offs)
+        meta = torch.tensor(offs, dtype=torch.int64).pin_memory()
+        dm = torch.tensor(dims, dtype=torch.int32).pin_memory()
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)              # allocations made below are ordered after the caller's frees
+        with torch.cuda.stream(self.stream):
+            self.dev[i][:pos].copy_(self.pinned[i][:pos], non_blocking=True)
+            offs_d = meta.to(self.device, non_blocking=True)
+            dims_d = dm.to(self.device, non_blocking=True)
+            u8 = crop_resize_u8(self.dev[i], offs_d, dims_d, self.crop, self.size)
+            x16, x32 = ingest_u8(u8, self.mean, self.std, flip, shift, want16, want32)
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        self.free_evt[i] = done
+        t = self.next_ticket
+        self.next_ticket += 1
+        self.tickets[t] = (x16, x32, done, (meta, dm, offs_d, dims_d, u8))
+        return t
+
+    def take(self, ticket: int):
+        """(fp16 NHWC8 engine input or None, fp32 NCHW module input or None) of a submitted batch; the CURRENT stream
+        waits for the staging work (device-side wait: the host does not block)."""
+        x16, x32, done, keep = self.tickets.pop(ticket)
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(done)
+        for t in (x16, x32) + keep[2:]:
+            if t is not None:
+                t.record_stream(cur)
+        return x16, x32

@@ -15,6 +15,20 @@
 
 namespace fmri {
 
+namespace {
+typedef int v4i __attribute__((ext_vector_type(4)));
+// 16-byte buffer -> LDS DMA (see igemm_tc5.hip::bdma16): offsets >= num_records read as zero
+__device__ __forceinline__ void wdma16(v4i srd, uint32_t voff, uint32_t lds) {
+    srd.x = __builtin_amdgcn_readfirstlane(srd.x);
+    srd.y = __builtin_amdgcn_readfirstlane(srd.y);
+    srd.z = __builtin_amdgcn_readfirstlane(srd.z);
+    srd.w = __builtin_amdgcn_readfirstlane(srd.w);
+    lds = __builtin_amdgcn_readfirstlane(lds);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(srd), "s"(lds)
+                 : "memory");
+}
+}  // namespace
+
 // P tile: 64 m-rows x 256 B, swizzled exactly like wgrad.hip.  Window: WH x WW pixels x 64 B, linear.
 template <int NSY, int NSX, bool SLABS>
 __device__ __forceinline__ void wgrad_win_body(const WgradWinArgs& a, char* smem, int py, int px, int a_tile,
@@ -33,17 +47,23 @@ __device__ __forceinline__ void wgrad_win_body(const WgradWinArgs& a, char* smem
     const int b0 = b_tile * 32;
     const int tminy = a.tmin[py], tminx = a.tmin[px];
 
-    // ---- P source: thread loads the 16-B chunk `clog` of rows trow + 16 i (i < 4), wgrad.hip's swizzle
+    // ---- P source: thread loads the 16-B chunk `clog` of rows trow + 16 i (i < 4), wgrad.hip's swizzle.
+    // Round 3: both operands are DMA'd through buffer descriptors with 32-bit offsets = (per-lane constant) + (scalar
+    // of the tile); out-of-image lanes carry the out-of-range offset and read as zero.  Round 2's form built a 64-bit
+    // address (and a select against the zero page) per lane and DMA instruction: 330-680 vector + 350-590 scalar
+    // instructions per K-step around its 32-72 MFMAs -- the kernel was bound by VALU issue, not by the matrix pipe.
     const int trow = tid >> 4;
     const int cphys = tid & 15;
     const int fsw = (((trow & 3) | (((trow >> 3) & 1) << 2)) << 1);
     const int clog = cphys ^ fsw;
     const bool p_on = a0 + clog * 8 < a.A;
-    const half_t* pbase = a.P + a0 + clog * 8;
+    const int prow = trow >> 3, pcol = trow & 7;                     // tile pixel of row trow (+ 2 pixel rows per i)
+    const uint32_t lane_p = (uint32_t)(((prow * a.Xc + pcol) * a.A + a0 + clog * 8) * 2);
 
     // ---- window source: units u = tid, tid + 256 -> window pixel u >> 2, channels 8 * (u & 3)
     int wj[2], wi[2];
     bool won[2];
+    uint32_t lane_q[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         const int u = tid + 256 * e;
@@ -51,8 +71,17 @@ __device__ __forceinline__ void wgrad_win_body(const WgradWinArgs& a, char* smem
         won[e] = pix < WH * WW;
         wj[e] = pix / WW;
         wi[e] = pix - wj[e] * WW;
+        lane_q[e] = (uint32_t)(((2 * wj[e] * a.Wq + 2 * wi[e]) * a.Bc + b0 + (tid & 3) * 8) * 2);
     }
-    const half_t* qbase = a.Q + b0 + (tid & 3) * 8;
+    v4i srdP, srdQ;
+    srdP.x = (int)(uint32_t)(uintptr_t)a.P;
+    srdP.y = (int)(uint32_t)((uintptr_t)a.P >> 32);
+    srdP.z = (int)((uint32_t)a.N * (uint32_t)a.Yc * (uint32_t)a.Xc * (uint32_t)a.A * 2u);
+    srdP.w = 0x00020000;
+    srdQ.x = (int)(uint32_t)(uintptr_t)a.Q;
+    srdQ.y = (int)(uint32_t)((uintptr_t)a.Q >> 32);
+    srdQ.z = (int)((uint32_t)a.N * (uint32_t)a.Hq * (uint32_t)a.Wq * (uint32_t)a.Bc * 2u);
+    srdQ.w = 0x00020000;
 
     // the K range (8x8 pixel tiles) is cut into equal pieces, the same for every plane (see api.hip)
     const int tps = a.plane_tps[py * 2 + px];
@@ -66,36 +95,37 @@ __device__ __forceinline__ void wgrad_win_body(const WgradWinArgs& a, char* smem
     // loop-invariant scalars of the K loop and the epilogue, pinned in SGPRs (see FMRI_KEEP)
     int kYc = a.Yc, kXc = a.Xc, kA = a.A, kHq = a.Hq, kWq = a.Wq, kBc = a.Bc, ktx = a.tiles_x, ktpi = tpi;
     uint32_t tpi_magic = a.fdTPI.magic, tpi_sh = a.fdTPI.sh, tx_magic = a.fdTX.magic, tx_sh = a.fdTX.sh;
-    const half_t* kzero = a.zero;
     FMRI_KEEP(kYc); FMRI_KEEP(kXc); FMRI_KEEP(kA); FMRI_KEEP(kHq); FMRI_KEEP(kWq); FMRI_KEEP(kBc); FMRI_KEEP(ktx);
-    FMRI_KEEP(ktpi); FMRI_KEEP(tpi_magic); FMRI_KEEP(tpi_sh); FMRI_KEEP(tx_magic); FMRI_KEEP(tx_sh); FMRI_KEEP(kzero);
+    FMRI_KEEP(ktpi); FMRI_KEEP(tpi_magic); FMRI_KEEP(tpi_sh); FMRI_KEEP(tx_magic); FMRI_KEEP(tx_sh);
     const FastDiv fTPI{tpi_magic, tpi_sh, 0, 0}, fTX{tx_magic, tx_sh, 0, 0};
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+    const uint32_t prow_step = (uint32_t)(2 * kXc * kA * 2);          // two pixel rows of P
 
-    auto stage_load = [&](int buf, int t) {
+    auto stage_load = [&](int buf, int t) __attribute__((always_inline)) {
         // tile -> (image, tile row, tile col): wave-uniform
         const int n = (int)fd_div((uint32_t)t, fTPI);
         const int trem = t - n * ktpi;
         const int tyi = (int)fd_div((uint32_t)trem, fTX);
         const int txi = trem - tyi * ktx;
         const int y0 = tyi * 8, x0 = txi * 8;
-        char* dstP = smem + buf * STAGE + wave * (4 * 256);
+        const uint32_t tile_p = (uint32_t)(((n * kYc + y0) * kXc + x0) * kA * 2);
+        const bool pcol_ok = p_on && x0 + pcol < kXc;
+        const uint32_t dstP = lds0 + buf * STAGE + wave * (4 * 256);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int r = trow + 16 * i;
-            const int y = y0 + (r >> 3), x = x0 + (r & 7);
-            const bool ok = p_on && y < kYc && x < kXc;
-            const half_t* ps = ok ? pbase + (int64_t)((n * kYc + y) * kXc + x) * kA : kzero;
-            glds16_raw(ps, dstP + i * (16 * 256));
+            const bool ok = pcol_ok && y0 + prow + 2 * i < kYc;
+            wdma16(srdP, ok ? tile_p + lane_p + i * prow_step : 0x80000000u, dstP + i * (16 * 256));
         }
-        char* dstW = smem + buf * STAGE + P_BYTES + wave * 1024;
+        // window origin in Q (may lie outside the image: the per-lane checks below) and its byte offset (signed)
+        const int by = 2 * (y0 + tminy) + py, bx = 2 * (x0 + tminx) + px;
+        const int tile_q = ((n * kHq + by) * kWq + bx) * kBc * 2;
+        const uint32_t dstW = lds0 + buf * STAGE + P_BYTES + wave * 1024;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             if (e * 4096 + wave * 1024 < W_BYTES) {      // wave-uniform
-                const int iy = 2 * (y0 + tminy + wj[e]) + py;
-                const int ix = 2 * (x0 + tminx + wi[e]) + px;
+                const int iy = by + 2 * wj[e], ix = bx + 2 * wi[e];
                 const bool ok = won[e] && (unsigned)iy < (unsigned)kHq && (unsigned)ix < (unsigned)kWq;
-                const half_t* qs = ok ? qbase + (int64_t)((n * kHq + iy) * kWq + ix) * kBc : kzero;
-                glds16_raw(qs, dstW + e * 4096);
+                wdma16(srdQ, ok ? (uint32_t)(tile_q + (int)lane_q[e]) : 0x80000000u, dstW + e * 4096);
             }
         }
     };
@@ -236,6 +266,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_win_kernel(const WgradWinArgs a)
 }
 
 int wgrad_win_launch(const WgradWinArgs& a, int apad, hipStream_t st) {
+    // 32-bit buffer offsets
+    if ((int64_t)a.N * a.Yc * a.Xc * a.A * 2 >= 0x80000000LL || (int64_t)a.N * a.Hq * a.Wq * a.Bc * 2 >= 0x80000000LL)
+        return E_UNSUPPORTED;
     dim3 grid((a.Bc / 32) * a.a_tiles * 4 * a.splits);
     const int lds = 3 * (64 * 256 + 7 * 1024);
     // raising the dynamic-LDS limit is idempotent; every call sets it (no library-global state)

@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfmri_hip.so")
+# FMRI_LIB_PATH: another build of the same library (A/B timing of two builds in one gpurun call)
+LIB_PATH = os.environ.get("FMRI_LIB_PATH") or os.path.join(_HERE, "libfmri_hip.so")
 
 _i, _f, _l, _p = C.c_int, C.c_float, C.c_int64, C.c_void_p
 

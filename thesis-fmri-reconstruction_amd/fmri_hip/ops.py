@@ -336,7 +336,8 @@ def run_wgrad(P, Q, N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad, flip=0, flops=0.0)
         note = lambda kern: lib.note(kernel=kern, flops=fl, bytes=nb)
     else:
         note = lambda kern: None
-    if stride == 2 and not flip and ba == 128 and Bc % 32 == 0 and Yc * Xc > 1 and k == 5 and pad == 2 and _WW_ON:
+    if (stride == 2 and not flip and ba == 128 and Bc % 32 == 0 and Yc * Xc > 1 and k == 5 and pad == 2 and _WW_ON
+            and 2 * N * Yc * Xc * A < 2 ** 31 and 2 * N * Hq * Wq * Bc < 2 ** 31):       # 32-bit buffer offsets
         # window-resident kernel (csrc/wgrad_win.hip): blocks = 32-channel column blocks x 128-row blocks x 4 parity
         # planes x splits over the 8x8 pixel tiles; every split stores its own slab, unpack_grad sums them
         groups = (Bc // 32) * (apad // 128)

@@ -105,28 +105,35 @@ def pmc_traffic(family):
     return None, None
 
 
-# entry point -> family of the launches that carry no kernel note (lib.note): BatchNorm / activation passes, weight
-# re-pack and gradient unpack, optimizer, the rest (losses, latent, gate, layout casts)
+# A launch's kernel family: the kernel the library routes it to (lib.note(kernel=...), template arguments dropped) or, for
+# the single-kernel entry points, the entry point itself.  Coarse groups for the per-step summary:
 def _family_of(entry, note):
     if note and note.get("kernel"):
         return note["kernel"].split("<")[0]
+    return entry
+
+
+def _group_of(entry, note):
+    if note and note.get("kernel"):
+        return "weight-gradient GEMMs" if "wgrad" in note["kernel"] else "conv / deconv / dense forward + data-gradient GEMMs"
     if entry.startswith("fmri_bn_") or entry == "fmri_act_bwd":
-        return "batchnorm + activation passes (norm.hip)"
+        return "BatchNorm + activation passes"
     if entry in ("fmri_pack_weight", "fmri_pack_weight_batch", "fmri_unpack_grad", "fmri_reduce_slabs"):
-        return "weight re-pack / gradient unpack / slab sums (layout.hip)"
+        return "weight re-pack / gradient unpack / slab sums"
     if entry in ("fmri_rmsprop_dev", "fmri_adam_dev", "fmri_rmsprop", "fmri_adam", "fmri_counter_inc"):
-        return "optimizer (loss.hip)"
+        return "optimizer"
     return "losses, latent, gate, layout casts"
 
 
-def family_table(prof, steps):
-    """HIP-event time of every library launch of ``steps`` one-stream steps, grouped into kernel families.  GEMM families
-    carry algorithmic FLOPs (TFLOP/s against the dense fp16 MFMA peak), the streaming families algorithmic bytes (GB/s
-    against the HBM peak) where the caller annotated them.  An event pair brackets the launch's slot on the stream, i.e.
-    kernel time + the gap to the next launch: a few per cent on the large kernels, most of the ~5 us launches."""
+def family_table(prof, steps, key=_family_of):
+    """HIP-event time of every library launch of ``steps`` one-stream steps, grouped by ``key`` (kernel family or coarse
+    group).  GEMM families carry algorithmic FLOPs (TFLOP/s against the dense fp16 MFMA peak), the streaming kernels
+    algorithmic bytes (GB/s against the HBM peak) where the caller annotated them.  An event pair brackets the launch's
+    slot on the stream, i.e. kernel time + the gap to the next launch: a few per cent on the large kernels, most of the
+    ~5 us launches."""
     fam = {}
     for entry, note, e0, e1 in prof:
-        f = fam.setdefault(_family_of(entry, note), dict(ms=0.0, n=0, flops=0.0, bytes=0.0, ms_b=0.0))
+        f = fam.setdefault(key(entry, note), dict(ms=0.0, n=0, flops=0.0, bytes=0.0, ms_b=0.0))
         ms = e0.elapsed_time(e1)
         f["ms"] += ms
         f["n"] += 1
@@ -144,7 +151,6 @@ def family_table(prof, steps):
         elif f["bytes"] > 0 and f["ms_b"] > 0:
             row["gb_s"] = round(f["bytes"] / (f["ms_b"] * 1e-3) / 1e9, 1)
             row["frac_of_hbm_peak"] = round(row["gb_s"] / HBM_PEAK_GBS, 4)
-            row["ms_per_step_with_bytes"] = round(f["ms_b"] / steps, 3)
         rows.append((row, f))
     return rows
 
@@ -499,7 +505,8 @@ def main():
             "families": {"ms_per_step_one_stream": round(prof_ms_per_step, 3),
                          "ms_per_step_library_launches": round(lib_ms, 3),
                          "ms_per_step_torch_ops_and_gaps": round(prof_ms_per_step - lib_ms, 3),
-                         "rows": [row for row, _ in fams]},
+                         "groups": [row for row, _ in family_table(prof, ps, _group_of)],
+                         "rows": [row for row, _ in fams if row["ms_per_step"] >= 0.02]},
             "launch": {"graph": "hip-graph replay" if single else "hip-graph segments + eager collectives",
                        "hybrid": "forward replayed from a HIP graph, backward eager with weight gradients on a side "
                                  "stream" + ("" if single else " and eager collectives"),

@@ -484,7 +484,12 @@ def test_stage1_full_batch_two_steps_match_oracle():
                 with open(log, "a") as f:
                     f.write(line + "\n")
             worst[(s, k)] = r
-            assert r < (LOSS_RTOL if s == 0 else (1e-2 if k == "kl" else 3e-3)), (s, k, eng[s]["logs"][k], ref["logs"][k])
+            # step 0: the north-star bar (1e-3; measured <= 5e-5).  step 1 = "after one step" on the engine's own updated
+            # weights: measured 3.1e-4 (mse / loss_encoder), 6.3e-4 (kl) in round 3 and 1.29e-3 / 2e-4 in round 2
+            # (profiles/r03_fullbatch_two_steps.log, r02_gradcheck.log) -- RMSprop's first update is +-3.16 lr per weight
+            # whatever the gradient's size, so ReLU-mask flips under fp16 storage move this number between builds;
+            # bound = the worst of the two rounds x 1.25
+            assert r < (LOSS_RTOL if s == 0 else 1.6e-3), (s, k, eng[s]["logs"][k], ref["logs"][k])
 
 
 def test_decoder_fc_running_statistics_lazy_shadow_round_trips():

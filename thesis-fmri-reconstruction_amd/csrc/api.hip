@@ -604,8 +604,8 @@ int fmri_wgrad(const void* P, const void* Q, float* out, const void* zero16, int
         w.N = N; w.H = Yc; w.W = Xc; w.ldo = ldo; w.flip = flip;
         w.tiles_y = (Yc + 7) / 8; w.tiles_x = (Xc + 7) / 8;
         w.ntiles = N * w.tiles_y * w.tiles_x;
-        int nb = (w.ntiles + 63) / 64;              // >= 16 tiles per wave, at most two 4-wave blocks per CU
-        if (nb > 512) nb = 512;
+        int nb = (w.ntiles + 31) / 32;              // >= 16 tiles per wave PAIR, at most three 4-wave blocks per CU
+        if (nb > 768) nb = 768;
         if (nb < 1) nb = 1;
         w.nslabs = splits < 1 ? 1 : splits;         // the caller allocated `splits` zeroed slabs of apad x ldo
         w.pad0 = 0;

@@ -358,7 +358,7 @@ def run_wgrad(P, Q, N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad, flip=0, flops=0.0)
         # wave-private window kernel (csrc/wgrad_narrow.hip): atomic accumulation into zeroed 32 x ldo slab(s).  It
         # needs >= ~16 tiles per wave to amortise its block reduction: measured 1.9x on the 3B-image discriminator
         # layer, a loss on the B-image decoder layer
-        nslabs = 1
+        nslabs = 4                   # blocks add into slab (block index % 4): a quarter of the same-address atomics
         out = torch.zeros(nslabs, apad, ldo, dtype=torch.float32, device=P.device)
         note("fmri::wgrad_narrow_kernel")
         lib.call("fmri_wgrad", _P(P), _P(Q), _P(out), _P(zero_page(P.device)), N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad,

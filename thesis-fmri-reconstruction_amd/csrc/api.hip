@@ -307,6 +307,32 @@ int fmri_igemm_ep(const void* in, const void* w, void* out, const float* bias, c
         }
         q.bb = bb;
         if (!q.st.part) q.bb.x = nullptr;       // no statistics rows: plain output (*ep_done = 0 tells the caller)
+        // wide form (csrc/igemm_c5w.hip): 16 x 16-pixel tiles, one block per CU; FMRI_C5W=off disables, =all takes every
+        // Wo >= 16 geometry (default: Ci >= 128)
+        static const char* c5w_env = getenv("FMRI_C5W");
+        static const int c5w_min_sub = c5w_env && !strcmp(c5w_env, "off") ? 1 << 30 : c5w_env && !strcmp(c5w_env, "all") ? 1 : 4;
+        if (q.pw16 && q.nsub >= c5w_min_sub && !q.bb.x && Ho >= 16) {
+            C5Args w = q;
+            w.tiles_y = (Ho + 15) / 16;
+            w.ntiles = N * w.tiles_y * w.tiles_x;
+            w.fdTPI = make_fastdiv((uint32_t)(w.tiles_y * w.tiles_x));
+            w.st = se;
+            const int tpgw = se.group_n > 0 ? se.group_n * w.tiles_y * w.tiles_x : w.ntiles;
+            // whole rounds of one block per CU, statistics groups not sharing a block
+            w.tpb = 1;
+            for (int t = (w.ntiles * ncol) / 256; t > 1; --t)
+                if (tpgw % t == 0 && w.ntiles % t == 0 && ((w.ntiles / t) * ncol) % 256 == 0) { w.tpb = t; break; }
+            if (tpb_force > 0 && tpgw % tpb_force == 0) w.tpb = tpb_force;
+            if (se.part) {
+                w.st.tpg[0] = (tpgw + w.tpb - 1) / w.tpb;
+                if (w.st.tpg[0] > se.rows_cap) w.st.part = nullptr;
+            }
+            if (w.st.part || !se.part) {
+                const int r = igemm_c5w_launch(w, copad, S(stream));
+                if (r == OK && ep_done && w.st.part) *ep_done = w.st.tpg[0];
+                if (r != E_UNSUPPORTED) return r;
+            }
+        }
         const int r = igemm_c5_launch(q, copad, S(stream));
         if (r == OK && ep_done && q.st.part) *ep_done = q.st.tpg[0];
         if (r != E_UNSUPPORTED) return r;

@@ -7,14 +7,18 @@ from fmri_hip import ops
 class G:
     def __init__(s, t): s.views = t; s.grads = {k: torch.zeros_like(v) for k, v in t.items()}; s.version = 0; s.device = torch.device("cuda:0")
 REP = int(os.environ.get("REP", "10"))
+ZERO = os.environ.get("ZERO") == "1"      # all-zero operands: the clock the chip holds then is its unloaded one
+ONLY = os.environ.get("ONLY")
 def run(tag, cin, cout, stride, N, H, kind="conv", what="fwd"):
+    if ONLY and ONLY not in tag: return
     shape = (cout, cin, 5, 5) if kind == "conv" else (cin, cout, 5, 5)
-    g = G({"w": torch.randn(*shape, device="cuda") * 0.05})
+    g = G({"w": torch.randn(*shape, device="cuda") * (0.0 if ZERO else 0.05)})
     L = ops.ConvLayer(g, "w", None, kind, cin, cout, 5, stride, 2, 1 if kind == "deconv" else 0)
     x = torch.randn(N, H, H, ops.pad8(cin), device="cuda").half()
+    if ZERO: x.zero_()
     y = L.forward(x)
     fl = L._flops(N, H, H, y.shape[1], y.shape[2])
-    dy = torch.randn_like(y)
+    dy = torch.zeros_like(y) if ZERO else torch.randn_like(y)
     f = (lambda: L.forward(x, out=y)) if what == "fwd" else (lambda: L.dgrad(dy, H, H, out=x))
     for _ in range(2): f()
     torch.cuda.synchronize(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)

@@ -37,7 +37,9 @@ def _check_counters(st, g, tag, tol=2e-2):
             assert float(sd[k]) == summ[i][1], (k, float(sd[k]), summ[i][1])
             seen += 1
         elif "running_mean" in k or "running_var" in k:
-            assert _rel(sd[k].double().norm().item(), summ[i][0]) < tol, k
+            r = _rel(sd[k].double().norm().item(), summ[i][0])
+            print(f"{tag} {k} norm rel {r:.3e}")
+            assert r < tol, k
     assert seen > 0
 
 
@@ -139,8 +141,10 @@ def test_wae_step_matches_oracle_and_golden(golden_dir, stage):
                     ref16 = fn(P16, o16, data["fmri"], data["x"], cfg_o, V, keep_grads=True)
             special = [k for k in ref["grads"] if k.startswith("discriminator.") or k.endswith("l_mu.bias")]
             gradcheck.check(grads, ref["grads"], ref16["grads"], f"wae{stage}", skip=special, tol16=None)
-        # running statistics after the first (sign-like) parameter update follow the 5e-2 "next forward" bound
-        _check_counters(st, g, f"step{s}", 2e-2 if s == 0 else 5e-2)
+        # running statistics after the first (sign-like) parameter update follow the 5e-2 "next forward" bound; after the
+        # second update the B = 4 BatchNorm1d variance (4 samples per feature) is chaotic: decoder.fc.1.running_var moved
+        # 0.2 % ... 5.6 % with nothing but the choice of convolution kernel (FMRI_C5W / FMRI_TC5 / FMRI_C5 on / off)
+        _check_counters(st, g, f"step{s}", 2e-2 if s == 0 else (5e-2 if s == 1 else 1e-1))
 
 
 def test_dual_stage1_matches_oracle_and_golden(golden_dir):
@@ -186,8 +190,10 @@ def test_dual_stage1_matches_oracle_and_golden(golden_dir):
             gradcheck.check(grads, ref["grads"], ref16["grads"], "dual1", skip=latent_d, tol16=None)
             for k in latent_d:
                 assert _terr(grads[k], ref["grads"][k]) < 0.1, k
-        # running statistics after the first (sign-like) parameter update follow the 5e-2 "next forward" bound
-        _check_counters(st, g, f"step{s}", 2e-2 if s == 0 else 5e-2)
+        # running statistics after the first (sign-like) parameter update follow the 5e-2 "next forward" bound; after the
+        # second update the B = 4 BatchNorm1d variance (4 samples per feature) is chaotic: decoder.fc.1.running_var moved
+        # 0.2 % ... 5.6 % with nothing but the choice of convolution kernel (FMRI_C5W / FMRI_TC5 / FMRI_C5 on / off)
+        _check_counters(st, g, f"step{s}", 2e-2 if s == 0 else (5e-2 if s == 1 else 1e-1))
 
 
 def test_wae_stage3_px128_matches_reference_golden(golden_dir):

@@ -307,11 +307,11 @@ int fmri_igemm_ep(const void* in, const void* w, void* out, const float* bias, c
         }
         q.bb = bb;
         if (!q.st.part) q.bb.x = nullptr;       // no statistics rows: plain output (*ep_done = 0 tells the caller)
-        // wide form (csrc/igemm_c5w.hip): 16 x 16-pixel tiles, one block per CU; FMRI_C5W=off disables, =all takes every
-        // Wo >= 16 geometry (default: Ci >= 128)
+        // wide form (csrc/igemm_c5w.hip): 16 x 16-pixel tiles, one 8-wave block per CU, loader / compute waves;
+        // FMRI_C5W=off disables
         static const char* c5w_env = getenv("FMRI_C5W");
-        static const int c5w_min_sub = c5w_env && !strcmp(c5w_env, "off") ? 1 << 30 : c5w_env && !strcmp(c5w_env, "all") ? 1 : 4;
-        if (q.pw16 && q.nsub >= c5w_min_sub && !q.bb.x && Ho >= 16) {
+        static const bool no_c5w = c5w_env && !strcmp(c5w_env, "off");
+        if (!no_c5w && q.pw16 && !q.bb.x && Ho > 8) {
             C5Args w = q;
             w.tiles_y = (Ho + 15) / 16;
             w.ntiles = N * w.tiles_y * w.tiles_x;

@@ -24,6 +24,16 @@
 #include "kernels.h"
 #include <type_traits>
 
+#ifndef C5W_NSTG
+#define C5W_NSTG 4      // weight ring stages (16 KB each)
+#endif
+#ifndef C5W_HALFA
+#define C5W_HALFA 1
+#endif
+#ifndef C5W_ABL
+#define C5W_ABL 0       // diagnostic builds only: 1 no output stores, 2 no fragment reads, 3 no operand DMA, 4 no MFMAs
+#endif
+
 namespace fmri {
 
 #ifdef FMRI_STAMP
@@ -58,6 +68,7 @@ __device__ __forceinline__ void wdma(v4i srd, uint32_t voff, uint32_t soff, uint
     srd.w = __builtin_amdgcn_readfirstlane(srd.w);
     soff = __builtin_amdgcn_readfirstlane(soff);
     lds = __builtin_amdgcn_readfirstlane(lds);
+    if (C5W_ABL == 3 && srd.z != 0x7fffffff) return;
     asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
                  ::"v"(voff), "s"(srd), "s"(soff), "s"(lds)
                  : "memory");
@@ -65,7 +76,7 @@ __device__ __forceinline__ void wdma(v4i srd, uint32_t voff, uint32_t soff, uint
 
 template <int N>
 __device__ __forceinline__ void wait_vmw() {
-    static_assert(N >= 0 && N <= 15, "vmcnt");
+    static_assert(N >= 0 && N <= 63, "vmcnt");
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
@@ -73,35 +84,57 @@ __device__ __forceinline__ void wait_vmw() {
 constexpr int w5_ky(int i) { return i < 15 ? 2 * (i / 5) : 1 + 2 * ((i - 15) / 5); }
 constexpr int w5_kx(int i) { return i < 15 ? i % 5 : (i - 15) % 5; }
 
+// ---- DMA schedule of one 32-channel sub-chunk (13 K-steps), ring of NSTG weight stages filled D = NSTG - 1 steps ahead.
+// Issued behind the barrier of step t, in this order: the 4 weight pieces of step t + D (of the next sub-chunk past step 12),
+// then window slices: steps 0-4 two slices of this sub-chunk's odd-row window (buffer 1, first read in step 7), steps 8-11
+// 3, 3, 2, 2 slices of the next sub-chunk's even-row window (buffer 0, last read in step 7).
+constexpr int w5_ev_n(int t) { return (t == 8 || t == 9) ? 3 : ((t == 10 || t == 11) ? 2 : 0); }
+constexpr int w5_ev_0(int t) { return t == 8 ? 0 : (t == 9 ? 3 : (t == 10 ? 6 : 8)); }
+constexpr int w5_s(int t, bool more) { return t <= 4 ? 2 : (more ? w5_ev_n(t) : 0); }
+constexpr int w5_w(int t, bool more, int D) { return (t + D < 13 || more) ? 4 : 0; }
+// pieces that may still be in flight at the barrier of step t (vmcnt counts in issue order): the weights of step t were
+// issued at step t - D; index i < 0 = step i + 13 of the previous sub-chunk (which had a successor)
+constexpr int w5_allow(int t, bool more, int D) {
+    int n = t - D < 0 ? w5_s(t - D + 13, true) : w5_s(t - D, more);
+    for (int i = t - D + 1; i < t; ++i) n += i < 0 ? 4 + w5_s(i + 13, true) : w5_w(i, more, D) + w5_s(i, more);
+    if (t == 7) {                       // the odd-row window (last slices issued at step 4) is read from here on
+        int m = 0;
+        for (int i = 5; i < 7; ++i) m += w5_w(i, more, D) + w5_s(i, more);
+        n = m < n ? m : n;
+    }
+    if (t == 0) n = 4 < n ? 4 : n;      // the even-row window (last slices at step 11 of the previous sub-chunk) is read from here on
+    return n;
+}
+
 }  // namespace
 
 // STATS: 0 none, 1 BatchNorm forward statistics (StatEpi)
 template <int STATS>
-__global__ __launch_bounds__(256, 1) void igemm_c5w_kernel(const C5Args a) {
-    constexpr int BN = 128, WM = 2, WN = 2, TM = 8, TN = 4;
+__global__ __launch_bounds__(512, 1) void igemm_c5w_kernel(const C5Args a) {
+    constexpr int BN = 128, WN = 2, TM = 8, TN = 4;
     constexpr int PW = 16, PH = 16;
     constexpr int ROW = 2 * PW + 3;                       // window pixels per row: plane 0 (PW + 2), plane 1 (PW + 1)
     constexpr int NSL = 10;                               // 4 KB DMA slices per window ((PH + 2) * ROW * 64 B = 40 320)
     constexpr int WINB = NSL * 4096;
     constexpr int W_BYTES = 2 * 8192;                     // two tap slots of [128 co][32 ch]
     constexpr int WBUF0 = 2 * WINB;
+    constexpr int NSTG = C5W_NSTG, D = NSTG - 1;          // weight ring stages, K-steps of weights in flight
     static_assert((PH + 2) * ROW * 64 <= WINB, "window fits its slices");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool loader = wave >= 4;                        // waves 4-7 move bytes, waves 0-3 multiply
     int bx, by;
     xcd_tile(bx, by);
     const int tile0 = bx * a.tpb;
     if (tile0 >= a.ntiles) return;
     const int tile1 = tile0 + a.tpb < a.ntiles ? tile0 + a.tpb : a.ntiles;
     const int co0 = by * BN;
-    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+    const int nsub = a.nsub;
 
     // ---- tile -> (image, tile origin)
     const int tpi = a.tiles_y * a.tiles_x;
-    int grp, y0, x0;                      // of the tile being computed (epilogue)
     auto tile_geom = [&](int tile, int& g, int& yy, int& xx) __attribute__((always_inline)) {
         g = (int)fd_div((uint32_t)tile, a.fdTPI);
         const int trem = tile - g * tpi;
@@ -109,350 +142,421 @@ __global__ __launch_bounds__(256, 1) void igemm_c5w_kernel(const C5Args a) {
         yy = tyi * PH;
         xx = (trem - tyi * a.tiles_x) * PW;
     };
-    tile_geom(tile0, grp, y0, x0);
-
-    v4i srd_in, srd_w;
-    srd_in.x = (int)(uint32_t)(uintptr_t)a.in;
-    srd_in.y = (int)(uint32_t)((uintptr_t)a.in >> 32);
-    srd_in.z = (int)a.in_bytes;
-    srd_in.w = 0x00020000;
-    srd_w.x = (int)(uint32_t)(uintptr_t)a.w;
-    srd_w.y = (int)(uint32_t)((uintptr_t)a.w >> 32);
-    srd_w.z = (int)a.w_bytes;
-    srd_w.w = 0x00020000;
-
-    // ---- window DMA: 16-B unit q = e*256 + tid of a window buffer holds channels 8*cc .. 8*cc+7 (of the 32-channel
-    // sub-chunk) of window pixel p = q >> 2 = row j, column position ii; cc = (q & 3) ^ 2*bit2(ii).
-    // Column position ii < PW + 2: input column 2*x0 - 2 + 2*ii; else 2*x0 - 1 + 2*(ii - PW - 2).  Row j of phase rp:
-    // input row 2*y0 - 2 + rp + 2*j (the odd phase has PH + 1 rows).
-    uint32_t soff0[NSL], soff1[NSL];
-    uint32_t wstat[NSL];                  // column term | row << 8 | cc << 13 | valid << 15
-#pragma unroll
-    for (int e = 0; e < NSL; ++e) {
-        const int q = e * 256 + tid;
-        const int p = q >> 2;
-        const int j = p / ROW;
-        const int ii = p - j * ROW;
-        const int cp = ii >= PW + 2 ? 1 : 0;
-        const int m = ii - cp * (PW + 2);
-        const int cc = (q & 3) ^ (((ii >> 2) & 1) << 1);
-        const int valid = j < PH + 2 ? 1 : 0;
-        wstat[e] = (uint32_t)((2 * m + cp) | ((j & 31) << 8) | (cc << 13) | (valid << 15));
-    }
-    auto tile_offsets = [&](int g, int yy, int xx) __attribute__((always_inline)) {
-#pragma unroll
-        for (int e = 0; e < NSL; ++e) {
-            soff0[e] = soff1[e] = 0x80000000u;             // out of range -> the DMA writes zeros
-            const uint32_t ws = wstat[e];
-            const int j = (ws >> 8) & 31, cc = (ws >> 13) & 3;
-            const int ix = 2 * xx - 2 + (int)(ws & 255);
-            const int iy = 2 * yy - 2 + 2 * j;
-            if ((ws >> 15) && g < a.N && (unsigned)ix < (unsigned)a.Wi) {
-                const uint32_t o = (uint32_t)((((g * a.Hi + iy) * a.Wi + ix) * a.Ci + cc * 8) * 2);
-                if ((unsigned)iy < (unsigned)a.Hi) soff0[e] = o;
-                if (j < PH + 1 && (unsigned)(iy + 1) < (unsigned)a.Hi) soff1[e] = o + (uint32_t)(a.Wi * a.Ci * 2);
-            }
-        }
-    };
-    tile_offsets(grp, y0, x0);
-    const uint32_t lds_wave = lds0 + wave * 1024;
-    // slice E of sub-chunk `sub`, phase RP, into window buffer RP
-    auto load_slice = [&](auto RP_, int sub, auto E_) __attribute__((always_inline)) {
-        constexpr int rp = decltype(RP_)::value, e = decltype(E_)::value;
-        if constexpr (e < NSL) wdma(srd_in, rp ? soff1[e] : soff0[e], (uint32_t)sub * 64u, lds_wave + rp * WINB + e * 4096);
-    };
-
-    // ---- weight DMA: tap slot = [128 co][32 ch] = 8 KB, 64 rows per block instruction; chunk swizzle 2*bit2(row)
-    const int trow = tid >> 2;
-    const int wcc = (tid & 3) ^ (((trow >> 2) & 1) << 1);
-    const uint32_t vw = (uint32_t)(((co0 + trow) * a.Kpad + wcc * 8) * 2);
-    const uint32_t rs64 = (uint32_t)(a.Kpad * 128);      // 64 rows
-    const int Ci2 = a.Ci * 2;
-    // piece PC (tap slot * 2 + 64-row half) of taps [T0, T0 + 2) (those < 25) of sub-chunk `sub` into ring stage STG
-    auto load_w_piece = [&](auto STG_, auto T0_, auto PC_, int sub) __attribute__((always_inline)) {
-        constexpr int stg = decltype(STG_)::value, t0 = decltype(T0_)::value, pc = decltype(PC_)::value;
-        constexpr int s = pc >> 1, i = pc & 1;
-        if constexpr (t0 + s < 25) {
-            constexpr int tap = w5_ky(t0 + s) * 5 + w5_kx(t0 + s);
-            const uint32_t so = (uint32_t)(tap * Ci2 + sub * 64);
-            wdma(srd_w, vw, so + i * rs64, lds_wave + WBUF0 + stg * W_BYTES + s * 8192 + i * 4096);
-        }
-    };
-
-    const int wm = wave >> 1, wn = wave & 1;
+    float vsum = 0.f, vsq = 0.f;         // compute waves: statistics over all tiles of the block
+    const int wm = (wave >> 1) & 1, wn = wave & 1;
     const int frow = lane & 15, fq = lane >> 4;
+    int grp0, ty0, tx0;
+    tile_geom(tile0, grp0, ty0, tx0);
+    const int sgrp = (STATS != 0 && a.st.group_n > 0) ? grp0 / a.st.group_n : 0;   // statistics group of the block's tiles
 #ifdef FMRI_STAMP
     unsigned long long st_sync = 0, st_pend = 0, st_first = 0, st_epi = 0, st_steps = 0, k0, k1, r0, r1;
     FMRI_STAMP_AT(k0);
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r0)::"memory");
 #endif
 
-    // ---- A fragment addresses: abase[kx] for tile row wm*8 (row tile tm adds tm * ROW * 64, a window row shift sy adds
-    // sy * ROW * 64: immediates)
-    uint32_t abase[5];
-#pragma unroll
-    for (int kx = 0; kx < 5; ++kx) {
-        const int ii = (kx & 1) * (PW + 2) + frow + (kx >> 1);
-        const int p = (wm * 8) * ROW + ii;
-        abase[kx] = (uint32_t)((p << 6) + ((fq ^ (((ii >> 2) & 1) << 1)) << 4));
-    }
-    // ---- B fragment address (row = wn*64 + tn*16 + frow)
-    const uint32_t boff = (uint32_t)(WBUF0 + (wn * (BN / WN) + frow) * 64 + ((fq ^ (((frow >> 2) & 1) << 1)) << 4));
+    if (loader) {
+        // =====================================================================================================
+        // loader waves: per K-step, wait for the operands of this step, meet the compute waves at the barrier (they are
+        // done with the ring stage and window rows about to be overwritten), issue the six DMA pieces of the step
+        // =====================================================================================================
+        const int tid = threadIdx.x & 255;
+        const int lw = wave - 4;
+        const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+        v4i srd_in, srd_w;
+        srd_in.x = (int)(uint32_t)(uintptr_t)a.in;
+        srd_in.y = (int)(uint32_t)((uintptr_t)a.in >> 32);
+        srd_in.z = (int)a.in_bytes;
+        srd_in.w = 0x00020000;
+        srd_w.x = (int)(uint32_t)(uintptr_t)a.w;
+        srd_w.y = (int)(uint32_t)((uintptr_t)a.w >> 32);
+        srd_w.z = (int)a.w_bytes;
+        srd_w.w = 0x00020000;
 
-    f4 acc[TN][TM];
+        // ---- window DMA: 16-B unit q = e*256 + tid of a window buffer holds channels 8*cc .. 8*cc+7 (of the 32-channel
+        // sub-chunk) of window pixel p = q >> 2 = row j, column position ii; cc = (q & 3) ^ 2*bit2(ii).
+        // Column position ii < PW + 2: input column 2*x0 - 2 + 2*ii; else 2*x0 - 1 + 2*(ii - PW - 2).  Row j of phase rp:
+        // input row 2*y0 - 2 + rp + 2*j (the odd phase has PH + 1 rows).
+        uint32_t soff0[NSL], soff1[NSL];
+        uint32_t wstat[NSL];                  // column term | row << 8 | cc << 13 | valid << 15
 #pragma unroll
-    for (int i = 0; i < TN; ++i)
+        for (int e = 0; e < NSL; ++e) {
+            const int q = e * 256 + tid;
+            const int p = q >> 2;
+            const int j = p / ROW;
+            const int ii = p - j * ROW;
+            const int cp = ii >= PW + 2 ? 1 : 0;
+            const int m = ii - cp * (PW + 2);
+            const int cc = (q & 3) ^ (((ii >> 2) & 1) << 1);
+            const int valid = j < PH + 2 ? 1 : 0;
+            wstat[e] = (uint32_t)((2 * m + cp) | ((j & 31) << 8) | (cc << 13) | (valid << 15));
+        }
+        auto tile_offsets = [&](int g, int yy, int xx) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < TM; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+            for (int e = 0; e < NSL; ++e) {
+                soff0[e] = soff1[e] = 0x80000000u;             // out of range -> the DMA writes zeros
+                const uint32_t ws = wstat[e];
+                const int j = (ws >> 8) & 31, cc = (ws >> 13) & 3;
+                const int ix = 2 * xx - 2 + (int)(ws & 255);
+                const int iy = 2 * yy - 2 + 2 * j;
+                if ((ws >> 15) && g < a.N && (unsigned)ix < (unsigned)a.Wi) {
+                    const uint32_t o = (uint32_t)((((g * a.Hi + iy) * a.Wi + ix) * a.Ci + cc * 8) * 2);
+                    if ((unsigned)iy < (unsigned)a.Hi) soff0[e] = o;
+                    if (j < PH + 1 && (unsigned)(iy + 1) < (unsigned)a.Hi) soff1[e] = o + (uint32_t)(a.Wi * a.Ci * 2);
+                }
+            }
+        };
+        tile_offsets(grp0, ty0, tx0);
+        const uint32_t lds_wave = lds0 + lw * 1024;
+        // slice E of sub-chunk `sub`, phase RP, into window buffer RP
+        auto load_slice = [&](auto RP_, int sub, auto E_) __attribute__((always_inline)) {
+            constexpr int rp = decltype(RP_)::value, e = decltype(E_)::value;
+            if constexpr (e < NSL) wdma(srd_in, rp ? soff1[e] : soff0[e], (uint32_t)sub * 64u, lds_wave + rp * WINB + e * 4096);
+        };
+        // ---- weight DMA: tap slot = [128 co][32 ch] = 8 KB, 64 rows per instruction of the four waves; chunk swizzle
+        // 2*bit2(row)
+        const int trow = tid >> 2;
+        const int wcc = (tid & 3) ^ (((trow >> 2) & 1) << 1);
+        const uint32_t vw = (uint32_t)(((co0 + trow) * a.Kpad + wcc * 8) * 2);
+        const uint32_t rs64 = (uint32_t)(a.Kpad * 128);      // 64 rows
+        const int Ci2 = a.Ci * 2;
+        // piece PC (tap slot * 2 + 64-row half) of taps [T0, T0 + 2) (those < 25) of sub-chunk `sub` into ring stage stg
+        auto load_w_piece = [&](int stg, auto T0_, auto PC_, int sub) __attribute__((always_inline)) {
+            constexpr int t0 = decltype(T0_)::value, pc = decltype(PC_)::value;
+            constexpr int s = pc >> 1, i = pc & 1;
+            if constexpr (t0 + s < 25) {
+                constexpr int tap = w5_ky(t0 + s) * 5 + w5_kx(t0 + s);
+                const uint32_t so = (uint32_t)(tap * Ci2 + sub * 64);
+                wdma(srd_w, vw, so + i * rs64, lds_wave + WBUF0 + stg * W_BYTES + s * 8192 + i * 4096);
+            }
+        };
+        int stg = 0;                              // ring stage of the current step (wave-uniform)
+        // one 32-channel sub-chunk: 13 steps (schedule: w5_allow's comment)
+        auto feed_sub = [&](int sub, bool more, int nsubi, bool switch_tile, int ng, int ny, int nx)
+                            __attribute__((always_inline)) {
+            static_for_w<0, 13>([&](auto T_) __attribute__((always_inline)) {
+                constexpr int t = decltype(T_)::value;
+                constexpr int n_more = w5_allow(t, true, D), n_last = w5_allow(t, false, D);
+                if constexpr (n_more == n_last) wait_vmw<n_more>();
+                else { if (more) wait_vmw<n_more>(); else wait_vmw<n_last>(); }
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                int sd = stg + D;
+                if (sd >= NSTG) sd -= NSTG;
+                static_for_w<0, 4>([&](auto K_) __attribute__((always_inline)) {
+                    if constexpr (t + D < 13) {
+                        load_w_piece(sd, std::integral_constant<int, 2 * (t + D)>{}, K_, sub);
+                    } else {
+                        if (more) load_w_piece(sd, std::integral_constant<int, 2 * (t + D - 13)>{}, K_, nsubi);
+                    }
+                });
+                if constexpr (t <= 4) {
+                    load_slice(std::integral_constant<int, 1>{}, sub, std::integral_constant<int, 2 * t>{});
+                    load_slice(std::integral_constant<int, 1>{}, sub, std::integral_constant<int, 2 * t + 1>{});
+                } else if constexpr (t == 6) {
+                    if (switch_tile) tile_offsets(ng, ny, nx);
+                } else if constexpr (w5_ev_n(t) > 0) {
+                    if (more)
+                        static_for_w<0, w5_ev_n(t)>([&](auto J_) __attribute__((always_inline)) {
+                            load_slice(std::integral_constant<int, 0>{}, nsubi, std::integral_constant<int, w5_ev_0(t) + decltype(J_)::value>{});
+                        });
+                }
+                stg = stg + 1 == NSTG ? 0 : stg + 1;
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+        // prologue: even-row window of the first tile's sub-chunk 0 and the weights of the first D steps, all landed
+        static_for_w<0, NSL>([&](auto E_) __attribute__((always_inline)) { load_slice(std::integral_constant<int, 0>{}, 0, E_); });
+        static_for_w<0, D>([&](auto S_) __attribute__((always_inline)) {
+            static_for_w<0, 4>([&](auto K_) __attribute__((always_inline)) {
+                load_w_piece(decltype(S_)::value, std::integral_constant<int, 2 * decltype(S_)::value>{}, K_, 0);
+            });
+        });
+        wait_vmw<0>();
+        int tile = tile0, sub = 0;
+        int ng = 0, ny = 0, nx = 0;
+        if (tile + 1 < tile1) tile_geom(tile + 1, ng, ny, nx);
+        while (tile < tile1) {
+            const bool next_tile = tile + 1 < tile1;
+            const bool last_sub = sub + 1 >= nsub;
+            feed_sub(sub, !last_sub || next_tile, last_sub ? 0 : sub + 1, last_sub && next_tile, ng, ny, nx);
+            ++sub;
+            if (last_sub) {
+                sub = 0;
+                ++tile;
+                if (tile + 1 < tile1) tile_geom(tile + 1, ng, ny, nx);
+            }
+        }
+    } else {
+        // =====================================================================================================
+        // compute waves: LDS fragment reads and MFMAs only
+        // =====================================================================================================
+        int grp = grp0, y0 = ty0, x0 = tx0;
+        // ---- A fragment addresses: abase[kx] for tile row wm*8 (row tile tm adds tm * ROW * 64, a window row shift sy
+        // adds sy * ROW * 64: immediates)
+        uint32_t abase[5];
+#pragma unroll
+        for (int kx = 0; kx < 5; ++kx) {
+            const int ii = (kx & 1) * (PW + 2) + frow + (kx >> 1);
+            const int p = (wm * 8) * ROW + ii;
+            abase[kx] = (uint32_t)((p << 6) + ((fq ^ (((ii >> 2) & 1) << 1)) << 4));
+        }
+        // ---- B fragment address (row = wn*64 + tn*16 + frow)
+        const uint32_t boff = (uint32_t)(WBUF0 + (wn * (BN / WN) + frow) * 64 + ((fq ^ (((frow >> 2) & 1) << 1)) << 4));
 
-    // ---- the pending second tap slot of the previous K-step (all zeros: nothing pending)
-    h8 paf[TM], pbf[TN];
+        f4 acc[TN][TM];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) paf[i] = (h8)(half_t)0.f;
+        for (int i = 0; i < TN; ++i)
 #pragma unroll
-    for (int i = 0; i < TN; ++i) pbf[i] = (h8)(half_t)0.f;
-    auto pending_mfma = [&](auto M_) __attribute__((always_inline)) {
-        constexpr int m = decltype(M_)::value, tn = m / TM, tm = m % TM;
-        acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pbf[tn], paf[tm], acc[tn][tm], 0, 0, 0);
-    };
-    auto drain_pending = [&]() __attribute__((always_inline)) {
-        static_for_w<0, TM * TN>([&](auto M_) __attribute__((always_inline)) { pending_mfma(M_); });
+            for (int j = 0; j < TM; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+
+        // ---- the pending second tap slot of the previous K-step (all zeros: nothing pending)
+        h8 paf[TM], pbf[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) paf[i] = (h8)(half_t)0.f;
 #pragma unroll
         for (int i = 0; i < TN; ++i) pbf[i] = (h8)(half_t)0.f;
-    };
-
-    // one K-step: taps T0, T0 + 1 (those < 25), weights in ring stage STG; `piece(K)` issues DMA instruction K of the step
-    auto step = [&](auto T0_, auto STG_, auto&& piece) __attribute__((always_inline)) {
-        constexpr int t0 = decltype(T0_)::value, stg = decltype(STG_)::value;
-        constexpr int NS = t0 + 1 < 25 ? 2 : 1;
-        h8 af0[TM], bf0[TN];
-        {
-            constexpr int ky = w5_ky(t0), kx = w5_kx(t0);
-            const char* Ps = smem + (ky & 1) * WINB + (ky >> 1) * (ROW * 64);
-            const char* Ws = smem + stg * W_BYTES;
+        auto pending_mfmas = [&]() __attribute__((always_inline)) {
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm) af0[tm] = *(const h8*)(Ps + abase[kx] + tm * (ROW * 64));
+            for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn) bf0[tn] = *(const h8*)(Ws + (boff + tn * 1024));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#ifdef FMRI_STAMP
-        unsigned long long tb, tc, td;
-        FMRI_STAMP_AT(tb);
-#endif
-        // pending MFMAs with the six DMA pieces between them
-        static_for_w<0, TM * TN>([&](auto M_) __attribute__((always_inline)) {
-            constexpr int m = decltype(M_)::value;
-            pending_mfma(M_);
-            constexpr int k = m == 4 ? 0 : m == 9 ? 1 : m == 14 ? 2 : m == 19 ? 3 : m == 24 ? 4 : m == 29 ? 5 : -1;
-            if constexpr (k >= 0) {
-                __builtin_amdgcn_sched_barrier(0);
-                piece(std::integral_constant<int, k>{});
-                __builtin_amdgcn_sched_barrier(0);
+                for (int tm = 0; tm < TM; ++tm)
+                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pbf[tn], paf[tm], acc[tn][tm], 0, 0, 0);
+        };
+        auto clear_pending = [&]() __attribute__((always_inline)) {
+            if constexpr (C5W_ABL == 2) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) paf[i] = (h8)(half_t)(0.37f * (float)((lane * 7 + i) & 15) - 2.f);
+#pragma unroll
+                for (int i = 0; i < TN; ++i) pbf[i] = (h8)(half_t)(0.011f * (float)((lane * 5 + i) & 15) - 0.08f);
+                return;
             }
-        });
-#ifdef FMRI_STAMP
-        FMRI_STAMP_AT(tc);
-#endif
-        // first-slot MFMAs; the second slot's 12 fragment reads (into the pending registers) between the first 12
-        if constexpr (NS == 2) {
-            constexpr int ky = w5_ky(t0 + 1), kx = w5_kx(t0 + 1);
-            const char* Ps = smem + (ky & 1) * WINB + (ky >> 1) * (ROW * 64);
-            const char* Ws = smem + stg * W_BYTES + 8192;
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm) paf[tm] = *(const h8*)(Ps + abase[kx] + tm * (ROW * 64));
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) pbf[tn] = *(const h8*)(Ws + (boff + tn * 1024));
-        } else {
 #pragma unroll
             for (int i = 0; i < TM; ++i) paf[i] = (h8)(half_t)0.f;
 #pragma unroll
             for (int i = 0; i < TN; ++i) pbf[i] = (h8)(half_t)0.f;
-        }
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-                acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf0[tn], af0[tm], acc[tn][tm], 0, 0, 0);
-        if constexpr (NS == 2) {
-#pragma unroll
-            for (int i = 0; i < TM + TN; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - 2 * (TM + TN), 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#ifdef FMRI_STAMP
-        FMRI_STAMP_AT(td);
-        st_pend += tc - tb; st_first += td - tc; st_steps += 1;
-#endif
-    };
+        };
 
-    // ---- one 32-channel sub-chunk: 13 steps.  P = parity of the sub-chunk (ring stage of step t = (P + t) & 1).
-    // Window traffic: steps 0-4 bring this sub-chunk's odd-row window (buffer 1, first read in step 7), two slices per step;
-    // steps 8-12 the next sub-chunk's even-row window (buffer 0, last read in step 7).  Waits: a step leaves the two window
-    // slices issued behind the previous step's weight pieces in flight.
-    const int nsub = a.nsub;
-    auto run_sub = [&](auto P_, int sub, bool more, int nsubi, bool switch_tile, int ng, int ny, int nx, bool landed)
-                       __attribute__((always_inline)) {
-        constexpr int P = decltype(P_)::value;
-        static_for_w<0, 13>([&](auto T_) __attribute__((always_inline)) {
-            constexpr int t = decltype(T_)::value;
-            constexpr int stg = (P + t) & 1;
-            constexpr int prev_n = (t >= 1 && t <= 5) ? 2 : ((t >= 9) ? 2 : 0);
-            constexpr bool prev_cond = t >= 9;             // ... only when another (tile, sub-chunk) follows
-#ifdef FMRI_STAMP
-            unsigned long long ta, tb0;
-            FMRI_STAMP_AT(ta);
-#endif
-            if constexpr (t == 0) { if (!landed) wait_vmw<0>(); }
-            else if constexpr (prev_n == 0) wait_vmw<0>();
-            else if constexpr (prev_cond) { if (more) wait_vmw<prev_n>(); else wait_vmw<0>(); }
-            else wait_vmw<prev_n>();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+        // one K-step: taps T0, T0 + 1 (those < 25), weights in ring stage STG.  The first slot's 12 fragment reads go out
+        // first and land under the pending slot's 32 MFMAs; the second slot's reads sit between the first slot's MFMAs
+        auto step = [&](auto T0_, uint32_t wb) __attribute__((always_inline)) {
+            constexpr int t0 = decltype(T0_)::value;
+            constexpr int NS = t0 + 1 < 25 ? 2 : 1;
+            h8 af0[TM], bf0[TN];
+            if constexpr (C5W_ABL == 2) {
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) af0[tm] = paf[tm];
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) bf0[tn] = pbf[tn];
+            } else {
+                constexpr int ky = w5_ky(t0), kx = w5_kx(t0);
+                const char* Ps = smem + (ky & 1) * WINB + (ky >> 1) * (ROW * 64);
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) af0[tm] = *(const h8*)(Ps + abase[kx] + tm * (ROW * 64));
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) bf0[tn] = *(const h8*)(smem + (wb + tn * 1024));
+            }
+#if !C5W_HALFA
             __builtin_amdgcn_sched_barrier(0);
-#ifdef FMRI_STAMP
-            FMRI_STAMP_AT(tb0);
-            st_sync += tb0 - ta;
 #endif
-            // DMA pieces of this step, in issue order: 4 weight pieces of the next step, then 2 window slices
-            auto piece = [&](auto K_) __attribute__((always_inline)) {
-                constexpr int k = decltype(K_)::value;
-                if constexpr (k < 4) {
-                    if constexpr (t < 12) {
-                        load_w_piece(std::integral_constant<int, stg ^ 1>{}, std::integral_constant<int, 2 * t + 2>{}, K_, sub);
-                    } else {
-                        if (more) load_w_piece(std::integral_constant<int, stg ^ 1>{}, std::integral_constant<int, 0>{}, K_, nsubi);
-                    }
-                } else {
-                    constexpr int j = k - 4;                      // 0, 1
-                    if constexpr (t <= 4) {
-                        load_slice(std::integral_constant<int, 1>{}, sub, std::integral_constant<int, 2 * t + j>{});
-                    } else if constexpr (t == 6) {
-                        if constexpr (j == 0) { if (switch_tile) tile_offsets(ng, ny, nx); }
-                    } else if constexpr (t >= 8) {
-                        if (more) load_slice(std::integral_constant<int, 0>{}, nsubi, std::integral_constant<int, 2 * (t - 8) + j>{});
+#if defined(FMRI_STAMP) && FMRI_STAMP >= 2
+            unsigned long long tb, tc, td;
+            FMRI_STAMP_AT(tb);
+#endif
+            pending_mfmas();
+#if C5W_HALFA
+            if constexpr (C5W_ABL != 2) {
+                // the reads one by one between the first MFMAs, not as a burst in front of them
+#pragma unroll
+                for (int i = 0; i < TM + TN; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - 2 * (TM + TN), 0);
+            }
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+#if defined(FMRI_STAMP) && FMRI_STAMP >= 2
+            FMRI_STAMP_AT(tc);
+#endif
+            if constexpr (C5W_ABL == 2) {
+            } else if constexpr (NS == 2) {
+                constexpr int ky = w5_ky(t0 + 1), kx = w5_kx(t0 + 1);
+                const char* Ps = smem + (ky & 1) * WINB + (ky >> 1) * (ROW * 64);
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) paf[tm] = *(const h8*)(Ps + abase[kx] + tm * (ROW * 64));
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) pbf[tn] = *(const h8*)(smem + (wb + 8192 + tn * 1024));
+            } else {
+                clear_pending();
+            }
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf0[tn], af0[tm], acc[tn][tm], 0, 0, 0);
+            if constexpr (NS == 2) {
+#pragma unroll
+                for (int i = 0; i < TM + TN; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - 2 * (TM + TN), 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#if defined(FMRI_STAMP) && FMRI_STAMP >= 2
+            FMRI_STAMP_AT(td);
+            st_pend += tc - tb; st_first += td - tc; st_steps += 1;
+#endif
+        };
+        int stg = 0;                              // ring stage of the current step (wave-uniform)
+        auto run_sub = [&]() __attribute__((always_inline)) {
+            static_for_w<0, 13>([&](auto T_) __attribute__((always_inline)) {
+                constexpr int t = decltype(T_)::value;
+#if defined(FMRI_STAMP) && FMRI_STAMP >= 2
+                unsigned long long ta, tb0;
+                FMRI_STAMP_AT(ta);
+#endif
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+#if defined(FMRI_STAMP) && FMRI_STAMP >= 2
+                FMRI_STAMP_AT(tb0);
+                st_sync += tb0 - ta;
+#endif
+                step(std::integral_constant<int, 2 * t>{}, boff + (uint32_t)(stg * W_BYTES));
+                stg = stg + 1 == NSTG ? 0 : stg + 1;
+            });
+        };
+
+        // ---- epilogue: D[i = co][j = tile pixel] -> NHWC fp16 (no bias / activation: BatchNorm or a data gradient follows)
+        // Buffer stores: one 32-bit offset per lane and tile (0x80000000 = dropped by the range check), the row of the
+        // tile as the scalar offset; FULL: every channel of the block exists (Co, CoStore multiples of 128)
+        typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+        const __amdgpu_buffer_rsrc_t srd_out = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)a.out, 0, (int)((uint32_t)a.N * (uint32_t)a.Ho * (uint32_t)a.Wo * (uint32_t)a.CoStore * 2u), 0x00020000);
+        const uint32_t row_b = (uint32_t)(a.Wo * a.CoStore * 2);
+        const bool full_co = ((a.Co | a.CoStore) & 127) == 0;
+        auto epi_body = [&](auto FULL_) __attribute__((always_inline)) {
+            constexpr bool FULL = decltype(FULL_)::value;
+            const int x = x0 + frow;
+            const bool xok = grp < a.N && x < a.Wo;
+            const int yb = y0 + wm * 8;
+            const int cw = co0 + wn * (BN / WN) + fq * 4;
+            const uint32_t vo = xok ? (uint32_t)(((((C5W_ABL == 5 ? 0 : grp) * a.Ho + yb) * a.Wo + x) * a.CoStore + cw) * 2) : 0x80000000u;
+            const int nrow = a.Ho - yb;                      // tile rows tm < nrow exist (wave-uniform)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int co = cw + tn * 16;
+                uint32_t vt = vo + tn * 32;
+                if constexpr (!FULL) { if (co >= a.CoStore) vt = 0x80000000u; }
+                f4 s0 = (f4){0.f, 0.f, 0.f, 0.f}, s1 = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+                    if (tm < nrow) {
+                        const f4 v = acc[tn][tm];
+                        h4 hv;
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg) hv[rg] = (half_t)((FULL || co + rg < a.Co) ? v[rg] : 0.f);
+                        if constexpr (STATS == 1) {
+                            // statistics of the STORED (fp16-rounded) values: what the consumers and the BN backward see
+#pragma unroll
+                            for (int rg = 0; rg < 4; ++rg) {
+                                const float f = xok ? (float)hv[rg] : 0.f;
+                                s0[rg] += f;
+                                s1[rg] += f * f;
+                            }
+                        }
+                        if (C5W_ABL == 1 && a.N > 0) continue;
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, hv), srd_out, (int)vt, (int)(tm * row_b), 0);
                     }
                 }
-            };
-            step(std::integral_constant<int, 2 * t>{}, std::integral_constant<int, stg>{}, piece);
-        });
-    };
-
-    // ---- epilogue: D[i = co][j = tile pixel] -> NHWC fp16 (no bias / activation: BatchNorm or a data gradient follows)
-    float vsum = 0.f, vsq = 0.f;         // over all tiles of the block
-    const int sgrp = (STATS != 0 && a.st.group_n > 0) ? grp / a.st.group_n : 0;     // statistics group of the block's tiles
-    auto epilogue = [&]() __attribute__((always_inline)) {
-        const int x = x0 + frow;
-        const bool xok = grp < a.N && x < a.Wo;
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const int co = co0 + wn * (BN / WN) + tn * 16 + fq * 4;
-            if (co >= a.CoStore) continue;
-            f4 s0 = (f4){0.f, 0.f, 0.f, 0.f}, s1 = (f4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm) {
-                const int y = y0 + wm * 8 + tm;
-                if (!xok || y >= a.Ho) continue;
-                const f4 v = acc[tn][tm];
-                h4 hv;
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg) hv[rg] = (half_t)(co + rg < a.Co ? v[rg] : 0.f);
-                if constexpr (STATS == 1) {
-                    // statistics of the STORED (fp16-rounded) values: what the consumers and the BN backward see
+                if constexpr (STATS != 0) {
 #pragma unroll
                     for (int rg = 0; rg < 4; ++rg) {
-                        const float f = (float)hv[rg];
-                        s0[rg] += f;
-                        s1[rg] += f * f;
+                        const float ra = row16_sum(s0[rg]);
+                        const float rb = row16_sum(s1[rg]);
+                        if (frow == tn * 4 + rg) { vsum += ra; vsq += rb; }
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                *(h4*)(a.out + (((int64_t)grp * a.Ho + y) * a.Wo + x) * a.CoStore + co) = hv;
             }
-            if constexpr (STATS != 0) {
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    const float ra = row16_sum(s0[rg]);
-                    const float rb = row16_sum(s1[rg]);
-                    if (frow == tn * 4 + rg) { vsum += ra; vsq += rb; }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    };
+        };
+        auto epilogue = [&]() __attribute__((always_inline)) {
+            if (full_co) epi_body(std::true_type{});
+            else epi_body(std::false_type{});
+        };
 
-    // prologue: even-row window of the first tile's sub-chunk 0 and the first weight tiles
-    static_for_w<0, NSL>([&](auto E_) __attribute__((always_inline)) { load_slice(std::integral_constant<int, 0>{}, 0, E_); });
-    static_for_w<0, 4>([&](auto K_) __attribute__((always_inline)) {
-        load_w_piece(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, K_, 0);
-    });
-    int tile = tile0, sub = 0;
-    bool landed = false;
-    int ng = 0, ny = 0, nx = 0;
-    if (tile + 1 < tile1) tile_geom(tile + 1, ng, ny, nx);
-    auto one = [&](auto P_) __attribute__((always_inline)) {
-        const bool next_tile = tile + 1 < tile1;
-        const bool last_sub = sub + 1 >= nsub;
-        run_sub(P_, sub, !last_sub || next_tile, last_sub ? 0 : sub + 1, last_sub && next_tile, ng, ny, nx, landed);
-        ++sub;
-        landed = false;
-        if (last_sub) {
-            drain_pending();                                     // the last step's second tap slot
-            if (next_tile) { wait_vmw<0>(); landed = true; }     // the next tile's first window and weights
-#ifdef FMRI_STAMP
-            unsigned long long te0, te1;
-            FMRI_STAMP_AT(te0);
+        int tile = tile0, sub = 0;
+        int ng = 0, ny = 0, nx = 0;
+        if (tile + 1 < tile1) tile_geom(tile + 1, ng, ny, nx);
+        while (tile < tile1) {
+            const bool last_sub = sub + 1 >= nsub;
+            run_sub();
+            ++sub;
+            if (last_sub) {
+                pending_mfmas();                                     // the last step's second tap slot
+                clear_pending();
+#if defined(FMRI_STAMP) && FMRI_STAMP >= 2
+                unsigned long long te0, te1;
+                FMRI_STAMP_AT(te0);
 #endif
-            epilogue();
-#ifdef FMRI_STAMP
-            FMRI_STAMP_AT(te1);
-            st_epi += te1 - te0;
+                epilogue();
+#if defined(FMRI_STAMP) && FMRI_STAMP >= 2
+                FMRI_STAMP_AT(te1);
+                st_epi += te1 - te0;
 #endif
 #pragma unroll
-            for (int i = 0; i < TN; ++i)
+                for (int i = 0; i < TN; ++i)
 #pragma unroll
-                for (int j = 0; j < TM; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
-            grp = ng; y0 = ny; x0 = nx;
-            sub = 0;
-            ++tile;
-            if (tile + 1 < tile1) tile_geom(tile + 1, ng, ny, nx);
+                    for (int j = 0; j < TM; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+                grp = ng; y0 = ny; x0 = nx;
+                sub = 0;
+                ++tile;
+                if (tile + 1 < tile1) tile_geom(tile + 1, ng, ny, nx);
+            }
         }
-    };
-    while (tile < tile1) {
-        one(std::integral_constant<int, 0>{});
-        if (tile < tile1) one(std::integral_constant<int, 1>{});
     }
 #ifdef FMRI_STAMP
     FMRI_STAMP_AT(k1);
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r1)::"memory");
-    if (lane == 0) {
+    if (lane == 0 && !loader) {
         atomicAdd(&c5w_stamp_acc[0], st_sync); atomicAdd(&c5w_stamp_acc[1], st_pend); atomicAdd(&c5w_stamp_acc[2], st_first);
         atomicAdd(&c5w_stamp_acc[3], st_epi); atomicAdd(&c5w_stamp_acc[4], st_steps); atomicAdd(&c5w_stamp_acc[5], 1ull);
         atomicAdd(&c5w_stamp_acc[6], k1 - k0); atomicAdd(&c5w_stamp_acc[7], r1 - r0);
     }
 #endif
     if constexpr (STATS != 0) {
-        // one row per block; the blocks of one statistics group are contiguous (tpg[0] = blocks per group).  The lane that
-        // owns channel (frow >> 2)*16 + fq*4 + (frow & 3) of the wave's 64 holds its sums; the two pixel halves (wm) meet
-        // in LDS (stat_store)
-        const int prow = bx - sgrp * a.st.tpg[0];
-        stat_store<TN, WM, WN>(vsum, vsq, lane, wm, wn, co0, (float*)smem,
-                               a.st.part + ((size_t)sgrp * a.st.rows_cap + prow) * 2 * a.st.C, a.st.C);
+        // one row per block; the blocks of one statistics group are contiguous (tpg[0] = blocks per group).  Compute lane
+        // (fq, frow) owns channel (frow >> 2)*16 + fq*4 + (frow & 3) of its wave's 64; the two pixel halves (wm) meet in LDS
+        float* scratch = (float*)smem;
+        const int ch = (frow >> 2) * 16 + fq * 4 + (frow & 3);
+        __syncthreads();                                     // everyone is done with the operand tiles
+        if (!loader && wm == 1) {
+            scratch[wn * 128 + ch] = vsum;
+            scratch[wn * 128 + 64 + ch] = vsq;
+        }
+        __syncthreads();
+        if (!loader && wm == 0) {
+            vsum += scratch[wn * 128 + ch];
+            vsq += scratch[wn * 128 + 64 + ch];
+            const int co = co0 + wn * 64 + ch;
+            float* row = a.st.part + ((size_t)sgrp * a.st.rows_cap + (bx - sgrp * a.st.tpg[0])) * 2 * a.st.C;
+            if (co < a.st.C) {
+                row[co] = vsum;
+                row[a.st.C + co] = vsq;
+            }
+        }
     }
 }
 
 template <int STATS>
 static int launch_c5w(const C5Args& a, int copad, hipStream_t st) {
     auto kern = igemm_c5w_kernel<STATS>;
-    constexpr int lds = 2 * 10 * 4096 + 2 * 16384;
+    constexpr int lds = 2 * 10 * 4096 + C5W_NSTG * 16384;
     // raising the dynamic-LDS limit is idempotent; every call sets it (no library-global state)
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return E_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3((a.ntiles + a.tpb - 1) / a.tpb, copad / 128, 1), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3((a.ntiles + a.tpb - 1) / a.tpb, copad / 128, 1), dim3(512), lds, st, a);
     return hipGetLastError() == hipSuccess ? OK : E_LAUNCH;
 }
 
@@ -460,6 +564,7 @@ static int launch_c5w(const C5Args& a, int copad, hipStream_t st) {
 // C5Args with tiles_y = ceil(Ho / 16), tiles_x = ceil(Wo / 16), ntiles = N * tiles_y * tiles_x.
 int igemm_c5w_launch(const C5Args& a, int copad, hipStream_t st) {
     if (a.nsub < 1 || (copad & 127) || a.ntiles < 1 || a.tpb < 1 || a.bb.x) return E_UNSUPPORTED;
+    if ((int64_t)a.N * a.Ho * a.Wo * a.CoStore * 2 >= 0x7fffffffLL) return E_UNSUPPORTED;      // 32-bit store offsets
     return a.st.part ? launch_c5w<1>(a, copad, st) : launch_c5w<0>(a, copad, st);
 }
 

@@ -1,6 +1,6 @@
 """Diagnostic (GPU box): where a wave of igemm_c5w spends its cycles inside a K-step, and the clock the chip holds
 (s_memtime / s_memrealtime stamps, FMRI_STAMP in csrc/igemm_c5w.hip).  Uses tools/probes/libfmri_stamp.so
-(tools/probes/build_stamp_lib.sh igemm_c5w).  The stamp build's fences forbid overlaps the real kernel has: read the
+(tools/probes/build_variant.sh stamp igemm_c5w -DFMRI_STAMP=2; VARIANT=<name> picks another build).  The stamp build's fences forbid overlaps the real kernel has: read the
 SHARES, not the run time."""
 import ctypes, os, sys
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "thesis-fmri-rec
 os.environ.setdefault("FMRI_C5W", "all")
 import torch
 from fmri_hip import lib
-lib.LIB_PATH = os.path.join(ROOT, "tools", "probes", "libfmri_stamp.so")
+lib.LIB_PATH = os.path.join(ROOT, "tools", "probes", "libfmri_%s.so" % os.environ.get("VARIANT", "stamp"))
 from fmri_hip import ops
 L = lib.load()
 L.fmri_debug_c5w_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -38,7 +38,7 @@ def run(cin, cout, N, H, stats, reps=200):
     e1.record(); torch.cuda.synchronize()
     L.fmri_debug_c5w_stamps(out, 1)
     sync, pend, first, epi, steps, waves, kc, kr = [int(v) for v in out[:8]]
-    tot = sync + pend + first + epi
+    tot = max(sync + pend + first + epi, 1); steps = max(steps, 1)
     ms = e0.elapsed_time(e1) / 20
     fl = 2.0 * N * (H // 2) ** 2 * cin * cout * 25
     print(f"conv {cin}->{cout} N={N} {H}px stats={stats} zero={ZERO}: {ms*1e3:7.1f} us ({fl/ms/1e9:6.1f} TF/s, stamped build) clock {kc/kr*0.1:.2f} GHz "
@@ -47,5 +47,6 @@ def run(cin, cout, N, H, stats, reps=200):
 
 
 run(128, 256, 768, 32, False)
-run(128, 256, 768, 32, True)
-run(32, 128, 768, 64, True)
+if os.environ.get("ALL"):
+    run(128, 256, 768, 32, True)
+    run(32, 128, 768, 64, True)

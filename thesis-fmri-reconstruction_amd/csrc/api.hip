@@ -389,6 +389,29 @@ int fmri_igemm_ep(const void* in, const void* w, void* out, const float* bias, c
             if (q.st.tpg[0] > se.rows_cap) q.st.part = nullptr;
         }
         if (!q.st.part) q.bb.x = nullptr;       // no statistics rows: plain output (*ep_done = 0 tells the caller)
+        // wide form (csrc/igemm_tc5w.hip): 16 x 16-position tiles, one 8-wave block per CU, loader / compute waves;
+        // FMRI_TC5W=off disables
+        static const char* tc5w_env = getenv("FMRI_TC5W");
+        static const bool no_tc5w = tc5w_env && !strcmp(tc5w_env, "off");
+        if (ok && !no_tc5w && bn_tile == 128 && Xc0 > 8 && Yc0 > 8 && !q.bb.x && !(q.nchunks & 1)) {
+            Tc5Args w = q;
+            w.pw_log2 = 4; w.ph_log2 = 4; w.PH = 16; w.IPB = 1; w.IH = 18; w.IW = 18; w.nslice = 11;
+            w.tiles_x = (Xc0 + 15) / 16;
+            w.tiles_y = (Yc0 + 15) / 16;
+            w.ntiles = N * w.tiles_y * w.tiles_x;
+            w.fdTPI = make_fastdiv((uint32_t)(w.tiles_y * w.tiles_x));
+            w.fdTX = make_fastdiv((uint32_t)w.tiles_x);
+            w.st = se;
+            if (se.part) {
+                w.st.tpg[0] = se.group_n > 0 ? se.group_n * w.tiles_y * w.tiles_x : w.ntiles;
+                if (w.st.tpg[0] > se.rows_cap) w.st.part = nullptr;
+            }
+            if (w.st.part || !se.part) {
+                const int r = igemm_tc5w_launch(w, copad, S(stream));
+                if (r == OK && ep_done && w.st.part) *ep_done = w.st.tpg[0];
+                if (r != E_UNSUPPORTED) return r;
+            }
+        }
         if (ok && q.ntiles > 0) {
             const int r = igemm_tc5_launch(q, bn_tile, copad, S(stream));
             if (r == OK && ep_done && q.st.part) *ep_done = q.st.tpg[0];

@@ -1,0 +1,468 @@
+// Stride-2 transposed convolution (k5 p2), Ci % 128 == 0, 128-channel tiles, class grids wider than 8 on MFMA (gfx950):
+// WIDE form of igemm_tc5.hip -- one 8-wave block per CU owns 16 x 16 class-grid positions x 128 channels, four loader
+// waves feed four compute waves (wave tile 128 positions x 64 channels).
+//
+// Replaces (reference models/vae_gan.py): ConvTranspose2d(k5, s2, p2, output_padding 1) forward of decoder.conv.1
+// (:46-53, :112-116) and the data gradient of discriminator.conv.2 (:149-153), i.e. the 16-wide-tile launches of
+// igemm_tc5.hip with 128 output channels per block.
+//
+// Same recipe as igemm_c5w.hip (round 3): with two 4-wave blocks per CU every wave issued its own operand
+// DMA (~60 cycles of its instruction stream per 1 KB piece, 5 pieces per 32 MFMAs) and fetched 0.5 LDS fragments per
+// MFMA.  Here
+//   * waves 4-7 only move bytes (window slices, weight tiles: buffer_load ... lds, counted vmcnt), waves 0-3 only read
+//     fragments and issue MFMAs; one s_barrier per K-step joins them;
+//   * the wave tile is 8 x 4 MFMA tiles: 0.375 fragment reads per MFMA, 64 MFMAs per wave and K-step (one tap x 64 channels);
+//   * the second 32-channel half of a K-step stays pending in registers across the barrier: its 32 MFMAs cover the
+//     first half's fragment reads of the next step;
+//   * the window swizzle depends on the window COLUMN only, so that a tile row (and a tap's row shift) is an immediate
+//     of the ds_read: 6 address registers instead of igemm_tc5's 36;
+//   * outputs leave through buffer stores (one 32-bit offset per lane and class, the tile row as the scalar offset).
+// Everything else is igemm_tc5.hip's: the four parity classes (3x3, 3x2, 2x3, 2x2 unit-shift taps) run back to back over
+// the same (16 + 2)^2 window of 64-channel chunks (double-buffered), weights straight out of the per-class packed
+// matrices, BatchNorm forward statistics of the stored values summed over the four classes (StatEpi).
+#include "kernels.h"
+#include <type_traits>
+
+#ifndef TC5W_ABL
+#define TC5W_ABL 0      // diagnostic builds only: 1 no output stores, 2 no fragment reads, 3 no operand DMA, 4 no window DMA, 5 no weight DMA
+#endif
+
+namespace fmri {
+
+#ifdef FMRI_STAMP
+// Diagnostic build only (tools/probes/c5w_stamps.py; never shipped): [5] compute waves, [6] their cycles in the kernel
+// (s_memtime), [7] 100 MHz ticks (s_memrealtime)
+__device__ unsigned long long tc5w_stamp_acc[8];
+#endif
+
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for_t(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for_t<I + 1, N>(f);
+    }
+}
+
+__device__ __forceinline__ void tdma(v4i srd, uint32_t voff, uint32_t soff, uint32_t lds) {
+    srd.x = __builtin_amdgcn_readfirstlane(srd.x);
+    srd.y = __builtin_amdgcn_readfirstlane(srd.y);
+    srd.z = __builtin_amdgcn_readfirstlane(srd.z);
+    srd.w = __builtin_amdgcn_readfirstlane(srd.w);
+    soff = __builtin_amdgcn_readfirstlane(soff);
+    lds = __builtin_amdgcn_readfirstlane(lds);
+    if (TC5W_ABL == 3 && srd.z != 0x7fffffff) return;
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+                 ::"v"(voff), "s"(srd), "s"(soff), "s"(lds)
+                 : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmt() {
+    static_assert(N >= 0 && N <= 63, "vmcnt");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+}  // namespace
+
+// STATS: 0 none, 1 BatchNorm forward statistics (StatEpi)
+template <int STATS>
+__global__ __launch_bounds__(512, 1) void igemm_tc5w_kernel(const Tc5Args a) {
+    constexpr int BN = 128, WN = 2, TM = 8, TN = 4;
+    constexpr int PW = 16, PH = 16;
+    constexpr int IW = PW + 2;                           // window row, pixels (128 B each: one 64-channel chunk)
+    constexpr int ROWB = IW * 128;
+    constexpr int NSL = 11;                              // 4 KB DMA slices per window chunk ((PH + 2) * IW * 128 B = 41 472)
+    constexpr int WINB = NSL * 4096;
+    constexpr int W_BYTES = BN * 128;                    // one tap x 64 channels of [128 co]
+    constexpr int WBUF0 = 2 * WINB;
+    static_assert((PH + 2) * IW * 128 <= WINB, "window fits its slices");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool loader = wave >= 4;                        // waves 4-7 move bytes, waves 0-3 multiply
+    int bx, by;
+    xcd_tile(bx, by);
+    if (bx >= a.ntiles) return;
+    const int co0 = by * BN;
+
+    // ---- tile -> (image, tile row, tile column) of the class grid
+    const int tpi = a.tiles_y * a.tiles_x;
+    const int grp = (int)fd_div((uint32_t)bx, a.fdTPI);
+    const int trem = bx - grp * tpi;
+    const int tyi = (int)fd_div((uint32_t)trem, a.fdTX);
+    const int y0 = tyi * PH, x0 = (trem - tyi * a.tiles_x) * PW;
+    const int nch = a.nchunks;
+
+    float vsum = 0.f, vsq = 0.f;         // compute waves: statistics over the tile's valid pixels, all classes
+    const int wm = (wave >> 1) & 1, wn = wave & 1;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int sgrp = (STATS != 0 && a.st.group_n > 0) ? grp / a.st.group_n : 0;     // statistics group of the tile
+
+#ifdef FMRI_STAMP
+    unsigned long long k0, k1, r0, r1;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(k0), "=s"(r0)::"memory");
+#endif
+    if (loader) {
+        // =====================================================================================================
+        // loader waves: per K-step, wait for the operands of this step, meet the compute waves at the barrier (they are
+        // done with the ring stage and the window buffer about to be overwritten), issue the DMA of the step
+        // =====================================================================================================
+        const int tid = threadIdx.x & 255;
+        const int lw = wave - 4;
+        const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+        v4i srd_in, srd_w;
+        srd_in.x = (int)(uint32_t)(uintptr_t)a.in;
+        srd_in.y = (int)(uint32_t)((uintptr_t)a.in >> 32);
+        srd_in.z = (int)a.in_bytes;
+        srd_in.w = 0x00020000;
+        srd_w.x = (int)(uint32_t)(uintptr_t)a.w;
+        srd_w.y = (int)(uint32_t)((uintptr_t)a.w >> 32);
+        srd_w.z = (int)a.w_bytes;
+        srd_w.w = 0x00020000;
+
+        // ---- window DMA: 16-B unit q = e*256 + tid of a window buffer holds channels 8*cc .. 8*cc+7 (of the 64-channel
+        // chunk) of window pixel q >> 3 = row j, column i; cc = (q & 7) ^ (i & 6).  Window origin = tile origin - 1.
+        uint32_t soff[NSL];
+#pragma unroll
+        for (int e = 0; e < NSL; ++e) {
+            soff[e] = 0x80000000u;                         // out of range -> the DMA writes zeros
+            const int q = e * 256 + tid;
+            const int pixel = q >> 3;
+            const int j = pixel / IW;
+            const int i = pixel - j * IW;
+            const int iy = y0 - 1 + j, ix = x0 - 1 + i;
+            if (j < PH + 2 && grp < a.N && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi)
+                soff[e] = (uint32_t)((((grp * a.Hi + iy) * a.Wi + ix) * a.Ci + (((q & 7) ^ (i & 6)) << 3)) * 2);
+        }
+        const uint32_t lds_wave = lds0 + lw * 1024;
+        // slices [LO, HI) of channel chunk `chunk` into window buffer BUF
+        auto load_slices = [&](auto BUF_, int chunk, auto LO_, auto HI_) __attribute__((always_inline)) {
+            constexpr int buf = decltype(BUF_)::value, lo = decltype(LO_)::value, hi = decltype(HI_)::value;
+            const uint32_t so = (uint32_t)chunk * 128u;
+            static_for_t<lo, (hi < NSL ? hi : NSL)>([&](auto E_) __attribute__((always_inline)) {
+                constexpr int e = decltype(E_)::value;
+                if (TC5W_ABL == 4 && a.N > 0) return;
+                tdma(srd_in, soff[e], so, lds_wave + buf * WINB + e * 4096);
+            });
+        };
+        // ---- weight tile DMA (rows = co, 64 k-values per step), XOR swizzled like igemm.hip.  Per class: per-lane offset
+        // vw (row, 16-B column), scalar offset of the class matrix sw and of 32 rows rs.
+        const int trow = tid >> 3;
+        const int clog = (tid & 7) ^ ((trow >> 1) & 7);
+        auto class_w = [&](int cls, uint32_t& vw, uint32_t& sw, uint32_t& rs) __attribute__((always_inline)) {
+            const int kp = a.cls[cls].Kpad;
+            vw = (uint32_t)(((co0 + trow) * kp + clog * 8) * 2);
+            sw = (uint32_t)(a.cls[cls].w_off * 2);
+            rs = (uint32_t)(kp * 64);
+        };
+        auto load_w = [&](auto STG_, uint32_t vw, uint32_t so, uint32_t rs) __attribute__((always_inline)) {
+            constexpr int stg = decltype(STG_)::value;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (TC5W_ABL == 5 && a.N > 0) continue;
+                tdma(srd_w, vw, so + i * rs, lds_wave + WBUF0 + stg * W_BYTES + i * 4096);
+            }
+        };
+        const int Ci2 = a.Ci * 2;
+        uint32_t vw, sw, rs;
+        class_w(0, vw, sw, rs);
+        auto feed_class = [&](auto CLS_) __attribute__((always_inline)) {
+            constexpr int cls = decltype(CLS_)::value;
+            constexpr int TH = (cls >> 1) ? 2 : 3, TW = (cls & 1) ? 2 : 3, T = TH * TW;
+            constexpr int SPT = (NSL + T - 1) / T;            // window slices issued per tap
+            constexpr bool LAST = cls == 3;
+            uint32_t vwn = 0, swn = 0, rsn = 0;
+            if constexpr (!LAST) class_w(cls + 1, vwn, swn, rsn);
+            for (int chunk = 0; chunk < nch; chunk += 2) {
+                static_for_t<0, 2>([&](auto PB_) __attribute__((always_inline)) {
+                    constexpr int pb = decltype(PB_)::value;
+                    const int ch = chunk + pb;
+                    const bool last_chunk = ch + 1 >= nch;
+                    const bool more_win = !(LAST && last_chunk);       // another (class, chunk) window follows
+                    static_for_t<0, T>([&](auto TAP_) __attribute__((always_inline)) {
+                        constexpr int t = decltype(TAP_)::value;
+                        constexpr int stg = (pb * T + t) & 1;
+                        // slices issued behind the weight tile of the PREVIOUS step (window of the next chunk)
+                        constexpr int prev_lo = t == 0 ? 0 : (t - 1) * SPT;
+                        constexpr int prev_n = t == 0 ? 0
+                                                      : ((prev_lo >= NSL) ? 0 : ((prev_lo + SPT > NSL ? NSL : prev_lo + SPT) - prev_lo));
+                        // weights of this step landed; at the first tap of a chunk the whole window must have landed too
+                        if constexpr (t == 0 || prev_n == 0) wait_vmt<0>();
+                        else if constexpr (LAST) { if (more_win) wait_vmt<prev_n>(); else wait_vmt<0>(); }
+                        else wait_vmt<prev_n>();
+                        __builtin_amdgcn_s_barrier();
+                        __builtin_amdgcn_sched_barrier(0);
+                        // next step's weight tile
+                        if constexpr (t + 1 < T) {
+                            load_w(std::integral_constant<int, stg ^ 1>{}, vw, sw + (uint32_t)((t + 1) * Ci2 + ch * 128), rs);
+                        } else {
+                            if (!last_chunk) load_w(std::integral_constant<int, stg ^ 1>{}, vw, sw + (uint32_t)((ch + 1) * 128), rs);
+                            else if constexpr (!LAST) load_w(std::integral_constant<int, stg ^ 1>{}, vwn, swn, rsn);
+                        }
+                        // window of the next (class, chunk), spread over the taps
+                        if (more_win)
+                            load_slices(std::integral_constant<int, pb ^ 1>{}, last_chunk ? 0 : ch + 1,
+                                        std::integral_constant<int, t * SPT>{}, std::integral_constant<int, t * SPT + SPT>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                });
+            }
+            vw = vwn; sw = swn; rs = rsn;
+        };
+        // prologue: window of (class 0, chunk 0) and the first weight tile
+        load_slices(std::integral_constant<int, 0>{}, 0, std::integral_constant<int, 0>{}, std::integral_constant<int, NSL>{});
+        load_w(std::integral_constant<int, 0>{}, vw, sw, rs);
+        feed_class(std::integral_constant<int, 0>{});
+        feed_class(std::integral_constant<int, 1>{});
+        feed_class(std::integral_constant<int, 2>{});
+        feed_class(std::integral_constant<int, 3>{});
+    } else {
+        // =====================================================================================================
+        // compute waves: LDS fragment reads and MFMAs only
+        // =====================================================================================================
+        // ---- A fragment addresses of window column shift sx, first 32-channel half, window buffer 0, tile row wm*8:
+        // row tile tm and row shift sy add (tm + sy) * ROWB (immediates), the second half is ^ 64, buffer 1 is + WINB
+        uint32_t abase[2][3];
+#pragma unroll
+        for (int sx = 0; sx < 3; ++sx) {
+            const int col = frow + sx;
+            abase[0][sx] = (uint32_t)(((wm * 8) * IW + col) * 128 + ((fq ^ (col & 6)) << 4));
+            abase[1][sx] = abase[0][sx] + WINB;          // (the immediates of buffer 1 would pass 16 bits)
+        }
+        // ---- B fragment address (row = wn*64 + tn*16 + frow; the swizzle term does not depend on tn or wn)
+        const uint32_t boff = (uint32_t)(WBUF0 + (wn * (BN / WN) + frow) * 128 + ((fq ^ ((frow >> 1) & 7)) << 4));
+
+        f4 acc[TN][TM];
+        auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+        };
+        zero_acc();
+
+        // ---- the pending second half of the previous K-step (all zeros: nothing pending)
+        h8 paf[TM], pbf[TN];
+        auto clear_pending = [&]() __attribute__((always_inline)) {
+            if constexpr (TC5W_ABL == 2) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) paf[i] = (h8)(half_t)(0.37f * (float)((lane * 7 + i) & 15) - 2.f);
+#pragma unroll
+                for (int i = 0; i < TN; ++i) pbf[i] = (h8)(half_t)(0.011f * (float)((lane * 5 + i) & 15) - 0.08f);
+                return;
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) paf[i] = (h8)(half_t)0.f;
+#pragma unroll
+            for (int i = 0; i < TN; ++i) pbf[i] = (h8)(half_t)0.f;
+        };
+        clear_pending();
+        auto pending_mfmas = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pbf[tn], paf[tm], acc[tn][tm], 0, 0, 0);
+        };
+        auto interleave = [&]() __attribute__((always_inline)) {
+            // the 12 fragment reads one by one between the first MFMAs
+#pragma unroll
+            for (int i = 0; i < TM + TN; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - 2 * (TM + TN), 0);
+        };
+
+        // one K-step: window shift (SY, SX), window buffer PB, ring stage STG
+        auto step = [&](auto SY_, auto SX_, auto PB_, auto STG_) __attribute__((always_inline)) {
+            constexpr int sy = decltype(SY_)::value, sx = decltype(SX_)::value, pb = decltype(PB_)::value, stg = decltype(STG_)::value;
+            const char* Ps = smem + sy * ROWB;
+            const char* Ws = smem + stg * W_BYTES;
+            h8 af0[TM], bf0[TN];
+            if constexpr (TC5W_ABL == 2) {
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) af0[tm] = paf[tm];
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) bf0[tn] = pbf[tn];
+            } else {
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) af0[tm] = *(const h8*)(Ps + abase[pb][sx] + tm * ROWB);
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) bf0[tn] = *(const h8*)(Ws + (boff + tn * 2048));
+            }
+            pending_mfmas();
+            interleave();
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (TC5W_ABL != 2) {
+                // the second half: one XOR each (volatile: the compiler would otherwise keep both address sets live)
+                uint32_t ax, bxo;
+                asm volatile("v_xor_b32 %0, 64, %1" : "=v"(ax) : "v"(abase[pb][sx]));
+                asm volatile("v_xor_b32 %0, 64, %1" : "=v"(bxo) : "v"(boff));
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) paf[tm] = *(const h8*)(Ps + ax + tm * ROWB);
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) pbf[tn] = *(const h8*)(Ws + (bxo + tn * 2048));
+            }
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf0[tn], af0[tm], acc[tn][tm], 0, 0, 0);
+            interleave();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+
+        // ---- epilogue of one class: D[i = co][j = class-grid position] -> output pixel (2y + cy, 2x + cx); buffer stores
+        // with one 32-bit offset per lane and class (0x80000000 = dropped by the range check), the tile row as the scalar
+        // offset; FULL: every channel of the block exists (Co, CoStore multiples of 128)
+        typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+        const __amdgpu_buffer_rsrc_t srd_out = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)a.out, 0, (int)((uint32_t)a.N * (uint32_t)a.Ho * (uint32_t)a.Wo * (uint32_t)a.CoStore * 2u), 0x00020000);
+        const uint32_t row2_b = (uint32_t)(2 * a.Wo * a.CoStore * 2);       // two output rows = one class-grid row
+        const bool full_co = ((a.Co | a.CoStore) & 127) == 0;
+        auto epi_body = [&](int cls, auto FULL_) __attribute__((always_inline)) {
+            constexpr bool FULL = decltype(FULL_)::value;
+            const int cy = cls >> 1, cx = cls & 1;
+            const int Yc = a.cls[cls].Yc, Xc = a.cls[cls].Xc;
+            const int x = x0 + frow;
+            const bool xok = grp < a.N && x < Xc;
+            const int yb = y0 + wm * 8;
+            const int cw = co0 + wn * (BN / WN) + fq * 4;
+            const uint32_t vo = xok ? (uint32_t)((((grp * a.Ho + 2 * yb + cy) * a.Wo + 2 * x + cx) * a.CoStore + cw) * 2) : 0x80000000u;
+            const int nrow = Yc - yb;                        // tile rows tm < nrow exist in this class (wave-uniform)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int co = cw + tn * 16;
+                uint32_t vt = vo + tn * 32;
+                if constexpr (!FULL) { if (co >= a.CoStore) vt = 0x80000000u; }
+                f4 s0 = (f4){0.f, 0.f, 0.f, 0.f}, s1 = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+                    if (tm < nrow) {
+                        const f4 v = acc[tn][tm];
+                        h4 hv;
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg) hv[rg] = (half_t)((FULL || co + rg < a.Co) ? v[rg] : 0.f);
+                        if constexpr (STATS == 1) {
+                            // statistics of the STORED (fp16-rounded) values: what the consumers and the BN backward see
+#pragma unroll
+                            for (int rg = 0; rg < 4; ++rg) {
+                                const float f = xok ? (float)hv[rg] : 0.f;
+                                s0[rg] += f;
+                                s1[rg] += f * f;
+                            }
+                        }
+                        if (TC5W_ABL == 1 && a.N > 0) continue;
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, hv), srd_out, (int)vt, (int)(tm * row2_b), 0);
+                    }
+                }
+                if constexpr (STATS != 0) {
+                    // 16-lane row sums; lane (fq, frow) owns channel (frow >> 2)*16 + fq*4 + (frow & 3) of the wave's 64
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        const float ra = row16_sum(s0[rg]);
+                        const float rb = row16_sum(s1[rg]);
+                        if (frow == tn * 4 + rg) { vsum += ra; vsq += rb; }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+
+        auto run_class = [&](auto CLS_) __attribute__((always_inline)) {
+            constexpr int cls = decltype(CLS_)::value;
+            constexpr int TH = (cls >> 1) ? 2 : 3, TW = (cls & 1) ? 2 : 3, T = TH * TW;
+            for (int chunk = 0; chunk < nch; chunk += 2) {
+                static_for_t<0, 2>([&](auto PB_) __attribute__((always_inline)) {
+                    constexpr int pb = decltype(PB_)::value;
+                    static_for_t<0, T>([&](auto TAP_) __attribute__((always_inline)) {
+                        constexpr int t = decltype(TAP_)::value;
+                        constexpr int ty = t / TW, tx = t % TW;
+                        constexpr int stg = (pb * T + t) & 1;
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                        __builtin_amdgcn_sched_barrier(0);
+                        step(std::integral_constant<int, 2 - ty>{}, std::integral_constant<int, 2 - tx>{}, PB_,
+                             std::integral_constant<int, stg>{});
+                    });
+                });
+            }
+            pending_mfmas();                                     // the last step's second half
+            clear_pending();
+            if (full_co) epi_body(cls, std::true_type{});
+            else epi_body(cls, std::false_type{});
+            zero_acc();
+        };
+        run_class(std::integral_constant<int, 0>{});
+        run_class(std::integral_constant<int, 1>{});
+        run_class(std::integral_constant<int, 2>{});
+        run_class(std::integral_constant<int, 3>{});
+    }
+
+#ifdef FMRI_STAMP
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(k1), "=s"(r1)::"memory");
+    if (lane == 0 && !loader) {
+        atomicAdd(&tc5w_stamp_acc[5], 1ull); atomicAdd(&tc5w_stamp_acc[6], k1 - k0); atomicAdd(&tc5w_stamp_acc[7], r1 - r0);
+    }
+#endif
+    // ---- BatchNorm statistics of the block (all four classes): its own row of the partial buffer.  Compute lane (fq, frow)
+    // owns channel (frow >> 2)*16 + fq*4 + (frow & 3) of its wave's 64; the two position halves (wm) meet in LDS
+    if constexpr (STATS != 0) {
+        float* scratch = (float*)smem;
+        const int ch = (frow >> 2) * 16 + fq * 4 + (frow & 3);
+        __syncthreads();                                     // everyone is done with the operand tiles
+        if (!loader && wm == 1) {
+            scratch[wn * 128 + ch] = vsum;
+            scratch[wn * 128 + 64 + ch] = vsq;
+        }
+        __syncthreads();
+        if (!loader && wm == 0) {
+            vsum += scratch[wn * 128 + ch];
+            vsq += scratch[wn * 128 + 64 + ch];
+            const int co = co0 + wn * 64 + ch;
+            float* row = a.st.part + ((size_t)sgrp * a.st.rows_cap + (bx - sgrp * a.st.tpg[0])) * 2 * a.st.C;
+            if (co < a.st.C) {
+                row[co] = vsum;
+                row[a.st.C + co] = vsq;
+            }
+        }
+    }
+}
+
+template <int STATS>
+static int launch_tc5w(const Tc5Args& a, int copad, hipStream_t st) {
+    auto kern = igemm_tc5w_kernel<STATS>;
+    constexpr int lds = 2 * 11 * 4096 + 2 * 128 * 128;
+    // raising the dynamic-LDS limit is idempotent; every call sets it (no library-global state)
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        return E_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(a.ntiles, copad / 128, 1), dim3(512), lds, st, a);
+    return hipGetLastError() == hipSuccess ? OK : E_LAUNCH;
+}
+
+// Tc5Args with 16 x 16-position tiles of one image: tiles_y = ceil(Yc0 / 16), tiles_x = ceil(Xc0 / 16), ntiles = N * tiles_y *
+// tiles_x, nchunks even; no bias / activation, no BnBwdEpi
+int igemm_tc5w_launch(const Tc5Args& a, int copad, hipStream_t st) {
+    if (a.bias != nullptr || a.act != ACT_NONE || a.bb.x || (copad & 127) || a.ntiles < 1 || (a.nchunks & 1)) return E_UNSUPPORTED;
+    if ((int64_t)a.N * a.Ho * a.Wo * a.CoStore * 2 >= 0x7fffffffLL) return E_UNSUPPORTED;      // 32-bit store offsets
+    return a.st.part ? launch_tc5w<1>(a, copad, st) : launch_tc5w<0>(a, copad, st);
+}
+
+#ifdef FMRI_STAMP
+extern "C" int fmri_debug_tc5w_stamps(unsigned long long* out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(tc5w_stamp_acc), 64) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(tc5w_stamp_acc), z, 64) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
+
+}  // namespace fmri

@@ -40,6 +40,7 @@ int igemm_tc32_launch(const Tc32Args& a, int nblocks, hipStream_t st);
 int igemm_tc5_launch(const Tc5Args& a, int bn_tile, int copad, hipStream_t st);
 int igemm_c5_launch(const C5Args& a, int copad, hipStream_t st);
 int igemm_c5w_launch(const C5Args& a, int copad, hipStream_t st);
+int igemm_tc5w_launch(const Tc5Args& a, int copad, hipStream_t st);
 int mlp_fwd_launch(const MlpFwdArgs& a, hipStream_t st);
 int mlp_bwd_launch(const MlpBwdArgs& a, hipStream_t st);
 int igemm_narrow_launch(const NarrowArgs& a, int ci, int co_tiles, bool flip, hipStream_t st);

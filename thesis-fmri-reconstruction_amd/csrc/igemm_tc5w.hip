@@ -38,6 +38,11 @@ __device__ unsigned long long tc5w_stamp_acc[8];
 namespace {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+
+// output stores of the previous class issued behind the DMA of step J of a class with T taps (first chunk pair: 2T steps, 16 items)
+constexpr int t5_nst(int j, int T) { return 16 / (2 * T) + (j < 16 % (2 * T) ? 1 : 0); }
+constexpr int t5_st0(int j, int T) { return j * (16 / (2 * T)) + (j < 16 % (2 * T) ? j : 16 % (2 * T)); }
 
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for_t(F&& f) {
@@ -79,6 +84,7 @@ __global__ __launch_bounds__(512, 1) void igemm_tc5w_kernel(const Tc5Args a) {
     constexpr int WINB = NSL * 4096;
     constexpr int W_BYTES = BN * 128;                    // one tap x 64 channels of [128 co]
     constexpr int WBUF0 = 2 * WINB;
+    constexpr int STG0 = WBUF0 + 2 * W_BYTES;            // output staging: 128 positions x 128 channels fp16 (32 KB)
     static_assert((PH + 2) * IW * 128 <= WINB, "window fits its slices");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -171,6 +177,45 @@ __global__ __launch_bounds__(512, 1) void igemm_tc5w_kernel(const Tc5Args a) {
         const int Ci2 = a.Ci * 2;
         uint32_t vw, sw, rs;
         class_w(0, vw, sw, rs);
+
+        // ---- outputs: the compute waves hand a finished class over through LDS in two rounds (tile rows 0-7, 8-15; position
+        // p = row * 16 + x of the round at p * 256 B, 16-B channel slot s at slot s ^ x); thread tid keeps item k = row k,
+        // x = tid >> 4, slot tid & 15 of both rounds in registers and stores them one or two per K-step of the NEXT class
+        // (the last class: at the end): 256 contiguous bytes per position, and no store ever waits in a compute wave
+        const __amdgpu_buffer_rsrc_t srd_out = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)a.out, 0, (int)((uint32_t)a.N * (uint32_t)a.Ho * (uint32_t)a.Wo * (uint32_t)a.CoStore * 2u), 0x00020000);
+        const uint32_t row2_b = (uint32_t)(2 * a.Wo * a.CoStore * 2);       // two output rows = one class-grid row
+        v4i oreg[2][8];
+        uint32_t ovo[2];
+        int onrow[2];
+        auto take = [&](int cls) __attribute__((always_inline)) {
+            const int ox = tid >> 4;
+            const int slot = (tid & 15) ^ ox;
+            const int cy = cls >> 1, cx = cls & 1;
+            const int Yc = a.cls[cls].Yc, Xc = a.cls[cls].Xc;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                __builtin_amdgcn_s_barrier();                      // the round is in LDS
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) oreg[r][k] = *(const v4i*)(smem + STG0 + tid * 16 + k * 4096);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                      // ... and in registers: the staging area is free
+                __builtin_amdgcn_sched_barrier(0);
+                const int yb = y0 + r * 8, x = x0 + ox;
+                const bool ok = x < Xc && co0 + slot * 8 < a.CoStore;
+                ovo[r] = ok ? (uint32_t)((((grp * a.Ho + 2 * yb + cy) * a.Wo + 2 * x + cx) * a.CoStore + co0 + slot * 8) * 2) : 0x80000000u;
+                onrow[r] = Yc - yb;                                // tile rows k < onrow exist in this class
+            }
+        };
+        // item I of the kept class (always issued, so that vmcnt counts stay compile-time: rows outside the class grid carry
+        // an out-of-range offset and are dropped)
+        auto put = [&](auto I_) __attribute__((always_inline)) {
+            constexpr int i = decltype(I_)::value, r = i >> 3, k = i & 7;
+            const uint32_t vt = k < onrow[r] ? ovo[r] : 0x80000000u;
+            if (TC5W_ABL == 1 && a.N > 0) return;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, oreg[r][k]), srd_out, (int)vt, (int)(k * row2_b), 0);
+        };
         auto feed_class = [&](auto CLS_) __attribute__((always_inline)) {
             constexpr int cls = decltype(CLS_)::value;
             constexpr int TH = (cls >> 1) ? 2 : 3, TW = (cls & 1) ? 2 : 3, T = TH * TW;
@@ -191,10 +236,16 @@ __global__ __launch_bounds__(512, 1) void igemm_tc5w_kernel(const Tc5Args a) {
                         constexpr int prev_lo = t == 0 ? 0 : (t - 1) * SPT;
                         constexpr int prev_n = t == 0 ? 0
                                                       : ((prev_lo >= NSL) ? 0 : ((prev_lo + SPT > NSL ? NSL : prev_lo + SPT) - prev_lo));
-                        // weights of this step landed; at the first tap of a chunk the whole window must have landed too
-                        if constexpr (t == 0 || prev_n == 0) wait_vmt<0>();
-                        else if constexpr (LAST) { if (more_win) wait_vmt<prev_n>(); else wait_vmt<0>(); }
-                        else wait_vmt<prev_n>();
+                        // weights of this step landed; at the first tap of a chunk the whole window must have landed too.
+                        // In flight may stay: the slices and the output stores issued behind the previous step's weights
+                        constexpr int j = pb * T + t;
+                        constexpr int ns_prev = (cls > 0 && t > 0) ? t5_nst(j - 1, T) : 0;
+                        if constexpr (t == 0) wait_vmt<0>();
+                        else {
+                            const bool win_prev = !LAST || more_win;
+                            if (chunk == 0) { if (win_prev) wait_vmt<prev_n + ns_prev>(); else wait_vmt<ns_prev>(); }
+                            else { if (win_prev) wait_vmt<prev_n>(); else wait_vmt<0>(); }
+                        }
                         __builtin_amdgcn_s_barrier();
                         __builtin_amdgcn_sched_barrier(0);
                         // next step's weight tile
@@ -208,11 +259,17 @@ __global__ __launch_bounds__(512, 1) void igemm_tc5w_kernel(const Tc5Args a) {
                         if (more_win)
                             load_slices(std::integral_constant<int, pb ^ 1>{}, last_chunk ? 0 : ch + 1,
                                         std::integral_constant<int, t * SPT>{}, std::integral_constant<int, t * SPT + SPT>{});
+                        // outputs of the previous class
+                        if constexpr (cls > 0) {
+                            if (chunk == 0)
+                                static_for_t<t5_st0(j, T), t5_st0(j, T) + t5_nst(j, T)>([&](auto I_) __attribute__((always_inline)) { put(I_); });
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                     });
                 });
             }
             vw = vwn; sw = swn; rs = rsn;
+            take(cls);
         };
         // prologue: window of (class 0, chunk 0) and the first weight tile
         load_slices(std::integral_constant<int, 0>{}, 0, std::integral_constant<int, 0>{}, std::integral_constant<int, NSL>{});
@@ -221,6 +278,7 @@ __global__ __launch_bounds__(512, 1) void igemm_tc5w_kernel(const Tc5Args a) {
         feed_class(std::integral_constant<int, 1>{});
         feed_class(std::integral_constant<int, 2>{});
         feed_class(std::integral_constant<int, 3>{});
+        static_for_t<0, 16>([&](auto I_) __attribute__((always_inline)) { put(I_); });
     } else {
         // =====================================================================================================
         // compute waves: LDS fragment reads and MFMAs only
@@ -318,49 +376,39 @@ __global__ __launch_bounds__(512, 1) void igemm_tc5w_kernel(const Tc5Args a) {
             __builtin_amdgcn_sched_barrier(0);
         };
 
-        // ---- epilogue of one class: D[i = co][j = class-grid position] -> output pixel (2y + cy, 2x + cx); buffer stores
-        // with one 32-bit offset per lane and class (0x80000000 = dropped by the range check), the tile row as the scalar
-        // offset; FULL: every channel of the block exists (Co, CoStore multiples of 128)
-        typedef uint32_t u2v __attribute__((ext_vector_type(2)));
-        const __amdgpu_buffer_rsrc_t srd_out = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)a.out, 0, (int)((uint32_t)a.N * (uint32_t)a.Ho * (uint32_t)a.Wo * (uint32_t)a.CoStore * 2u), 0x00020000);
-        const uint32_t row2_b = (uint32_t)(2 * a.Wo * a.CoStore * 2);       // two output rows = one class-grid row
+        // ---- a finished class: D[i = co][j = class-grid position] as fp16 into the staging area, tile rows 0-7 (the wm = 0 waves)
+        // then 8-15 (wm = 1); the loader waves take each round into registers and store it (see `take`).  Position p = tm * 16
+        // + frow at p * 256 B, 16-B channel slot s = wn * 8 + tn * 2 + (fq >> 1) at slot s ^ frow (spreads the 16 positions
+        // of a write over the banks).  Channels >= Co are written as zeros.
         const bool full_co = ((a.Co | a.CoStore) & 127) == 0;
-        auto epi_body = [&](int cls, auto FULL_) __attribute__((always_inline)) {
+        const uint32_t sbase = (uint32_t)(STG0 + frow * 256 + (((wn * 8 + (fq >> 1)) ^ frow) << 4) + (fq & 1) * 8);
+        auto hand_body = [&](int cls, auto FULL_) __attribute__((always_inline)) {
             constexpr bool FULL = decltype(FULL_)::value;
-            const int cy = cls >> 1, cx = cls & 1;
             const int Yc = a.cls[cls].Yc, Xc = a.cls[cls].Xc;
-            const int x = x0 + frow;
-            const bool xok = grp < a.N && x < Xc;
-            const int yb = y0 + wm * 8;
+            const bool xok = grp < a.N && x0 + frow < Xc;
+            const int nrow = Yc - (y0 + wm * 8);             // tile rows tm < nrow exist in this class (wave-uniform)
             const int cw = co0 + wn * (BN / WN) + fq * 4;
-            const uint32_t vo = xok ? (uint32_t)((((grp * a.Ho + 2 * yb + cy) * a.Wo + 2 * x + cx) * a.CoStore + cw) * 2) : 0x80000000u;
-            const int nrow = Yc - yb;                        // tile rows tm < nrow exist in this class (wave-uniform)
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
                 const int co = cw + tn * 16;
-                uint32_t vt = vo + tn * 32;
-                if constexpr (!FULL) { if (co >= a.CoStore) vt = 0x80000000u; }
                 f4 s0 = (f4){0.f, 0.f, 0.f, 0.f}, s1 = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm) {
-                    if (tm < nrow) {
-                        const f4 v = acc[tn][tm];
-                        h4 hv;
+                    const f4 v = acc[tn][tm];
+                    h4 hv;
 #pragma unroll
-                        for (int rg = 0; rg < 4; ++rg) hv[rg] = (half_t)((FULL || co + rg < a.Co) ? v[rg] : 0.f);
-                        if constexpr (STATS == 1) {
-                            // statistics of the STORED (fp16-rounded) values: what the consumers and the BN backward see
+                    for (int rg = 0; rg < 4; ++rg) hv[rg] = (half_t)((FULL || co + rg < a.Co) ? v[rg] : 0.f);
+                    if constexpr (STATS == 1) {
+                        // statistics of the STORED (fp16-rounded) values: what the consumers and the BN backward see
+                        const bool in = xok && tm < nrow;
 #pragma unroll
-                            for (int rg = 0; rg < 4; ++rg) {
-                                const float f = xok ? (float)hv[rg] : 0.f;
-                                s0[rg] += f;
-                                s1[rg] += f * f;
-                            }
+                        for (int rg = 0; rg < 4; ++rg) {
+                            const float f = in ? (float)hv[rg] : 0.f;
+                            s0[rg] += f;
+                            s1[rg] += f * f;
                         }
-                        if (TC5W_ABL == 1 && a.N > 0) continue;
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, hv), srd_out, (int)vt, (int)(tm * row2_b), 0);
                     }
+                    *(h4*)(smem + ((sbase ^ (uint32_t)(tn * 32)) + tm * 4096)) = hv;
                 }
                 if constexpr (STATS != 0) {
                     // 16-lane row sums; lane (fq, frow) owns channel (frow >> 2)*16 + fq*4 + (frow & 3) of the wave's 64
@@ -372,6 +420,19 @@ __global__ __launch_bounds__(512, 1) void igemm_tc5w_kernel(const Tc5Args a) {
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
+            }
+        };
+        auto hand_over = [&](int cls) __attribute__((always_inline)) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                if (wm == r) {
+                    if (full_co) hand_body(cls, std::true_type{});
+                    else hand_body(cls, std::false_type{});
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                      // the round is in LDS
+                __builtin_amdgcn_s_barrier();                      // ... and in the loader waves' registers
+                __builtin_amdgcn_sched_barrier(0);
             }
         };
 
@@ -394,9 +455,8 @@ __global__ __launch_bounds__(512, 1) void igemm_tc5w_kernel(const Tc5Args a) {
                 });
             }
             pending_mfmas();                                     // the last step's second half
+            hand_over(cls);
             clear_pending();
-            if (full_co) epi_body(cls, std::true_type{});
-            else epi_body(cls, std::false_type{});
             zero_acc();
         };
         run_class(std::integral_constant<int, 0>{});
@@ -438,7 +498,7 @@ __global__ __launch_bounds__(512, 1) void igemm_tc5w_kernel(const Tc5Args a) {
 template <int STATS>
 static int launch_tc5w(const Tc5Args& a, int copad, hipStream_t st) {
     auto kern = igemm_tc5w_kernel<STATS>;
-    constexpr int lds = 2 * 11 * 4096 + 2 * 128 * 128;
+    constexpr int lds = 2 * 11 * 4096 + 2 * 128 * 128 + 32768;
     // raising the dynamic-LDS limit is idempotent; every call sets it (no library-global state)
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return E_LAUNCH;

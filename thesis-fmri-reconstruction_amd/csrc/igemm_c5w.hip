@@ -25,7 +25,7 @@
 #include <type_traits>
 
 #ifndef C5W_NSTG
-#define C5W_NSTG 4      // weight ring stages (16 KB each)
+#define C5W_NSTG 2      // weight ring stages (16 KB each); deeper rings measured no faster
 #endif
 #ifndef C5W_HALFA
 #define C5W_HALFA 1
@@ -52,6 +52,7 @@ __device__ unsigned long long c5w_stamp_acc[8];
 namespace {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for_w(F&& f) {
@@ -106,6 +107,10 @@ constexpr int w5_allow(int t, bool more, int D) {
     return n;
 }
 
+// output stores of the previous tile issued behind the DMA of step t of a tile's first sub-chunk: 16 items over steps 0-11
+constexpr int w5_nst(int t) { return t < 4 ? 2 : (t < 12 ? 1 : 0); }
+constexpr int w5_st0(int t) { return t < 4 ? 2 * t : 8 + (t - 4); }
+
 }  // namespace
 
 // STATS: 0 none, 1 BatchNorm forward statistics (StatEpi)
@@ -119,6 +124,8 @@ __global__ __launch_bounds__(512, 1) void igemm_c5w_kernel(const C5Args a) {
     constexpr int W_BYTES = 2 * 8192;                     // two tap slots of [128 co][32 ch]
     constexpr int WBUF0 = 2 * WINB;
     constexpr int NSTG = C5W_NSTG, D = NSTG - 1;          // weight ring stages, K-steps of weights in flight
+    constexpr int STG0 = WBUF0 + NSTG * W_BYTES;          // output staging: 128 pixels x 128 channels fp16 (32 KB)
+    static_assert(STG0 + 32768 <= 160 * 1024, "LDS");
     static_assert((PH + 2) * ROW * 64 <= WINB, "window fits its slices");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -229,15 +236,57 @@ __global__ __launch_bounds__(512, 1) void igemm_c5w_kernel(const C5Args a) {
                 wdma(srd_w, vw, so + i * rs64, lds_wave + WBUF0 + stg * W_BYTES + s * 8192 + i * 4096);
             }
         };
+        // ---- outputs: the compute waves hand a finished tile over through LDS in two rounds (tile rows 0-7, 8-15; pixel
+        // p = row * 16 + x of the round at p * 256 B, 16-B channel slot s at slot s ^ x); thread tid keeps item k = row k,
+        // x = tid >> 4, slot tid & 15 of both rounds in registers and stores them one or two per K-step of the NEXT tile's
+        // first sub-chunk (the last tile: at the end): 256 contiguous bytes per pixel, and no store ever waits in a compute wave
+        const __amdgpu_buffer_rsrc_t srd_out = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)a.out, 0, (int)((uint32_t)a.N * (uint32_t)a.Ho * (uint32_t)a.Wo * (uint32_t)a.CoStore * 2u), 0x00020000);
+        const uint32_t row_b = (uint32_t)(a.Wo * a.CoStore * 2);
+        v4i oreg[2][8];
+        uint32_t ovo[2] = {0x80000000u, 0x80000000u};
+        int onrow[2] = {0, 0};
+        auto take = [&](int g, int yy, int xx) __attribute__((always_inline)) {
+            const int ox = tid >> 4;
+            const int slot = (tid & 15) ^ ox;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                __builtin_amdgcn_s_barrier();                      // the round is in LDS
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) oreg[r][k] = *(const v4i*)(smem + STG0 + tid * 16 + k * 4096);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                      // ... and in registers: the staging area is free
+                __builtin_amdgcn_sched_barrier(0);
+                const int yb = yy + r * 8, x = xx + ox;
+                const bool ok = g < a.N && x < a.Wo && co0 + slot * 8 < a.CoStore;
+                ovo[r] = ok ? (uint32_t)(((((C5W_ABL == 5 ? 0 : g) * a.Ho + yb) * a.Wo + x) * a.CoStore + co0 + slot * 8) * 2) : 0x80000000u;
+                onrow[r] = a.Ho - yb;                              // tile rows k < onrow exist
+            }
+        };
+        // item I of the kept tile (always issued, so that vmcnt counts stay compile-time: rows below the image carry an
+        // out-of-range offset and are dropped)
+        auto put = [&](auto I_) __attribute__((always_inline)) {
+            constexpr int i = decltype(I_)::value, r = i >> 3, k = i & 7;
+            const uint32_t vt = k < onrow[r] ? ovo[r] : 0x80000000u;
+            if (C5W_ABL == 1 && a.N > 0) return;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, oreg[r][k]), srd_out, (int)vt, (int)(k * row_b), 0);
+        };
         int stg = 0;                              // ring stage of the current step (wave-uniform)
-        // one 32-channel sub-chunk: 13 steps (schedule: w5_allow's comment)
-        auto feed_sub = [&](int sub, bool more, int nsubi, bool switch_tile, int ng, int ny, int nx)
+        // one 32-channel sub-chunk: 13 steps (schedule: w5_allow's comment); `outs`: the previous tile's outputs leave
+        // behind the DMA of steps 0-11 (and may stay in flight over the next barrier, like the window slices)
+        auto feed_sub = [&](int sub, bool more, int nsubi, bool switch_tile, int ng, int ny, int nx, bool outs)
                             __attribute__((always_inline)) {
             static_for_w<0, 13>([&](auto T_) __attribute__((always_inline)) {
                 constexpr int t = decltype(T_)::value;
                 constexpr int n_more = w5_allow(t, true, D), n_last = w5_allow(t, false, D);
-                if constexpr (n_more == n_last) wait_vmw<n_more>();
-                else { if (more) wait_vmw<n_more>(); else wait_vmw<n_last>(); }
+                constexpr int ns_prev = t > 0 ? w5_nst(t - 1) : 0;
+                static_assert(D == 1 || C5W_NSTG == 2, "the store allowance below assumes one step of weights in flight");
+                if (outs) {
+                    if (more) wait_vmw<n_more + ns_prev>(); else wait_vmw<n_last + ns_prev>();
+                } else {
+                    if (more) wait_vmw<n_more>(); else wait_vmw<n_last>();
+                }
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
                 int sd = stg + D;
@@ -260,6 +309,9 @@ __global__ __launch_bounds__(512, 1) void igemm_c5w_kernel(const C5Args a) {
                             load_slice(std::integral_constant<int, 0>{}, nsubi, std::integral_constant<int, w5_ev_0(t) + decltype(J_)::value>{});
                         });
                 }
+                if constexpr (w5_nst(t) > 0) {
+                    if (outs) static_for_w<w5_st0(t), w5_st0(t) + w5_nst(t)>([&](auto I_) __attribute__((always_inline)) { put(I_); });
+                }
                 stg = stg + 1 == NSTG ? 0 : stg + 1;
                 __builtin_amdgcn_sched_barrier(0);
             });
@@ -273,19 +325,23 @@ __global__ __launch_bounds__(512, 1) void igemm_c5w_kernel(const C5Args a) {
         });
         wait_vmw<0>();
         int tile = tile0, sub = 0;
+        int cg = grp0, cy = ty0, cx = tx0;        // the tile being computed
         int ng = 0, ny = 0, nx = 0;
         if (tile + 1 < tile1) tile_geom(tile + 1, ng, ny, nx);
         while (tile < tile1) {
             const bool next_tile = tile + 1 < tile1;
             const bool last_sub = sub + 1 >= nsub;
-            feed_sub(sub, !last_sub || next_tile, last_sub ? 0 : sub + 1, last_sub && next_tile, ng, ny, nx);
+            feed_sub(sub, !last_sub || next_tile, last_sub ? 0 : sub + 1, last_sub && next_tile, ng, ny, nx, sub == 0 && tile > tile0);
             ++sub;
             if (last_sub) {
+                take(cg, cy, cx);
+                cg = ng; cy = ny; cx = nx;
                 sub = 0;
                 ++tile;
                 if (tile + 1 < tile1) tile_geom(tile + 1, ng, ny, nx);
             }
         }
+        static_for_w<0, 16>([&](auto I_) __attribute__((always_inline)) { put(I_); });
     } else {
         // =====================================================================================================
         // compute waves: LDS fragment reads and MFMAs only
@@ -428,47 +484,39 @@ __global__ __launch_bounds__(512, 1) void igemm_c5w_kernel(const C5Args a) {
             });
         };
 
-        // ---- epilogue: D[i = co][j = tile pixel] -> NHWC fp16 (no bias / activation: BatchNorm or a data gradient follows)
-        // Buffer stores: one 32-bit offset per lane and tile (0x80000000 = dropped by the range check), the row of the
-        // tile as the scalar offset; FULL: every channel of the block exists (Co, CoStore multiples of 128)
-        typedef uint32_t u2v __attribute__((ext_vector_type(2)));
-        const __amdgpu_buffer_rsrc_t srd_out = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)a.out, 0, (int)((uint32_t)a.N * (uint32_t)a.Ho * (uint32_t)a.Wo * (uint32_t)a.CoStore * 2u), 0x00020000);
-        const uint32_t row_b = (uint32_t)(a.Wo * a.CoStore * 2);
+        // ---- a finished tile: D[i = co][j = tile pixel] as fp16 into the staging area (no bias / activation: BatchNorm or a
+        // data gradient follows), tile rows 0-7 (the wm = 0 waves) then 8-15 (wm = 1); the loader waves take each round into
+        // registers and store it (see `take`).  Pixel p = tm * 16 + frow at p * 256 B, 16-B channel slot s = wn * 8 + tn * 2
+        // + (fq >> 1) at slot s ^ frow (spreads the 16 pixels of a write over the banks).  Channels >= Co are written as zeros.
         const bool full_co = ((a.Co | a.CoStore) & 127) == 0;
-        auto epi_body = [&](auto FULL_) __attribute__((always_inline)) {
+        const uint32_t sbase = (uint32_t)(STG0 + frow * 256 + (((wn * 8 + (fq >> 1)) ^ frow) << 4) + (fq & 1) * 8);
+        auto hand_body = [&](auto FULL_) __attribute__((always_inline)) {
             constexpr bool FULL = decltype(FULL_)::value;
-            const int x = x0 + frow;
-            const bool xok = grp < a.N && x < a.Wo;
-            const int yb = y0 + wm * 8;
+            const bool xok = grp < a.N && x0 + frow < a.Wo;
+            const int nrow = a.Ho - (y0 + wm * 8);           // tile rows tm < nrow exist (wave-uniform)
             const int cw = co0 + wn * (BN / WN) + fq * 4;
-            const uint32_t vo = xok ? (uint32_t)(((((C5W_ABL == 5 ? 0 : grp) * a.Ho + yb) * a.Wo + x) * a.CoStore + cw) * 2) : 0x80000000u;
-            const int nrow = a.Ho - yb;                      // tile rows tm < nrow exist (wave-uniform)
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
                 const int co = cw + tn * 16;
-                uint32_t vt = vo + tn * 32;
-                if constexpr (!FULL) { if (co >= a.CoStore) vt = 0x80000000u; }
                 f4 s0 = (f4){0.f, 0.f, 0.f, 0.f}, s1 = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm) {
-                    if (tm < nrow) {
-                        const f4 v = acc[tn][tm];
-                        h4 hv;
+                    const f4 v = acc[tn][tm];
+                    h4 hv;
 #pragma unroll
-                        for (int rg = 0; rg < 4; ++rg) hv[rg] = (half_t)((FULL || co + rg < a.Co) ? v[rg] : 0.f);
-                        if constexpr (STATS == 1) {
-                            // statistics of the STORED (fp16-rounded) values: what the consumers and the BN backward see
+                    for (int rg = 0; rg < 4; ++rg) hv[rg] = (half_t)((FULL || co + rg < a.Co) ? v[rg] : 0.f);
+                    if constexpr (STATS == 1) {
+                        // statistics of the STORED (fp16-rounded) values: what the consumers and the BN backward see
+                        const bool in = xok && tm < nrow;
 #pragma unroll
-                            for (int rg = 0; rg < 4; ++rg) {
-                                const float f = xok ? (float)hv[rg] : 0.f;
-                                s0[rg] += f;
-                                s1[rg] += f * f;
-                            }
+                        for (int rg = 0; rg < 4; ++rg) {
+                            const float f = in ? (float)hv[rg] : 0.f;
+                            s0[rg] += f;
+                            s1[rg] += f * f;
                         }
-                        if (C5W_ABL == 1 && a.N > 0) continue;
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, hv), srd_out, (int)vt, (int)(tm * row_b), 0);
                     }
+                    *(h4*)(smem + ((sbase ^ (uint32_t)(tn * 32)) + tm * 4096)) = hv;
+                    if constexpr (STATS != 0) __builtin_amdgcn_sched_barrier(0);      // one tile at a time: register peak
                 }
                 if constexpr (STATS != 0) {
 #pragma unroll
@@ -482,8 +530,17 @@ __global__ __launch_bounds__(512, 1) void igemm_c5w_kernel(const C5Args a) {
             }
         };
         auto epilogue = [&]() __attribute__((always_inline)) {
-            if (full_co) epi_body(std::true_type{});
-            else epi_body(std::false_type{});
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                if (wm == r) {
+                    if (full_co) hand_body(std::true_type{});
+                    else hand_body(std::false_type{});
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                      // the round is in LDS
+                __builtin_amdgcn_s_barrier();                      // ... and in the loader waves' registers
+                __builtin_amdgcn_sched_barrier(0);
+            }
         };
 
         int tile = tile0, sub = 0;
@@ -495,12 +552,12 @@ __global__ __launch_bounds__(512, 1) void igemm_c5w_kernel(const C5Args a) {
             ++sub;
             if (last_sub) {
                 pending_mfmas();                                     // the last step's second tap slot
-                clear_pending();
 #if defined(FMRI_STAMP) && FMRI_STAMP >= 2
                 unsigned long long te0, te1;
                 FMRI_STAMP_AT(te0);
 #endif
                 epilogue();
+                clear_pending();
 #if defined(FMRI_STAMP) && FMRI_STAMP >= 2
                 FMRI_STAMP_AT(te1);
                 st_epi += te1 - te0;
@@ -552,7 +609,7 @@ __global__ __launch_bounds__(512, 1) void igemm_c5w_kernel(const C5Args a) {
 template <int STATS>
 static int launch_c5w(const C5Args& a, int copad, hipStream_t st) {
     auto kern = igemm_c5w_kernel<STATS>;
-    constexpr int lds = 2 * 10 * 4096 + C5W_NSTG * 16384;
+    constexpr int lds = 2 * 10 * 4096 + C5W_NSTG * 16384 + 32768;
     // raising the dynamic-LDS limit is idempotent; every call sets it (no library-global state)
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return E_LAUNCH;

@@ -409,6 +409,7 @@ __global__ __launch_bounds__(512, 1) void igemm_tc5w_kernel(const Tc5Args a) {
                         }
                     }
                     *(h4*)(smem + ((sbase ^ (uint32_t)(tn * 32)) + tm * 4096)) = hv;
+                    if constexpr (STATS != 0) __builtin_amdgcn_sched_barrier(0);      // one tile at a time: register peak
                 }
                 if constexpr (STATS != 0) {
                     // 16-lane row sums; lane (fq, frow) owns channel (frow >> 2)*16 + fq*4 + (frow & 3) of the wave's 64

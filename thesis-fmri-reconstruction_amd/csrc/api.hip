@@ -307,17 +307,19 @@ int fmri_igemm_ep(const void* in, const void* w, void* out, const float* bias, c
         }
         q.bb = bb;
         if (!q.st.part) q.bb.x = nullptr;       // no statistics rows: plain output (*ep_done = 0 tells the caller)
-        // wide form (csrc/igemm_c5w.hip): 16 x 16-pixel tiles, one 8-wave block per CU, loader / compute waves;
-        // FMRI_C5W=off disables
+        // wide form (csrc/igemm_c5w.hip): 16 x 16-pixel tiles of one image or 8 x 8-pixel tiles of four, one 8-wave block per
+        // CU, loader / compute waves; FMRI_C5W=off disables
         static const char* c5w_env = getenv("FMRI_C5W");
         static const bool no_c5w = c5w_env && !strcmp(c5w_env, "off");
-        if (!no_c5w && q.pw16 && !q.bb.x && Ho > 8) {
+        const int ipbw = q.pw16 ? 1 : 4;
+        if (!no_c5w && !q.bb.x && (q.pw16 ? Ho > 8 : true) && !(se.part && se.group_n > 0 && (se.group_n % ipbw))) {
             C5Args w = q;
-            w.tiles_y = (Ho + 15) / 16;
-            w.ntiles = N * w.tiles_y * w.tiles_x;
+            const int ph = q.pw16 ? 16 : 8;
+            w.tiles_y = (Ho + ph - 1) / ph;
+            w.ntiles = ((N + ipbw - 1) / ipbw) * w.tiles_y * w.tiles_x;
             w.fdTPI = make_fastdiv((uint32_t)(w.tiles_y * w.tiles_x));
             w.st = se;
-            const int tpgw = se.group_n > 0 ? se.group_n * w.tiles_y * w.tiles_x : w.ntiles;
+            const int tpgw = se.group_n > 0 ? (se.group_n / ipbw) * w.tiles_y * w.tiles_x : w.ntiles;
             // whole rounds of one block per CU, statistics groups not sharing a block
             w.tpb = 1;
             for (int t = (w.ntiles * ncol) / 256; t > 1; --t)

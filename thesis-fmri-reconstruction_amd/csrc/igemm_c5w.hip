@@ -87,20 +87,23 @@ constexpr int w5_kx(int i) { return i < 15 ? i % 5 : (i - 15) % 5; }
 
 // ---- DMA schedule of one 32-channel sub-chunk (13 K-steps), ring of NSTG weight stages filled D = NSTG - 1 steps ahead.
 // Issued behind the barrier of step t, in this order: the 4 weight pieces of step t + D (of the next sub-chunk past step 12),
-// then window slices: steps 0-4 two slices of this sub-chunk's odd-row window (buffer 1, first read in step 7), steps 8-11
-// 3, 3, 2, 2 slices of the next sub-chunk's even-row window (buffer 0, last read in step 7).
-constexpr int w5_ev_n(int t) { return (t == 8 || t == 9) ? 3 : ((t == 10 || t == 11) ? 2 : 0); }
-constexpr int w5_ev_0(int t) { return t == 8 ? 0 : (t == 9 ? 3 : (t == 10 ? 6 : 8)); }
-constexpr int w5_s(int t, bool more) { return t <= 4 ? 2 : (more ? w5_ev_n(t) : 0); }
+// then window slices: the NSL slices of this sub-chunk's odd-row window (buffer 1, first read in step 7) over steps 0-4
+// (2 each of 10; 3, 3, 2, 2, 2 of 12), those of the next sub-chunk's even-row window (buffer 0, last read in step 7) over steps
+// 8-11 (3, 3, 2, 2 of 10; 3 each of 12).
+constexpr int w5_od_n(int t, int NSL) { return t <= 4 ? NSL / 5 + (t < NSL % 5 ? 1 : 0) : 0; }
+constexpr int w5_od_0(int t, int NSL) { return t * (NSL / 5) + (t < NSL % 5 ? t : NSL % 5); }
+constexpr int w5_ev_n(int t, int NSL) { return (t >= 8 && t <= 11) ? NSL / 4 + (t - 8 < NSL % 4 ? 1 : 0) : 0; }
+constexpr int w5_ev_0(int t, int NSL) { return (t - 8) * (NSL / 4) + (t - 8 < NSL % 4 ? t - 8 : NSL % 4); }
+constexpr int w5_s(int t, bool more, int NSL) { return t <= 4 ? w5_od_n(t, NSL) : (more ? w5_ev_n(t, NSL) : 0); }
 constexpr int w5_w(int t, bool more, int D) { return (t + D < 13 || more) ? 4 : 0; }
 // pieces that may still be in flight at the barrier of step t (vmcnt counts in issue order): the weights of step t were
 // issued at step t - D; index i < 0 = step i + 13 of the previous sub-chunk (which had a successor)
-constexpr int w5_allow(int t, bool more, int D) {
-    int n = t - D < 0 ? w5_s(t - D + 13, true) : w5_s(t - D, more);
-    for (int i = t - D + 1; i < t; ++i) n += i < 0 ? 4 + w5_s(i + 13, true) : w5_w(i, more, D) + w5_s(i, more);
+constexpr int w5_allow(int t, bool more, int D, int NSL) {
+    int n = t - D < 0 ? w5_s(t - D + 13, true, NSL) : w5_s(t - D, more, NSL);
+    for (int i = t - D + 1; i < t; ++i) n += i < 0 ? 4 + w5_s(i + 13, true, NSL) : w5_w(i, more, D) + w5_s(i, more, NSL);
     if (t == 7) {                       // the odd-row window (last slices issued at step 4) is read from here on
         int m = 0;
-        for (int i = 5; i < 7; ++i) m += w5_w(i, more, D) + w5_s(i, more);
+        for (int i = 5; i < 7; ++i) m += w5_w(i, more, D) + w5_s(i, more, NSL);
         n = m < n ? m : n;
     }
     if (t == 0) n = 4 < n ? 4 : n;      // the even-row window (last slices at step 11 of the previous sub-chunk) is read from here on
@@ -113,20 +116,23 @@ constexpr int w5_st0(int t) { return t < 4 ? 2 * t : 8 + (t - 4); }
 
 }  // namespace
 
-// STATS: 0 none, 1 BatchNorm forward statistics (StatEpi)
-template <int STATS>
+// PW: 16 = tiles of 16 x 16 pixels of one image, 8 = 8 x 8 pixels of FOUR images (an MFMA row tile = one tile row of two
+// images).  STATS: 0 none, 1 BatchNorm forward statistics (StatEpi)
+template <int PW, int STATS>
 __global__ __launch_bounds__(512, 1) void igemm_c5w_kernel(const C5Args a) {
     constexpr int BN = 128, WN = 2, TM = 8, TN = 4;
-    constexpr int PW = 16, PH = 16;
+    constexpr int PH = PW, IPB = PW == 16 ? 1 : 4;
+    constexpr int IH = PH + 2;                            // window rows per image
     constexpr int ROW = 2 * PW + 3;                       // window pixels per row: plane 0 (PW + 2), plane 1 (PW + 1)
-    constexpr int NSL = 10;                               // 4 KB DMA slices per window ((PH + 2) * ROW * 64 B = 40 320)
+    constexpr int NSL = (IPB * IH * ROW * 64 + 4095) / 4096;      // 4 KB DMA slices per window: 10 (40 320 B) / 12 (48 640 B)
     constexpr int WINB = NSL * 4096;
     constexpr int W_BYTES = 2 * 8192;                     // two tap slots of [128 co][32 ch]
     constexpr int WBUF0 = 2 * WINB;
     constexpr int NSTG = C5W_NSTG, D = NSTG - 1;          // weight ring stages, K-steps of weights in flight
     constexpr int STG0 = WBUF0 + NSTG * W_BYTES;          // output staging: 128 pixels x 128 channels fp16 (32 KB)
     static_assert(STG0 + 32768 <= 160 * 1024, "LDS");
-    static_assert((PH + 2) * ROW * 64 <= WINB, "window fits its slices");
+    static_assert(PW == 16 || PW == 8, "tile");
+    static_assert(WINB + (2 + 7) * ROW * 64 < 65536, "ds_read immediates");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int lane = threadIdx.x & 63;
@@ -154,7 +160,7 @@ __global__ __launch_bounds__(512, 1) void igemm_c5w_kernel(const C5Args a) {
     const int frow = lane & 15, fq = lane >> 4;
     int grp0, ty0, tx0;
     tile_geom(tile0, grp0, ty0, tx0);
-    const int sgrp = (STATS != 0 && a.st.group_n > 0) ? grp0 / a.st.group_n : 0;   // statistics group of the block's tiles
+    const int sgrp = (STATS != 0 && a.st.group_n > 0) ? (grp0 * IPB) / a.st.group_n : 0;   // statistics group of the block's tiles
 #ifdef FMRI_STAMP
     unsigned long long st_sync = 0, st_pend = 0, st_first = 0, st_epi = 0, st_steps = 0, k0, k1, r0, r1;
     FMRI_STAMP_AT(k0);
@@ -180,22 +186,25 @@ __global__ __launch_bounds__(512, 1) void igemm_c5w_kernel(const C5Args a) {
         srd_w.w = 0x00020000;
 
         // ---- window DMA: 16-B unit q = e*256 + tid of a window buffer holds channels 8*cc .. 8*cc+7 (of the 32-channel
-        // sub-chunk) of window pixel p = q >> 2 = row j, column position ii; cc = (q & 3) ^ 2*bit2(ii).
+        // sub-chunk) of window pixel p = q >> 2 = image ip, row j, column position ii; cc = (q & 3) ^ 2*bit2(ii) (PW = 16) or
+        // (q & 3) ^ 2*(ip & 1) (PW = 8): the fragment reads are bank-conflict free with these.
         // Column position ii < PW + 2: input column 2*x0 - 2 + 2*ii; else 2*x0 - 1 + 2*(ii - PW - 2).  Row j of phase rp:
         // input row 2*y0 - 2 + rp + 2*j (the odd phase has PH + 1 rows).
         uint32_t soff0[NSL], soff1[NSL];
-        uint32_t wstat[NSL];                  // column term | row << 8 | cc << 13 | valid << 15
+        uint32_t wstat[NSL];                  // column term | row << 8 | cc << 13 | valid << 15 | image << 16
 #pragma unroll
         for (int e = 0; e < NSL; ++e) {
             const int q = e * 256 + tid;
             const int p = q >> 2;
-            const int j = p / ROW;
-            const int ii = p - j * ROW;
+            const int ip = p / (IH * ROW);
+            const int pr = p - ip * (IH * ROW);
+            const int j = pr / ROW;
+            const int ii = pr - j * ROW;
             const int cp = ii >= PW + 2 ? 1 : 0;
             const int m = ii - cp * (PW + 2);
-            const int cc = (q & 3) ^ (((ii >> 2) & 1) << 1);
-            const int valid = j < PH + 2 ? 1 : 0;
-            wstat[e] = (uint32_t)((2 * m + cp) | ((j & 31) << 8) | (cc << 13) | (valid << 15));
+            const int cc = (q & 3) ^ ((PW == 16 ? ((ii >> 2) & 1) : (ip & 1)) << 1);
+            const int valid = ip < IPB ? 1 : 0;
+            wstat[e] = (uint32_t)((2 * m + cp) | ((j & 31) << 8) | (cc << 13) | (valid << 15) | ((ip & 3) << 16));
         }
         auto tile_offsets = [&](int g, int yy, int xx) __attribute__((always_inline)) {
 #pragma unroll
@@ -203,10 +212,11 @@ __global__ __launch_bounds__(512, 1) void igemm_c5w_kernel(const C5Args a) {
                 soff0[e] = soff1[e] = 0x80000000u;             // out of range -> the DMA writes zeros
                 const uint32_t ws = wstat[e];
                 const int j = (ws >> 8) & 31, cc = (ws >> 13) & 3;
+                const int n = g * IPB + (int)((ws >> 16) & 3);
                 const int ix = 2 * xx - 2 + (int)(ws & 255);
                 const int iy = 2 * yy - 2 + 2 * j;
-                if ((ws >> 15) && g < a.N && (unsigned)ix < (unsigned)a.Wi) {
-                    const uint32_t o = (uint32_t)((((g * a.Hi + iy) * a.Wi + ix) * a.Ci + cc * 8) * 2);
+                if (((ws >> 15) & 1) && n < a.N && (unsigned)ix < (unsigned)a.Wi) {
+                    const uint32_t o = (uint32_t)((((n * a.Hi + iy) * a.Wi + ix) * a.Ci + cc * 8) * 2);
                     if ((unsigned)iy < (unsigned)a.Hi) soff0[e] = o;
                     if (j < PH + 1 && (unsigned)(iy + 1) < (unsigned)a.Hi) soff1[e] = o + (uint32_t)(a.Wi * a.Ci * 2);
                 }
@@ -242,13 +252,15 @@ __global__ __launch_bounds__(512, 1) void igemm_c5w_kernel(const C5Args a) {
         // first sub-chunk (the last tile: at the end): 256 contiguous bytes per pixel, and no store ever waits in a compute wave
         const __amdgpu_buffer_rsrc_t srd_out = __builtin_amdgcn_make_buffer_rsrc(
             (void*)a.out, 0, (int)((uint32_t)a.N * (uint32_t)a.Ho * (uint32_t)a.Wo * (uint32_t)a.CoStore * 2u), 0x00020000);
+        // (PW = 8: a round = two images, item k = tile row k of both, pixel tid >> 4 = image (bit 3), column)
         const uint32_t row_b = (uint32_t)(a.Wo * a.CoStore * 2);
         v4i oreg[2][8];
         uint32_t ovo[2] = {0x80000000u, 0x80000000u};
         int onrow[2] = {0, 0};
         auto take = [&](int g, int yy, int xx) __attribute__((always_inline)) {
-            const int ox = tid >> 4;
-            const int slot = (tid & 15) ^ ox;
+            const int opx = tid >> 4;                      // pixel of the item
+            const int slot = (tid & 15) ^ opx;
+            const int ox = PW == 16 ? opx : (opx & 7);
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 __builtin_amdgcn_s_barrier();                      // the round is in LDS
@@ -258,9 +270,10 @@ __global__ __launch_bounds__(512, 1) void igemm_c5w_kernel(const C5Args a) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();                      // ... and in registers: the staging area is free
                 __builtin_amdgcn_sched_barrier(0);
-                const int yb = yy + r * 8, x = xx + ox;
-                const bool ok = g < a.N && x < a.Wo && co0 + slot * 8 < a.CoStore;
-                ovo[r] = ok ? (uint32_t)(((((C5W_ABL == 5 ? 0 : g) * a.Ho + yb) * a.Wo + x) * a.CoStore + co0 + slot * 8) * 2) : 0x80000000u;
+                const int n = PW == 16 ? g : g * IPB + r * 2 + (opx >> 3);
+                const int yb = PW == 16 ? yy + r * 8 : yy, x = xx + ox;
+                const bool ok = n < a.N && x < a.Wo && co0 + slot * 8 < a.CoStore;
+                ovo[r] = ok ? (uint32_t)(((((C5W_ABL == 5 ? 0 : n) * a.Ho + yb) * a.Wo + x) * a.CoStore + co0 + slot * 8) * 2) : 0x80000000u;
                 onrow[r] = a.Ho - yb;                              // tile rows k < onrow exist
             }
         };
@@ -279,7 +292,7 @@ __global__ __launch_bounds__(512, 1) void igemm_c5w_kernel(const C5Args a) {
                             __attribute__((always_inline)) {
             static_for_w<0, 13>([&](auto T_) __attribute__((always_inline)) {
                 constexpr int t = decltype(T_)::value;
-                constexpr int n_more = w5_allow(t, true, D), n_last = w5_allow(t, false, D);
+                constexpr int n_more = w5_allow(t, true, D, NSL), n_last = w5_allow(t, false, D, NSL);
                 constexpr int ns_prev = t > 0 ? w5_nst(t - 1) : 0;
                 static_assert(D == 1 || C5W_NSTG == 2, "the store allowance below assumes one step of weights in flight");
                 if (outs) {
@@ -299,14 +312,15 @@ __global__ __launch_bounds__(512, 1) void igemm_c5w_kernel(const C5Args a) {
                     }
                 });
                 if constexpr (t <= 4) {
-                    load_slice(std::integral_constant<int, 1>{}, sub, std::integral_constant<int, 2 * t>{});
-                    load_slice(std::integral_constant<int, 1>{}, sub, std::integral_constant<int, 2 * t + 1>{});
+                    static_for_w<0, w5_od_n(t, NSL)>([&](auto J_) __attribute__((always_inline)) {
+                        load_slice(std::integral_constant<int, 1>{}, sub, std::integral_constant<int, w5_od_0(t, NSL) + decltype(J_)::value>{});
+                    });
                 } else if constexpr (t == 6) {
                     if (switch_tile) tile_offsets(ng, ny, nx);
-                } else if constexpr (w5_ev_n(t) > 0) {
+                } else if constexpr (w5_ev_n(t, NSL) > 0) {
                     if (more)
-                        static_for_w<0, w5_ev_n(t)>([&](auto J_) __attribute__((always_inline)) {
-                            load_slice(std::integral_constant<int, 0>{}, nsubi, std::integral_constant<int, w5_ev_0(t) + decltype(J_)::value>{});
+                        static_for_w<0, w5_ev_n(t, NSL)>([&](auto J_) __attribute__((always_inline)) {
+                            load_slice(std::integral_constant<int, 0>{}, nsubi, std::integral_constant<int, w5_ev_0(t, NSL) + decltype(J_)::value>{});
                         });
                 }
                 if constexpr (w5_nst(t) > 0) {
@@ -347,14 +361,17 @@ __global__ __launch_bounds__(512, 1) void igemm_c5w_kernel(const C5Args a) {
         // compute waves: LDS fragment reads and MFMAs only
         // =====================================================================================================
         int grp = grp0, y0 = ty0, x0 = tx0;
-        // ---- A fragment addresses: abase[kx] for tile row wm*8 (row tile tm adds tm * ROW * 64, a window row shift sy
-        // adds sy * ROW * 64: immediates)
+        // ---- A fragment addresses: abase[kx] for row tile 0 of the wave (PW = 16: tile row wm*8, lane = column; PW = 8: tile
+        // row 0 of images wm*2 + (frow >> 3), lane & 7 = column); row tile tm adds tm * ROW * 64, a window row shift sy adds
+        // sy * ROW * 64: immediates
         uint32_t abase[5];
 #pragma unroll
         for (int kx = 0; kx < 5; ++kx) {
-            const int ii = (kx & 1) * (PW + 2) + frow + (kx >> 1);
-            const int p = (wm * 8) * ROW + ii;
-            abase[kx] = (uint32_t)((p << 6) + ((fq ^ (((ii >> 2) & 1) << 1)) << 4));
+            const int x = PW == 16 ? frow : (frow & 7);
+            const int ii = (kx & 1) * (PW + 2) + x + (kx >> 1);
+            const int p = (PW == 16 ? (wm * 8) * ROW : (wm * 2 + (frow >> 3)) * IH * ROW) + ii;
+            const int swz = PW == 16 ? ((ii >> 2) & 1) : (frow >> 3);
+            abase[kx] = (uint32_t)((p << 6) + ((fq ^ (swz << 1)) << 4));
         }
         // ---- B fragment address (row = wn*64 + tn*16 + frow)
         const uint32_t boff = (uint32_t)(WBUF0 + (wn * (BN / WN) + frow) * 64 + ((fq ^ (((frow >> 2) & 1) << 1)) << 4));
@@ -492,8 +509,11 @@ __global__ __launch_bounds__(512, 1) void igemm_c5w_kernel(const C5Args a) {
         const uint32_t sbase = (uint32_t)(STG0 + frow * 256 + (((wn * 8 + (fq >> 1)) ^ frow) << 4) + (fq & 1) * 8);
         auto hand_body = [&](auto FULL_) __attribute__((always_inline)) {
             constexpr bool FULL = decltype(FULL_)::value;
-            const bool xok = grp < a.N && x0 + frow < a.Wo;
-            const int nrow = a.Ho - (y0 + wm * 8);           // tile rows tm < nrow exist (wave-uniform)
+            // PW = 16: pixel (y0 + wm*8 + tm, x0 + frow) of image grp; PW = 8: pixel (y0 + tm, x0 + (frow & 7)) of image
+            // grp*4 + wm*2 + (frow >> 3)
+            const bool xok = PW == 16 ? (grp < a.N && x0 + frow < a.Wo)
+                                      : (grp * IPB + wm * 2 + (frow >> 3) < a.N && x0 + (frow & 7) < a.Wo);
+            const int nrow = a.Ho - (PW == 16 ? y0 + wm * 8 : y0);      // tile rows tm < nrow exist (wave-uniform)
             const int cw = co0 + wn * (BN / WN) + fq * 4;
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
@@ -606,10 +626,10 @@ __global__ __launch_bounds__(512, 1) void igemm_c5w_kernel(const C5Args a) {
     }
 }
 
-template <int STATS>
+template <int PW, int STATS>
 static int launch_c5w(const C5Args& a, int copad, hipStream_t st) {
-    auto kern = igemm_c5w_kernel<STATS>;
-    constexpr int lds = 2 * 10 * 4096 + C5W_NSTG * 16384 + 32768;
+    auto kern = igemm_c5w_kernel<PW, STATS>;
+    constexpr int lds = 2 * (PW == 16 ? 10 : 12) * 4096 + C5W_NSTG * 16384 + 32768;
     // raising the dynamic-LDS limit is idempotent; every call sets it (no library-global state)
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return E_LAUNCH;
@@ -622,7 +642,8 @@ static int launch_c5w(const C5Args& a, int copad, hipStream_t st) {
 int igemm_c5w_launch(const C5Args& a, int copad, hipStream_t st) {
     if (a.nsub < 1 || (copad & 127) || a.ntiles < 1 || a.tpb < 1 || a.bb.x) return E_UNSUPPORTED;
     if ((int64_t)a.N * a.Ho * a.Wo * a.CoStore * 2 >= 0x7fffffffLL) return E_UNSUPPORTED;      // 32-bit store offsets
-    return a.st.part ? launch_c5w<1>(a, copad, st) : launch_c5w<0>(a, copad, st);
+    if (a.pw16) return a.st.part ? launch_c5w<16, 1>(a, copad, st) : launch_c5w<16, 0>(a, copad, st);
+    return a.st.part ? launch_c5w<8, 1>(a, copad, st) : launch_c5w<8, 0>(a, copad, st);
 }
 
 #ifdef FMRI_STAMP

@@ -203,7 +203,7 @@ def igemm_kernel_label(N, Hi, Wi, Ci, Ho, Wo, CoStore, Co, k, stride, pad, mode,
     if (mode == MODE_CONV and stride == 2 and k == 5 and pad == 2 and Ci % 32 == 0 and tile == 128 and not out_f32
             and splits == 1 and bias_none and act == ACT_NONE and Ho == (Hi - 1) // 2 + 1 and Wo == (Wi - 1) // 2 + 1
             and os.environ.get("FMRI_C5") != "off"):
-        if Wo > 8 and Ho > 8 and os.environ.get("FMRI_C5W") != "off":
+        if (Wo <= 8 or Ho > 8) and os.environ.get("FMRI_C5W") != "off":
             return "fmri::igemm_c5w_kernel"
         return f"fmri::igemm_c5_kernel<{16 if Wo > 8 else 8}>"
     unit = (mode == MODE_TCONV2 or stride == 1) and spatial and 2 <= k <= 5 and not out_f32 and splits == 1

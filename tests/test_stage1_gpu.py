@@ -485,11 +485,13 @@ def test_stage1_full_batch_two_steps_match_oracle():
                     f.write(line + "\n")
             worst[(s, k)] = r
             # step 0: the north-star bar (1e-3; measured <= 5e-5).  step 1 = "after one step" on the engine's own updated
-            # weights: measured 3.1e-4 (mse / loss_encoder), 6.3e-4 (kl) in round 3 and 1.29e-3 / 2e-4 in round 2
-            # (profiles/r03_fullbatch_two_steps.log, r02_gradcheck.log) -- RMSprop's first update is +-3.16 lr per weight
-            # whatever the gradient's size, so ReLU-mask flips under fp16 storage move this number between builds;
-            # bound = the worst of the two rounds x 1.25
-            assert r < (LOSS_RTOL if s == 0 else 1.6e-3), (s, k, eng[s]["logs"][k], ref["logs"][k])
+            # weights: RMSprop's first update is +-3.16 lr per weight whatever the gradient's size, so the sign of every
+            # near-zero gradient decides where its weight goes, and that sign hangs on single fp16 roundings.  Measured in
+            # round 3 with nothing changed but which (numerically equivalent: 0.2503-0.2516 ulp mean error against fp64 for
+            # every one of them, tools/probes/conv_err.py) convolution kernels run: 3.1e-4, 7.2e-4, 1.66e-3, 2.4e-3
+            # (FMRI_C5W / FMRI_TC5W off-off, off-on, on-off, on-on; profiles/r03_fullbatch_routing.log); round 2: 1.29e-3.
+            # The bound is the spread, not a precision claim
+            assert r < (LOSS_RTOL if s == 0 else 3e-3), (s, k, eng[s]["logs"][k], ref["logs"][k])
 
 
 def test_decoder_fc_running_statistics_lazy_shadow_round_trips():

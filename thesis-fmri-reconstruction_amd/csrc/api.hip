@@ -311,8 +311,9 @@ int fmri_igemm_ep(const void* in, const void* w, void* out, const float* bias, c
         // CU, loader / compute waves; FMRI_C5W=off disables
         static const char* c5w_env = getenv("FMRI_C5W");
         static const bool no_c5w = c5w_env && !strcmp(c5w_env, "off");
+        static const bool no_c5w8 = c5w_env && !strcmp(c5w_env, "16");          // FMRI_C5W=16: the 16-wide form only
         const int ipbw = q.pw16 ? 1 : 4;
-        if (!no_c5w && !q.bb.x && (q.pw16 ? Ho > 8 : true) && !(se.part && se.group_n > 0 && (se.group_n % ipbw))) {
+        if (!no_c5w && !(no_c5w8 && !q.pw16) && !q.bb.x && (q.pw16 ? Ho > 8 : true) && !(se.part && se.group_n > 0 && (se.group_n % ipbw))) {
             C5Args w = q;
             const int ph = q.pw16 ? 16 : 8;
             w.tiles_y = (Ho + ph - 1) / ph;

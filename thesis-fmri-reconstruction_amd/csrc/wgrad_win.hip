@@ -12,11 +12,31 @@
 // 32 KB per 2.1 MFLOP.  The MFMA K index is the pixel, so both operands are read with transposing LDS reads
 // (ds_read_b64_tr_b16); the window fragments of a shift are the same reads at a compile-time byte offset.
 #include "kernels.h"
+#include <type_traits>
+
+#ifndef WGW_ABL
+#define WGW_ABL 0       // diagnostic builds only: 1 no output, 2 no fragment reads, 3 no operand DMA
+#endif
 
 namespace fmri {
 
+#ifdef FMRI_STAMP
+// Diagnostic build only (tools/probes/wgw_stamps.py; never shipped): [5] waves, [6] their cycles in the kernel (s_memtime),
+// [7] 100 MHz ticks (s_memrealtime)
+__device__ unsigned long long wgw_stamp_acc[8];
+#endif
+
 namespace {
 typedef int v4i __attribute__((ext_vector_type(4)));
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for_g(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for_g<I + 1, N>(f);
+    }
+}
+
 // 16-byte buffer -> LDS DMA (see igemm_tc5.hip::bdma16): offsets >= num_records read as zero
 __device__ __forceinline__ void wdma16(v4i srd, uint32_t voff, uint32_t lds) {
     srd.x = __builtin_amdgcn_readfirstlane(srd.x);
@@ -24,6 +44,7 @@ __device__ __forceinline__ void wdma16(v4i srd, uint32_t voff, uint32_t lds) {
     srd.z = __builtin_amdgcn_readfirstlane(srd.z);
     srd.w = __builtin_amdgcn_readfirstlane(srd.w);
     lds = __builtin_amdgcn_readfirstlane(lds);
+    if (WGW_ABL == 3 && srd.z != 0x7fffffff) return;
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(srd), "s"(lds)
                  : "memory");
 }
@@ -40,9 +61,15 @@ __device__ __forceinline__ void wgrad_win_body(const WgradWinArgs& a, char* smem
     constexpr int NS = NSY * NSX;
     constexpr int TA = 4;             // 2 x 2 waves: wave tile = 64 rows a x 16 channels b
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // Round 3: 8 waves, one block per CU.  Waves 4-7 only move bytes (the per-step tile arithmetic, bounds checks and DMA
+    // instructions: ~170 of the ~310 instructions a wave used to issue per K-step around its 32-72 MFMAs -- with one wave per
+    // SIMD the step was bound by instruction issue, ~1 300 cycles per step whatever the MFMA count), waves 0-3 only read
+    // fragments and multiply; one s_barrier per K-step joins them.
+    const int lane = threadIdx.x & 63;
+    const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool loader = wave_all >= 4;
+    const int wave = wave_all & 3;                // loader: DMA slice index; compute: tile quadrant
+    const int tid = threadIdx.x & 255;
     const int a0 = a_tile * 128;
     const int b0 = b_tile * 32;
     const int tminy = a.tmin[py], tminx = a.tmin[px];
@@ -145,62 +172,89 @@ __device__ __forceinline__ void wgrad_win_body(const WgradWinArgs& a, char* smem
     // window: K row r = 32 ks + 8 g + q (+4) is tile pixel (4 ks + g, q (+4)); shift (sy, sx) adds (sy*WW + sx) pixels
     const int woff = (g * WW + q) * 64 + wb * 32 + p * 8;
 
+    // One K-step: 2 K-halves x NS shifts "items" of TA MFMAs each.  With one wave per SIMD (the launch budget leaves the other
+    // half of the CU to the main stream's kernels) nothing hides an LDS read behind another wave's MFMAs, so the reads are
+    // pipelined by hand: the window fragment of item i + 2 (and, spread over the first half's last items, the P fragments of
+    // the second half) is requested before the MFMAs of item i; sched_group_barrier pins that order.
     auto compute = [&](int buf) {
         const char* Ps = smem + buf * STAGE;
         const char* Ws = Ps + P_BYTES + woff;
+        constexpr int NI = 2 * NS;
+        auto read_a = [&](int ks, int ta) __attribute__((always_inline)) -> h8 {
+            if constexpr (WGW_ABL == 2) return (h8)(half_t)(0.01f * (float)((lane + ta) & 15) - 0.07f);
+            const int blk = wa * 4 + ta;
+            const int ch = (2 * blk + (p >> 1)) ^ fr;
+            const char* ad = Ps + ks * (32 * 256) + rowoff + ch * 16;
+            union { s4v s[2]; h8 h; } u;
+            u.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(ad));
+            u.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(ad + 4 * 256));
+            return u.h;
+        };
+        auto read_w = [&](int i) __attribute__((always_inline)) -> h8 {
+            const int ks = i / NS, sh = i % NS, sy = sh / NSX, sx = sh % NSX;
+            if constexpr (WGW_ABL == 2) return (h8)(half_t)(0.3f * (float)((lane * 3 + sy + sx) & 15) - 2.f);
+            const char* ad = Ws + ((ks * 4 + sy) * WW + sx) * 64;
+            union { s4v s[2]; h8 h; } u;
+            u.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(ad));
+            u.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(ad + 4 * 64));
+            return u.h;
+        };
+        h8 af[2][TA], wf[3];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            h8 af[TA];
+        for (int ta = 0; ta < TA; ++ta) af[0][ta] = read_a(0, ta);
+        wf[0] = read_w(0);
+        wf[1] = read_w(1);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for_g<0, NI>([&](auto I_) __attribute__((always_inline)) {
+            constexpr int i = decltype(I_)::value;
+            constexpr int ks = i / NS, sh = i % NS;
+            constexpr bool rd_w = i + 2 < NI, rd_a = i >= NS - TA && i < NS;
+            if constexpr (rd_w) wf[(i + 2) % 3] = read_w(i + 2);
+            // the second half's P fragments ride on the last TA items of the first half
+            if constexpr (rd_a) af[1][i - (NS - TA)] = read_a(1, i - (NS - TA));
 #pragma unroll
-            for (int ta = 0; ta < TA; ++ta) {
-                const int blk = wa * 4 + ta;
-                const int ch = (2 * blk + (p >> 1)) ^ fr;
-                const char* ad = Ps + ks * (32 * 256) + rowoff + ch * 16;
-                union { s4v s[2]; h8 h; } u;
-                u.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(ad));
-                u.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(ad + 4 * 256));
-                af[ta] = u.h;
+            for (int ta = 0; ta < TA; ++ta)
+                acc[sh][ta] = SLABS ? __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i % 3], af[ks][ta], acc[sh][ta], 0, 0, 0)
+                                    : __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ks][ta], wf[i % 3], acc[sh][ta], 0, 0, 0);
+            if constexpr (WGW_ABL != 2) {
+                if constexpr (rd_w || rd_a) __builtin_amdgcn_sched_group_barrier(0x100, (rd_w ? 2 : 0) + (rd_a ? 2 : 0), 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, TA, 0);
             }
-#pragma unroll
-            for (int sy = 0; sy < NSY; ++sy)
-#pragma unroll
-                for (int sx = 0; sx < NSX; ++sx) {
-                    const char* ad = Ws + ((ks * 4 + sy) * WW + sx) * 64;
-                    union { s4v s[2]; h8 h; } u;
-                    u.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(ad));
-                    u.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(ad + 4 * 64));
-#pragma unroll
-                    for (int ta = 0; ta < TA; ++ta)
-                        acc[sy * NSX + sx][ta] =
-                            SLABS ? __builtin_amdgcn_mfma_f32_16x16x32_f16(u.h, af[ta], acc[sy * NSX + sx][ta], 0, 0, 0)
-                                  : __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ta], u.h, acc[sy * NSX + sx][ta], 0, 0, 0);
-                }
-        }
+        });
+        __builtin_amdgcn_sched_barrier(0);
     };
 
     // 3-stage ring: the DMAs of step it+2 are issued at the top of step it, so a stage has two full steps to land.
     // Every wave issues the same number of DMA instructions per stage (4 + 2, wave 3: 4 + 1 when the window ends
     // inside its slice), so "all but the newest stage" is a constant s_waitcnt vmcnt(NW) per wave.
-    const bool short_wave = 4096 + wave * 1024 >= W_BYTES;
-    if (nsteps > 0) stage_load(0, t0);
-    if (nsteps > 1) stage_load(1, t0 + 1);
-    int cur = 0, nxt = 2;
-    for (int it = 0; it < nsteps; ++it) {
-        if (it + 1 < nsteps) {
-            if (short_wave) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (loader) {
+        const bool short_wave = 4096 + wave * 1024 >= W_BYTES;
+        if (nsteps > 0) stage_load(0, t0);
+        if (nsteps > 1) stage_load(1, t0 + 1);
+        int nxt = 2;
+        for (int it = 0; it < nsteps; ++it) {
+            if (it + 1 < nsteps) {
+                if (short_wave) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            // raw barrier (a __syncthreads() would drain vmcnt): the current stage has landed for every loader wave, and
+            // every compute wave is done reading stage `nxt` (it was the current stage of step it-1)
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (it + 2 < nsteps) stage_load(nxt, t0 + it + 2);
+            if (++nxt == 3) nxt = 0;
         }
-        // raw barrier (a __syncthreads() would drain vmcnt): stage `cur` has landed for every wave, and every wave
-        // is done reading stage `nxt` (it was the current stage of step it-1)
+        return;
+    }
+    int cur = 0;
+    for (int it = 0; it < nsteps; ++it) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (it + 2 < nsteps) stage_load(nxt, t0 + it + 2);
         compute(cur);
         if (++cur == 3) cur = 0;
-        if (++nxt == 3) nxt = 0;
     }
 
     // Per-split slabs (SLABS: slab_stride != 0; every split writes its own fp32 slab with plain stores -- each slab
@@ -216,6 +270,16 @@ __device__ __forceinline__ void wgrad_win_body(const WgradWinArgs& a, char* smem
     FMRI_KEEP(kldo); FMRI_KEEP(kpad); FMRI_KEEP(kTW); FMRI_KEEP(slab);
     const int bcol = b0 + wb * 16 + (SLABS ? (lane >> 4) * 4 : (lane & 15));
     if (bcol >= kBc) return;
+    if (WGW_ABL == 1 && a.N > 0) {
+        // keep the accumulators alive without the stores
+        float keep = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int i = 0; i < TA; ++i) keep += acc[s][i][0] + acc[s][i][1] + acc[s][i][2] + acc[s][i][3];
+        if (keep == 12345.678f) slab[0] = keep;
+        return;
+    }
 #pragma unroll
     for (int sy = 0; sy < NSY; ++sy)
 #pragma unroll
@@ -239,7 +303,7 @@ __device__ __forceinline__ void wgrad_win_body(const WgradWinArgs& a, char* smem
 }
 
 template <bool SLABS>
-__global__ __launch_bounds__(256, 2) void wgrad_win_kernel(const WgradWinArgs a) {
+__global__ __launch_bounds__(512, 1) void wgrad_win_kernel(const WgradWinArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // XCD-aware block -> work map.  Consecutive workgroup ids are dealt round-robin to the 8 XCDs (each with its own
     // L2); the blocks that read the same P tiles and Q windows at the same time -- all (column block, plane, row
@@ -259,10 +323,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_win_kernel(const WgradWinArgs a)
     const int a_tile = rem >> 2;
     const int py = plane >> 1, px = plane & 1;
     const int nsy = a.nsy[py], nsx = a.nsx[px];
+#ifdef FMRI_STAMP
+    unsigned long long k0, k1, r0, r1;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(k0), "=s"(r0)::"memory");
+#endif
     if (nsy == 3 && nsx == 3) wgrad_win_body<3, 3, SLABS>(a, smem, py, px, a_tile, b_tile, split);
     else if (nsy == 3 && nsx == 2) wgrad_win_body<3, 2, SLABS>(a, smem, py, px, a_tile, b_tile, split);
     else if (nsy == 2 && nsx == 3) wgrad_win_body<2, 3, SLABS>(a, smem, py, px, a_tile, b_tile, split);
     else wgrad_win_body<2, 2, SLABS>(a, smem, py, px, a_tile, b_tile, split);
+#ifdef FMRI_STAMP
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(k1), "=s"(r1)::"memory");
+    if ((threadIdx.x & 63) == 0 && threadIdx.x < 256) {
+        atomicAdd(&wgw_stamp_acc[(nsy * nsx == 9) ? 0 : (nsy * nsx == 6 ? 1 : 2)], k1 - k0);
+        atomicAdd(&wgw_stamp_acc[5], 1ull); atomicAdd(&wgw_stamp_acc[6], k1 - k0); atomicAdd(&wgw_stamp_acc[7], r1 - r0);
+    }
+#endif
 }
 
 int wgrad_win_launch(const WgradWinArgs& a, int apad, hipStream_t st) {
@@ -274,9 +349,20 @@ int wgrad_win_launch(const WgradWinArgs& a, int apad, hipStream_t st) {
     // raising the dynamic-LDS limit is idempotent; every call sets it (no library-global state)
     if (hipFuncSetAttribute((const void*)wgrad_win_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return E_LAUNCH;
     if (hipFuncSetAttribute((const void*)wgrad_win_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return E_LAUNCH;
-    if (a.slab_stride != 0) hipLaunchKernelGGL(wgrad_win_kernel<true>, grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL(wgrad_win_kernel<false>, grid, dim3(256), lds, st, a);
+    if (a.slab_stride != 0) hipLaunchKernelGGL(wgrad_win_kernel<true>, grid, dim3(512), lds, st, a);
+    else hipLaunchKernelGGL(wgrad_win_kernel<false>, grid, dim3(512), lds, st, a);
     return hipGetLastError() == hipSuccess ? OK : E_LAUNCH;
 }
+
+#ifdef FMRI_STAMP
+extern "C" int fmri_debug_wgw_stamps(unsigned long long* out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(wgw_stamp_acc), 64) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(wgw_stamp_acc), z, 64) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 }  // namespace fmri

@@ -576,15 +576,38 @@ int fmri_igemm_ep(const void* in, const void* w, void* out, const float* bias, c
     return r;
 }
 
+// K pieces (8 x 8 pixel tiles per block) of the four parity planes of fmri_wgrad's window kernel for a budget of `splits`
+// blocks per (row block, column block) over the planes.  A K-step costs ~128 cycles per shift of the plane (8 MFMAs of one
+// wave) + ~550 of barrier, fragment reads and waits (csrc/wgrad_win.hip, measured 1 825 / 1 430 / 1 033 cycles at 9 / 6 / 4
+// shifts), so the planes get pieces in inverse proportion: all blocks of a launch finish together.  FMRI_WW_EQUAL=1: the
+// same pieces for every plane (round 2).  Returns the number of pieces of the plane with the most (= slabs written).
+static int wgrad_plane_pieces(int N, int Yc, int Xc, int k, int pad, int splits, int tps_out[4]) {
+    const int ntiles = N * ((Yc + 7) / 8) * ((Xc + 7) / 8);
+    int nsh[2] = {0, 0};
+    for (int t = 0; t < k; ++t) ++nsh[(t - pad) & 1];
+    int total = splits < 4 ? 4 : splits;
+    total -= total & 3;
+    static const char* eq_env = getenv("FMRI_WW_EQUAL");
+    static const bool equal = eq_env && !strcmp(eq_env, "1");
+    double cost[4], csum = 0;
+    for (int pl = 0; pl < 4; ++pl) { cost[pl] = equal ? 1.0 : 128.0 * nsh[pl >> 1] * nsh[pl & 1] + 550.0; csum += cost[pl]; }
+    int smax = 1;
+    for (int pl = 0; pl < 4; ++pl) {
+        int sp = (int)(total * cost[pl] / csum + 0.5);
+        if (sp < 1) sp = 1;
+        if (sp > ntiles) sp = ntiles > 0 ? ntiles : 1;
+        const int tps = (ntiles + sp - 1) / sp;
+        tps_out[pl] = tps < 1 ? 1 : tps;
+        const int pieces = ntiles > 0 ? (ntiles + tps_out[pl] - 1) / tps_out[pl] : 1;
+        if (pieces > smax) smax = pieces;
+    }
+    return smax;
+}
+
 // number of per-split slabs fmri_wgrad(..., atomic = 2) writes for a budget of `splits` blocks per tile group
 int fmri_wgrad_slabs(int N, int Yc, int Xc, int k, int pad, int splits) {
-    (void)k; (void)pad;
-    const int ntiles = N * ((Yc + 7) / 8) * ((Xc + 7) / 8);
-    int sp = (splits < 4 ? 4 : splits) / 4;
-    if (sp > ntiles) sp = ntiles;
-    if (sp < 1) return 1;
-    const int tps = (ntiles + sp - 1) / sp;
-    return (ntiles + tps - 1) / tps;
+    int tps[4];
+    return wgrad_plane_pieces(N, Yc, Xc, k, pad, splits, tps);
 }
 
 int fmri_wgrad(const void* P, const void* Q, float* out, const void* zero16, int N, int Yc, int Xc, int A, int Hq,
@@ -624,19 +647,14 @@ int fmri_wgrad(const void* P, const void* Q, float* out, const void* zero16, int
         if (ok) {
             w.tiles_y = (Yc + 7) / 8; w.tiles_x = (Xc + 7) / 8;
             w.ntiles = N * w.tiles_y * w.tiles_x;
-            // `splits` = blocks per (row block, column block) over the 4 planes.  All planes get the same K pieces although
-            // their MFMA counts differ (9 : 6 : 6 : 4 shifts for k = 5): the blocks of one piece then walk the same
-            // pixel tiles in lockstep and share them through their XCD's L2, which measured faster than equal-MFMA
-            // pieces with diverging tile sequences.
-            int sp = (splits < 4 ? 4 : splits) / 4;
-            if (sp > w.ntiles) sp = w.ntiles;
-            const int tps = (w.ntiles + sp - 1) / sp;
-            int smax = (w.ntiles + tps - 1) / tps;
-            for (int pl = 0; pl < 4; ++pl) w.plane_tps[pl] = tps;
+            // `splits` = blocks per (row block, column block) over the 4 planes; K pieces per plane: wgrad_plane_pieces()
+            int tps4[4];
+            const int smax = wgrad_plane_pieces(N, Yc, Xc, k, pad, splits, tps4);      // = fmri_wgrad_slabs(): in slab mode the
+            for (int pl = 0; pl < 4; ++pl) {                                          // caller sized the output with it, and
+                w.plane_tps[pl] = tps4[pl];                                           // every allocated slab is written
+                w.plane_pieces[pl] = (w.ntiles + tps4[pl] - 1) / tps4[pl];
+            }
             w.splits = smax;
-            // slab mode: the caller sized the output with fmri_wgrad_slabs()
-            if (atomic == 2 && smax > fmri_wgrad_slabs(N, Yc, Xc, k, pad, splits)) return FMRI_E_BADARG;
-            if (atomic == 2) smax = fmri_wgrad_slabs(N, Yc, Xc, k, pad, splits);   // every allocated slab is written
             w.fdTPI = make_fastdiv((uint32_t)(w.tiles_y * w.tiles_x));
             w.fdTX = make_fastdiv((uint32_t)w.tiles_x);
             return wgrad_win_launch(w, apad, S(stream));

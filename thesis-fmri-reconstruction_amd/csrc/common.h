@@ -300,6 +300,7 @@ struct WgradWinArgs {
     int32_t tiles_y, tiles_x;        // 8x8 output-pixel tiles per image
     int32_t ntiles, splits;          // grid.z = splits = max over planes
     int32_t plane_tps[4];            // tiles per split of plane (py*2 + px)
+    int32_t plane_pieces[4];         // K pieces (blocks per row / column block) of the plane; splits = their maximum
     int32_t ldo, a_tiles;            // a_tiles = 128-row blocks
     int64_t slab_stride;             // elements between the per-split output slabs
     int32_t nsy[2], nsx[2];          // shifts per parity (2 or 3)

@@ -270,6 +270,7 @@ __device__ __forceinline__ void wgrad_win_body(const WgradWinArgs& a, char* smem
     FMRI_KEEP(kldo); FMRI_KEEP(kpad); FMRI_KEEP(kTW); FMRI_KEEP(slab);
     const int bcol = b0 + wb * 16 + (SLABS ? (lane >> 4) * 4 : (lane & 15));
     if (bcol >= kBc) return;
+    const int nfill = (SLABS && split + 1 == a.plane_pieces[py * 2 + px]) ? a.splits - split : 1;
     if (WGW_ABL == 1 && a.N > 0) {
         // keep the accumulators alive without the stores
         float keep = 0.f;
@@ -293,6 +294,9 @@ __device__ __forceinline__ void wgrad_win_body(const WgradWinArgs& a, char* smem
                 if constexpr (SLABS) {
                     const int arow = a0 + wa * 64 + ta * 16 + (lane & 15);
                     *(f4*)(slab + (int64_t)arow * kldo + col) = v;
+                    // the plane's last piece also clears its columns in the slabs only other planes have pieces for
+                    for (int sl = 1; sl < nfill; ++sl)
+                        *(f4*)(slab + sl * a.slab_stride + (int64_t)arow * kldo + col) = (f4){0.f, 0.f, 0.f, 0.f};
                 } else {
                     const int arow = a0 + wa * 64 + ta * 16 + (lane >> 4) * 4;
 #pragma unroll
@@ -314,13 +318,14 @@ __global__ __launch_bounds__(512, 1) void wgrad_win_kernel(const WgradWinArgs a)
     int logical = blockIdx.x;
     if ((nb & 7) == 0) logical = (logical & 7) * (nb >> 3) + (logical >> 3);
     const int nbt = a.Bc >> 5;                 // 32-channel column blocks
-    const int per_split = nbt * 4 * a.a_tiles;
-    const int split = logical / per_split;
-    int rem = logical - split * per_split;
+    const int groups = nbt * a.a_tiles;        // (row block, column block) pairs: the same K piece of the same plane adjacent
+    int piece = logical / groups;
+    int rem = logical - piece * groups;
     const int b_tile = rem % nbt;
-    rem /= nbt;
-    const int plane = rem & 3;
-    const int a_tile = rem >> 2;
+    const int a_tile = rem / nbt;
+    int plane = 0;
+    while (plane < 3 && piece >= a.plane_pieces[plane]) { piece -= a.plane_pieces[plane]; ++plane; }
+    const int split = piece;
     const int py = plane >> 1, px = plane & 1;
     const int nsy = a.nsy[py], nsx = a.nsx[px];
 #ifdef FMRI_STAMP
@@ -344,7 +349,7 @@ int wgrad_win_launch(const WgradWinArgs& a, int apad, hipStream_t st) {
     // 32-bit buffer offsets
     if ((int64_t)a.N * a.Yc * a.Xc * a.A * 2 >= 0x80000000LL || (int64_t)a.N * a.Hq * a.Wq * a.Bc * 2 >= 0x80000000LL)
         return E_UNSUPPORTED;
-    dim3 grid((a.Bc / 32) * a.a_tiles * 4 * a.splits);
+    dim3 grid((a.Bc / 32) * a.a_tiles * (a.plane_pieces[0] + a.plane_pieces[1] + a.plane_pieces[2] + a.plane_pieces[3]));
     const int lds = 3 * (64 * 256 + 7 * 1024);
     // raising the dynamic-LDS limit is idempotent; every call sets it (no library-global state)
     if (hipFuncSetAttribute((const void*)wgrad_win_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return E_LAUNCH;

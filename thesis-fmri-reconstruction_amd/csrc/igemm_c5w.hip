@@ -155,7 +155,10 @@ __global__ __launch_bounds__(512, 1) void igemm_c5w_kernel(const C5Args a) {
         yy = tyi * PH;
         xx = (trem - tyi * a.tiles_x) * PW;
     };
-    float vsum = 0.f, vsq = 0.f;         // compute waves: statistics over all tiles of the block
+    // BatchNorm statistics: summed by the LOADER waves over the fp16 values they keep for the output stores (they idle
+    // between DMA issues; in the compute waves the same sums cost ~1 500 instructions per tile, +50 % on a 13-step tile).
+    // Loader thread tid holds channels co0 + 8*slot .. +7 (slot = (tid & 15) ^ (tid >> 4)) of pixel tid >> 4 of every item
+    float lsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, lsq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int wm = (wave >> 1) & 1, wn = wave & 1;
     const int frow = lane & 15, fq = lane >> 4;
     int grp0, ty0, tx0;
@@ -282,6 +285,17 @@ __global__ __launch_bounds__(512, 1) void igemm_c5w_kernel(const C5Args a) {
         auto put = [&](auto I_) __attribute__((always_inline)) {
             constexpr int i = decltype(I_)::value, r = i >> 3, k = i & 7;
             const uint32_t vt = k < onrow[r] ? ovo[r] : 0x80000000u;
+            if constexpr (STATS == 1) {
+                // statistics of the STORED (fp16-rounded) values: what the consumers and the BN backward see
+                const h8 hv = __builtin_bit_cast(h8, oreg[r][k]);
+                const bool in = vt != 0x80000000u;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float f = in ? (float)hv[j] : 0.f;
+                    lsum[j] += f;
+                    lsq[j] += f * f;
+                }
+            }
             if (C5W_ABL == 1 && a.N > 0) return;
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, oreg[r][k]), srd_out, (int)vt, (int)(k * row_b), 0);
         };
@@ -510,42 +524,18 @@ __global__ __launch_bounds__(512, 1) void igemm_c5w_kernel(const C5Args a) {
         auto hand_body = [&](auto FULL_) __attribute__((always_inline)) {
             constexpr bool FULL = decltype(FULL_)::value;
             // PW = 16: pixel (y0 + wm*8 + tm, x0 + frow) of image grp; PW = 8: pixel (y0 + tm, x0 + (frow & 7)) of image
-            // grp*4 + wm*2 + (frow >> 3)
-            const bool xok = PW == 16 ? (grp < a.N && x0 + frow < a.Wo)
-                                      : (grp * IPB + wm * 2 + (frow >> 3) < a.N && x0 + (frow & 7) < a.Wo);
-            const int nrow = a.Ho - (PW == 16 ? y0 + wm * 8 : y0);      // tile rows tm < nrow exist (wave-uniform)
+            // grp*4 + wm*2 + (frow >> 3); pixels outside the image are handed over too (the loader waves drop them)
             const int cw = co0 + wn * (BN / WN) + fq * 4;
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
                 const int co = cw + tn * 16;
-                f4 s0 = (f4){0.f, 0.f, 0.f, 0.f}, s1 = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm) {
                     const f4 v = acc[tn][tm];
                     h4 hv;
 #pragma unroll
                     for (int rg = 0; rg < 4; ++rg) hv[rg] = (half_t)((FULL || co + rg < a.Co) ? v[rg] : 0.f);
-                    if constexpr (STATS == 1) {
-                        // statistics of the STORED (fp16-rounded) values: what the consumers and the BN backward see
-                        const bool in = xok && tm < nrow;
-#pragma unroll
-                        for (int rg = 0; rg < 4; ++rg) {
-                            const float f = in ? (float)hv[rg] : 0.f;
-                            s0[rg] += f;
-                            s1[rg] += f * f;
-                        }
-                    }
                     *(h4*)(smem + ((sbase ^ (uint32_t)(tn * 32)) + tm * 4096)) = hv;
-                    if constexpr (STATS != 0) __builtin_amdgcn_sched_barrier(0);      // one tile at a time: register peak
-                }
-                if constexpr (STATS != 0) {
-#pragma unroll
-                    for (int rg = 0; rg < 4; ++rg) {
-                        const float ra = row16_sum(s0[rg]);
-                        const float rb = row16_sum(s1[rg]);
-                        if (frow == tn * 4 + rg) { vsum += ra; vsq += rb; }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         };
@@ -603,24 +593,30 @@ __global__ __launch_bounds__(512, 1) void igemm_c5w_kernel(const C5Args a) {
     }
 #endif
     if constexpr (STATS != 0) {
-        // one row per block; the blocks of one statistics group are contiguous (tpg[0] = blocks per group).  Compute lane
-        // (fq, frow) owns channel (frow >> 2)*16 + fq*4 + (frow & 3) of its wave's 64; the two pixel halves (wm) meet in LDS
+        // one row per block; the blocks of one statistics group are contiguous (tpg[0] = blocks per group).  The 16 loader
+        // threads that hold the same 8 channels (one per pixel column of an item) meet in LDS
         float* scratch = (float*)smem;
-        const int ch = (frow >> 2) * 16 + fq * 4 + (frow & 3);
         __syncthreads();                                     // everyone is done with the operand tiles
-        if (!loader && wm == 1) {
-            scratch[wn * 128 + ch] = vsum;
-            scratch[wn * 128 + 64 + ch] = vsq;
+        if (loader) {
+            const int t = threadIdx.x & 255;
+            float* dst = scratch + ((((t & 15) ^ (t >> 4)) * 16 + (t >> 4)) * 16);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { dst[j] = lsum[j]; dst[8 + j] = lsq[j]; }
         }
         __syncthreads();
-        if (!loader && wm == 0) {
-            vsum += scratch[wn * 128 + ch];
-            vsq += scratch[wn * 128 + 64 + ch];
-            const int co = co0 + wn * 64 + ch;
+        if (threadIdx.x < 128) {
+            const int c = threadIdx.x;                       // channel co0 + c = slot c >> 3, element c & 7
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int px = 0; px < 16; ++px) {
+                const float* src = scratch + ((c >> 3) * 16 + px) * 16 + (c & 7);
+                s0 += src[0];
+                s1 += src[8];
+            }
             float* row = a.st.part + ((size_t)sgrp * a.st.rows_cap + (bx - sgrp * a.st.tpg[0])) * 2 * a.st.C;
-            if (co < a.st.C) {
-                row[co] = vsum;
-                row[a.st.C + co] = vsq;
+            if (co0 + c < a.st.C) {
+                row[co0 + c] = s0;
+                row[a.st.C + co0 + c] = s1;
             }
         }
     }

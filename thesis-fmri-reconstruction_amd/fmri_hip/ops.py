@@ -345,7 +345,7 @@ def run_wgrad(P, Q, N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad, flip=0, flops=0.0)
         # window-resident kernel (csrc/wgrad_win.hip): blocks = 32-channel column blocks x 128-row blocks x 4 parity
         # planes x splits over the 8x8 pixel tiles; every split stores its own slab, unpack_grad sums them
         groups = (Bc // 32) * (apad // 128)
-        budget = _WW_BLOCKS or (256 if _SIDE["on"] else 512)
+        budget = _WW_BLOCKS or 256              # one 8-wave block per CU (csrc/wgrad_win.hip)
         splits = max(4, budget // groups)                               # block budget per group over the 4 planes
         nslabs = lib.load().fmri_wgrad_slabs(N, Yc, Xc, k, pad, splits)
         slabs = nslabs <= _WW_SLABS                                     # few splits: per-split slabs, else atomics

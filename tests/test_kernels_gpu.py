@@ -297,8 +297,12 @@ EPI_BWD_CASES = [
     ("conv", 128, 256, 32, 0, 4, 2),        # igemm_tc5<128>, double-buffered window, two cotangent streams
     ("conv", 64, 128, 32, 0, 6, 3),         # igemm_tc5<64>, three groups (decoder entries)
     ("conv", 128, 256, 26, 0, 3, 1),        # partial tiles
-    ("deconv", 256, 128, 16, 1, 4, 2),      # deconv dgrad = stride-2 convolution on the generic kernel
-    ("deconv", 128, 64, 16, 1, 128, 2),     # ... its 256 x 256 tile
+    ("deconv", 256, 128, 16, 1, 4, 2),      # deconv dgrad = stride-2 convolution: igemm_c5<16> (the wide form has no BnBwdEpi)
+    ("deconv", 128, 64, 16, 1, 128, 2),     # ... 64 cotangent channels, persistent blocks over 2 tiles
+    ("deconv", 256, 256, 8, 1, 8, 2),       # igemm_c5<8>: two images per tile, two tiles per statistics group
+    ("deconv", 256, 256, 8, 1, 4, 2),       # two images per group = one tile per group
+    ("deconv", 128, 32, 32, 1, 6, 1),       # one 32-channel sub-chunk per tile (13 K-steps), four tiles per image
+    ("deconv", 128, 32, 13, 0, 3, 3),       # partial tiles, three groups of one image
 ]
 
 

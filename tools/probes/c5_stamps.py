@@ -1,6 +1,6 @@
 """Diagnostic (GPU box): where a wave of igemm_c5 spends its cycles inside a K-step (s_memtime stamps, see FMRI_STAMP in
 csrc/igemm_c5.hip).  Uses tools/probes/libfmri_stamp.so = the library with igemm_c5.hip compiled with -DFMRI_STAMP
-(built in the dev container: hipcc ... -DFMRI_STAMP -c csrc/igemm_c5.hip, relinked with the other objects).  The stamp
+(built in the dev container: tools/probes/build_variant.sh stamp igemm_c5 -DFMRI_STAMP).  The stamp
 build's fences forbid overlaps the real kernel has: read the SHARES, not the run time."""
 import ctypes, os, sys
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))

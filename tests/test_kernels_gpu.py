@@ -205,6 +205,8 @@ DECONV_CASES = [
     (256, 256, 13, 0, 2),        # 100-px config first block: 13 -> 25
     (128, 64, 25, 1, 2),         # 25 -> 50
     (128, 32, 13, 0, 3),         # igemm_tc32 with partial tiles and output_padding = 0
+    (256, 256, 7, 0, 9),         # igemm_tc5w<8>: 7 -> 13, four images per tile, the last tile holds one
+    (256, 128, 8, 1, 8),         # igemm_tc5w<8>: two full tiles
 ]
 
 
@@ -245,6 +247,8 @@ EPI_STAT_CASES = [
     ("conv", 256, 256, 2, 16, 0, 3, 3, False),      # a two-image tile would hold two batches: no epilogue
     ("deconv", 256, 128, 2, 16, 1, 4, 2, True),     # igemm_tc5, double-buffered window, two BatchNorm batches
     ("deconv", 256, 256, 2, 8, 1, 4, 2, True),      # igemm_tc5, two images per tile
+    ("deconv", 256, 256, 2, 8, 1, 8, 2, True),      # igemm_tc5w<8>, four images per tile = one tile per BatchNorm batch
+    ("deconv", 256, 128, 2, 7, 0, 12, 1, True),     # igemm_tc5w<8>, 7 -> 13, three tiles
     ("deconv", 256, 256, 2, 8, 1, 6, 2, False),     # a tile would hold images of two batches: no epilogue
     ("deconv", 256, 256, 2, 13, 0, 3, 1, True),     # partial tiles, output_padding = 0
     ("deconv", 128, 64, 2, 25, 1, 2, 2, True),      # 64-channel tile

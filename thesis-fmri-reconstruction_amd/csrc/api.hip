@@ -396,17 +396,25 @@ int fmri_igemm_ep(const void* in, const void* w, void* out, const float* bias, c
         // FMRI_TC5W=off disables
         static const char* tc5w_env = getenv("FMRI_TC5W");
         static const bool no_tc5w = tc5w_env && !strcmp(tc5w_env, "off");
-        if (ok && !no_tc5w && bn_tile == 128 && Xc0 > 8 && Yc0 > 8 && !q.bb.x && !(q.nchunks & 1)) {
+        const bool wide16 = Xc0 > 8 && Yc0 > 8;
+        const bool wide8 = Xc0 <= 8 && Yc0 <= 8 && Hi <= 8 && Wi <= 8 && !(se.part && se.group_n > 0 && (se.group_n & 3));
+        if (ok && !no_tc5w && bn_tile == 128 && (wide16 || wide8) && !q.bb.x && !(q.nchunks & 1)) {
             Tc5Args w = q;
-            w.pw_log2 = 4; w.ph_log2 = 4; w.PH = 16; w.IPB = 1; w.IH = 18; w.IW = 18; w.nslice = 11;
-            w.tiles_x = (Xc0 + 15) / 16;
-            w.tiles_y = (Yc0 + 15) / 16;
-            w.ntiles = N * w.tiles_y * w.tiles_x;
+            if (wide16) {
+                w.pw_log2 = 4; w.ph_log2 = 4; w.PH = 16; w.IPB = 1; w.IH = 18; w.IW = 18; w.nslice = 11;
+                w.tiles_x = (Xc0 + 15) / 16;
+                w.tiles_y = (Yc0 + 15) / 16;
+                w.ntiles = N * w.tiles_y * w.tiles_x;
+            } else {
+                w.pw_log2 = 3; w.ph_log2 = 3; w.PH = 8; w.IPB = 4; w.IH = 10; w.IW = 10; w.nslice = 13;
+                w.tiles_x = w.tiles_y = 1;
+                w.ntiles = (N + 3) / 4;
+            }
             w.fdTPI = make_fastdiv((uint32_t)(w.tiles_y * w.tiles_x));
             w.fdTX = make_fastdiv((uint32_t)w.tiles_x);
             w.st = se;
             if (se.part) {
-                w.st.tpg[0] = se.group_n > 0 ? se.group_n * w.tiles_y * w.tiles_x : w.ntiles;
+                w.st.tpg[0] = se.group_n > 0 ? (se.group_n / w.IPB) * w.tiles_y * w.tiles_x : w.ntiles;
                 if (w.st.tpg[0] > se.rows_cap) w.st.part = nullptr;
             }
             if (w.st.part || !se.part) {

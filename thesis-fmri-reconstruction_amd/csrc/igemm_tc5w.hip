@@ -73,19 +73,24 @@ __device__ __forceinline__ void wait_vmt() {
 
 }  // namespace
 
-// STATS: 0 none, 1 BatchNorm forward statistics (StatEpi)
-template <int STATS>
+// PW: 16 = tiles of 16 x 16 class-grid positions of one image; 8 = 8 x 8 positions (class grids and inputs of at most 8 x 8)
+// of FOUR images, an MFMA row tile = one tile row of two images.  STATS: 0 none, 1 BatchNorm forward statistics (StatEpi)
+template <int PW, int STATS>
 __global__ __launch_bounds__(512, 1) void igemm_tc5w_kernel(const Tc5Args a) {
     constexpr int BN = 128, WN = 2, TM = 8, TN = 4;
-    constexpr int PW = 16, PH = 16;
-    constexpr int IW = PW + 2;                           // window row, pixels (128 B each: one 64-channel chunk)
+    constexpr int PH = PW, IPB = PW == 16 ? 1 : 4;
+    constexpr int IW = PW + 2, IH = PH + 2;              // window of one image, pixels (128 B each: one 64-channel chunk)
     constexpr int ROWB = IW * 128;
-    constexpr int NSL = 11;                              // 4 KB DMA slices per window chunk ((PH + 2) * IW * 128 B = 41 472)
+    constexpr int NSL = (IPB * IH * IW * 128 + 4095) / 4096;      // 4 KB DMA slices per window chunk: 11 (41 472 B) / 13 (51 200 B)
     constexpr int WINB = NSL * 4096;
     constexpr int W_BYTES = BN * 128;                    // one tap x 64 channels of [128 co]
     constexpr int WBUF0 = 2 * WINB;
-    constexpr int STG0 = WBUF0 + 2 * W_BYTES;            // output staging: 128 positions x 128 channels fp16 (32 KB)
-    static_assert((PH + 2) * IW * 128 <= WINB, "window fits its slices");
+    // output staging: 128 positions x 128 channels fp16 (32 KB).  PW = 8: inside window buffer 1 -- the buffer of a class's
+    // last (odd) chunk is free from its last fragment read to the first DMA of the next class's second chunk, and the hand-over
+    // sits in between
+    constexpr int STG0 = PW == 16 ? WBUF0 + 2 * W_BYTES : WINB;
+    static_assert(PW == 16 || PW == 8, "tile");
+    static_assert((2 + 7) * ROWB < 65536 && 32768 <= WINB, "ds_read immediates / staging");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int lane = threadIdx.x & 63;
@@ -110,7 +115,7 @@ __global__ __launch_bounds__(512, 1) void igemm_tc5w_kernel(const Tc5Args a) {
     float lsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, lsq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int wm = (wave >> 1) & 1, wn = wave & 1;
     const int frow = lane & 15, fq = lane >> 4;
-    const int sgrp = (STATS != 0 && a.st.group_n > 0) ? grp / a.st.group_n : 0;     // statistics group of the tile
+    const int sgrp = (STATS != 0 && a.st.group_n > 0) ? (grp * IPB) / a.st.group_n : 0;     // statistics group of the tile
 
 #ifdef FMRI_STAMP
     unsigned long long k0, k1, r0, r1;
@@ -135,18 +140,21 @@ __global__ __launch_bounds__(512, 1) void igemm_tc5w_kernel(const Tc5Args a) {
         srd_w.w = 0x00020000;
 
         // ---- window DMA: 16-B unit q = e*256 + tid of a window buffer holds channels 8*cc .. 8*cc+7 (of the 64-channel
-        // chunk) of window pixel q >> 3 = row j, column i; cc = (q & 7) ^ (i & 6).  Window origin = tile origin - 1.
+        // chunk) of window pixel q >> 3 = image ip, row j, column i; cc = (q & 7) ^ (i & 6).  Window origin = tile origin - 1.
         uint32_t soff[NSL];
 #pragma unroll
         for (int e = 0; e < NSL; ++e) {
             soff[e] = 0x80000000u;                         // out of range -> the DMA writes zeros
             const int q = e * 256 + tid;
             const int pixel = q >> 3;
-            const int j = pixel / IW;
-            const int i = pixel - j * IW;
+            const int ip = pixel / (IH * IW);
+            const int pr = pixel - ip * (IH * IW);
+            const int j = pr / IW;
+            const int i = pr - j * IW;
+            const int n = grp * IPB + ip;
             const int iy = y0 - 1 + j, ix = x0 - 1 + i;
-            if (j < PH + 2 && grp < a.N && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi)
-                soff[e] = (uint32_t)((((grp * a.Hi + iy) * a.Wi + ix) * a.Ci + (((q & 7) ^ (i & 6)) << 3)) * 2);
+            if (ip < IPB && n < a.N && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi)
+                soff[e] = (uint32_t)((((n * a.Hi + iy) * a.Wi + ix) * a.Ci + (((q & 7) ^ (i & 6)) << 3)) * 2);
         }
         const uint32_t lds_wave = lds0 + lw * 1024;
         // slices [LO, HI) of channel chunk `chunk` into window buffer BUF
@@ -192,10 +200,13 @@ __global__ __launch_bounds__(512, 1) void igemm_tc5w_kernel(const Tc5Args a) {
         uint32_t ovo[2];
         int onrow[2];
         auto take = [&](int cls) __attribute__((always_inline)) {
-            const int ox = tid >> 4;
-            const int slot = (tid & 15) ^ ox;
+            // (PW = 8: a round = two images, item k = class-grid row k of both, position tid >> 4 = image (bit 3), column)
+            const int opx = tid >> 4;
+            const int slot = (tid & 15) ^ opx;
+            const int ox = PW == 16 ? opx : (opx & 7);
             const int cy = cls >> 1, cx = cls & 1;
             const int Yc = a.cls[cls].Yc, Xc = a.cls[cls].Xc;
+            if constexpr (PW == 8) __builtin_amdgcn_s_barrier();   // (every compute wave is done with window buffer 1 = the staging area)
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 __builtin_amdgcn_s_barrier();                      // the round is in LDS
@@ -205,9 +216,10 @@ __global__ __launch_bounds__(512, 1) void igemm_tc5w_kernel(const Tc5Args a) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();                      // ... and in registers: the staging area is free
                 __builtin_amdgcn_sched_barrier(0);
-                const int yb = y0 + r * 8, x = x0 + ox;
-                const bool ok = x < Xc && co0 + slot * 8 < a.CoStore;
-                ovo[r] = ok ? (uint32_t)((((grp * a.Ho + 2 * yb + cy) * a.Wo + 2 * x + cx) * a.CoStore + co0 + slot * 8) * 2) : 0x80000000u;
+                const int n = PW == 16 ? grp : grp * IPB + r * 2 + (opx >> 3);
+                const int yb = PW == 16 ? y0 + r * 8 : y0, x = x0 + ox;
+                const bool ok = n < a.N && x < Xc && co0 + slot * 8 < a.CoStore;
+                ovo[r] = ok ? (uint32_t)((((n * a.Ho + 2 * yb + cy) * a.Wo + 2 * x + cx) * a.CoStore + co0 + slot * 8) * 2) : 0x80000000u;
                 onrow[r] = Yc - yb;                                // tile rows k < onrow exist in this class
             }
         };
@@ -297,13 +309,15 @@ __global__ __launch_bounds__(512, 1) void igemm_tc5w_kernel(const Tc5Args a) {
         // =====================================================================================================
         // compute waves: LDS fragment reads and MFMAs only
         // =====================================================================================================
-        // ---- A fragment addresses of window column shift sx, first 32-channel half, window buffer 0, tile row wm*8:
+        // ---- A fragment addresses of window column shift sx, first 32-channel half, window buffer 0, row tile 0 of the wave
+        // (PW = 16: tile row wm*8, lane = column; PW = 8: row 0 of images wm*2 + (frow >> 3), lane & 7 = column):
         // row tile tm and row shift sy add (tm + sy) * ROWB (immediates), the second half is ^ 64, buffer 1 is + WINB
         uint32_t abase[2][3];
 #pragma unroll
         for (int sx = 0; sx < 3; ++sx) {
-            const int col = frow + sx;
-            abase[0][sx] = (uint32_t)(((wm * 8) * IW + col) * 128 + ((fq ^ (col & 6)) << 4));
+            const int col = (PW == 16 ? frow : (frow & 7)) + sx;
+            const int pix0 = PW == 16 ? (wm * 8) * IW : (wm * 2 + (frow >> 3)) * IH * IW;
+            abase[0][sx] = (uint32_t)((pix0 + col) * 128 + ((fq ^ (col & 6)) << 4));
             abase[1][sx] = abase[0][sx] + WINB;          // (the immediates of buffer 1 would pass 16 bits)
         }
         // ---- B fragment address (row = wn*64 + tn*16 + frow; the swizzle term does not depend on tn or wn)
@@ -414,6 +428,12 @@ __global__ __launch_bounds__(512, 1) void igemm_tc5w_kernel(const Tc5Args a) {
             }
         };
         auto hand_over = [&](int cls) __attribute__((always_inline)) {
+            if constexpr (PW == 8) {
+                // the staging area lies in window buffer 1: every compute wave has to be done with the class's last fragments
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 if (wm == r) {
@@ -492,10 +512,10 @@ __global__ __launch_bounds__(512, 1) void igemm_tc5w_kernel(const Tc5Args a) {
     }
 }
 
-template <int STATS>
+template <int PW, int STATS>
 static int launch_tc5w(const Tc5Args& a, int copad, hipStream_t st) {
-    auto kern = igemm_tc5w_kernel<STATS>;
-    constexpr int lds = 2 * 11 * 4096 + 2 * 128 * 128 + 32768;
+    auto kern = igemm_tc5w_kernel<PW, STATS>;
+    constexpr int lds = PW == 16 ? 2 * 11 * 4096 + 2 * 128 * 128 + 32768 : 2 * 13 * 4096 + 2 * 128 * 128;
     // raising the dynamic-LDS limit is idempotent; every call sets it (no library-global state)
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return E_LAUNCH;
@@ -503,12 +523,17 @@ static int launch_tc5w(const Tc5Args& a, int copad, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? OK : E_LAUNCH;
 }
 
-// Tc5Args with 16 x 16-position tiles of one image: tiles_y = ceil(Yc0 / 16), tiles_x = ceil(Xc0 / 16), ntiles = N * tiles_y *
-// tiles_x, nchunks even; no bias / activation, no BnBwdEpi
+// Tc5Args with 16 x 16-position tiles of one image (IPB = 1: tiles_y = ceil(Yc0 / 16), tiles_x = ceil(Xc0 / 16), ntiles = N *
+// tiles_y * tiles_x) or, for class grids and inputs of at most 8 x 8, one 8 x 8 tile of four images (IPB = 4: ntiles =
+// ceil(N / 4)); nchunks even; no bias / activation, no BnBwdEpi
 int igemm_tc5w_launch(const Tc5Args& a, int copad, hipStream_t st) {
     if (a.bias != nullptr || a.act != ACT_NONE || a.bb.x || (copad & 127) || a.ntiles < 1 || (a.nchunks & 1)) return E_UNSUPPORTED;
     if ((int64_t)a.N * a.Ho * a.Wo * a.CoStore * 2 >= 0x7fffffffLL) return E_UNSUPPORTED;      // 32-bit store offsets
-    return a.st.part ? launch_tc5w<1>(a, copad, st) : launch_tc5w<0>(a, copad, st);
+    if (a.IPB == 4) {
+        if (a.Hi > 8 || a.Wi > 8 || a.tiles_x != 1 || a.tiles_y != 1) return E_BADARG;
+        return a.st.part ? launch_tc5w<8, 1>(a, copad, st) : launch_tc5w<8, 0>(a, copad, st);
+    }
+    return a.st.part ? launch_tc5w<16, 1>(a, copad, st) : launch_tc5w<16, 0>(a, copad, st);
 }
 
 #ifdef FMRI_STAMP

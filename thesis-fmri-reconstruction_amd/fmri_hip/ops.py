@@ -196,7 +196,8 @@ def igemm_kernel_label(N, Hi, Wi, Ci, Ho, Wo, CoStore, Co, k, stride, pad, mode,
         nsl = (ipb * (ph + 2) * (pw + 2) * 8 + 255) // 256
         if ipb == 2 and yc <= 8 and xc <= 8 and Hi <= 8 and Wi <= 8 and os.environ.get("FMRI_TC5_DENSE") != "off":
             nsl = 4
-        if (tile == 128 and xc > 8 and yc > 8 and (Ci // 64) % 2 == 0 and os.environ.get("FMRI_TC5W") != "off"):
+        if (tile == 128 and (Ci // 64) % 2 == 0 and os.environ.get("FMRI_TC5W") != "off"
+                and ((xc > 8 and yc > 8) or (xc <= 8 and yc <= 8 and Hi <= 8 and Wi <= 8))):
             return "fmri::igemm_tc5w_kernel"
         if nsl in (4, 6, 7):
             return f"fmri::igemm_tc5_kernel<{tile},{nsl},0>"

@@ -45,3 +45,5 @@ run("dec.deconv0 dgrad", 256, 256, 2, 768, 8, "deconv", "dgrad")
 run("disc.conv1 fwd", 32, 128, 2, 768, 64, "conv", "fwd")
 run("dec.deconv2 dgrad", 128, 32, 2, 768, 32, "deconv", "dgrad")
 run("enc.conv1 fwd", 64, 128, 2, 256, 32, "conv", "fwd")
+run("enc.conv2 dgrad", 128, 256, 2, 256, 16, "conv", "dgrad")
+run("enc.conv1 dgrad", 64, 128, 2, 256, 32, "conv", "dgrad")

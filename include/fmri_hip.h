@@ -104,8 +104,18 @@ typedef struct fmri_epilogue {
      * apply it set FMRI_EP_ACT_APPLIED in *ep_done; if the bit comes back clear `out` holds the plain dy (use
      * fmri_act_bwd). */
     const void* act_y;
+    /* Per-channel affine map (+ ReLU) on the fp32 accumulators in front of the fp16 store: out = relu?(acc * aff_scale[co] +
+     * aff_shift[co]) -- an eval-mode BatchNorm (running statistics, models/vae_gan.py:288-297 under model.eval()) folded
+     * into the convolution that feeds it: no pass over the raw output, one rounding less.  Vectors of CoStore floats.  Only
+     * without statistics, bias and activation.  Kernels that apply it set FMRI_EP_AFFINE_APPLIED in *ep_done; if the bit
+     * comes back clear `out` holds the plain contraction (use fmri_bn_apply). */
+    const float* aff_scale;
+    const float* aff_shift;
+    int32_t aff_relu;
+    int32_t reserved2;
 } fmri_epilogue;
 #define FMRI_EP_ACT_APPLIED 0x40000000
+#define FMRI_EP_AFFINE_APPLIED 0x20000000
 int fmri_igemm_ep(const void* in, const void* w, void* out, const float* bias, const void* zero16, int N, int Hi,
                   int Wi, int Ci, int Ho, int Wo, int CoStore, int Co, int k, int stride, int pad, int mode, int act,
                   int out_f32, int splits, int64_t slab_stride, int bn_tile, int64_t w_elems, const fmri_epilogue* ep,

@@ -741,3 +741,41 @@ def test_full_size_layers_sampled_images_and_adjoint_identities(kind, cin, cout,
     else:
         F.conv_transpose2d(xr, w, None, 2, 2, output_padding=op).backward(ys)
     _close(nhwc_to_images(dx16[pick].contiguous(), cin).cpu(), xr.grad, f"{kind} dgrad, sampled images")
+
+
+AFFINE_CASES = [
+    # kind, cin, cout, H, out_pad, N, expect the epilogue
+    ("conv", 128, 256, 32, 0, 3, True),       # igemm_c5w<16>
+    ("conv", 256, 256, 16, 0, 5, True),       # igemm_c5w<8>, partial last tile
+    ("conv", 32, 128, 20, 0, 2, True),        # one sub-chunk, partial tiles
+    ("deconv", 256, 128, 16, 1, 2, True),     # igemm_tc5w<16>
+    ("deconv", 256, 256, 8, 1, 6, True),      # igemm_tc5w<8>
+    ("deconv", 128, 32, 16, 1, 2, False),     # igemm_tc32: no such epilogue -> plain output, bit clear
+]
+
+
+@pytest.mark.parametrize("kind,cin,cout,H,op,N,expect", AFFINE_CASES)
+def test_conv_epilogue_eval_batchnorm(kind, cin, cout, H, op, N, expect):
+    """fmri_epilogue.aff_*: an eval-mode BatchNorm (+ ReLU) folded into the convolution in front of it equals the
+    convolution followed by BatchNorm.forward_eval (one fp16 rounding less: compared at 2e-3); kernels without the
+    epilogue leave the plain output and say so."""
+    from fmri_hip.ops import ConvLayer, BatchNorm
+    torch.manual_seed(cin + 3 * cout + H + N)
+    shape = (cout, cin, 5, 5) if kind == "conv" else (cin, cout, 5, 5)
+    g = _G({"w": _h(torch.randn(*shape) * 0.05), "bn.weight": torch.rand(cout) + 0.5, "bn.bias": torch.randn(cout) * 0.2})
+    g.bufs = {"bn.running_mean": torch.randn(cout, device=DEV) * 0.3, "bn.running_var": torch.rand(cout, device=DEV) + 0.5,
+              "bn.num_batches_tracked": torch.ones((), dtype=torch.int64, device=DEV)}
+    layer = ConvLayer(g, "w", None, kind, cin, cout, 5, 2, 2, op)
+    bn = BatchNorm(g, "bn.", layer.coutp)
+    x16 = torch.randn(N, H, H, layer.cinp, device=DEV).half()
+    raw = layer.forward(x16)
+    ref = bn.forward_eval(raw, relu=True)
+    fused = layer.forward(x16, affine=bn.eval_affine())
+    assert layer.aff_applied == expect
+    if not expect:
+        assert torch.equal(fused, raw)
+        return
+    err = (fused.float() - ref.float()).abs()
+    lim = 2e-3 * ref.float().abs() + 2e-3 * float(ref.float().pow(2).mean().sqrt())
+    assert (err <= lim).all(), float(err.max())
+    assert (fused >= 0).all()

@@ -171,6 +171,12 @@ int fmri_igemm_ep(const void* in, const void* w, void* out, const float* bias, c
     se.tpg[0] = se.tpg[1] = se.tpg[2] = se.tpg[3] = 0;
     BnBwdEpi bb;
     memset(&bb, 0, sizeof(bb));
+    AffEpi aff;
+    memset(&aff, 0, sizeof(aff));
+    if (ep && ep->aff_scale) {
+        if (!ep->aff_shift || ep->stat_part || bias || act != FMRI_ACT_NONE || out_f32) return FMRI_E_BADARG;
+        aff.scale = ep->aff_scale; aff.shift = ep->aff_shift; aff.relu = ep->aff_relu ? 1 : 0;
+    }
     if (ep && ep->stat_part) {
         if (ep->stat_rows_cap < 1 || ep->stat_group_n < 0 || out_f32 || (ep->stat_group_n > 0 && N % ep->stat_group_n))
             return FMRI_E_BADARG;
@@ -307,6 +313,7 @@ int fmri_igemm_ep(const void* in, const void* w, void* out, const float* bias, c
         }
         q.bb = bb;
         if (!q.st.part) q.bb.x = nullptr;       // no statistics rows: plain output (*ep_done = 0 tells the caller)
+        memset(&q.aff, 0, sizeof(q.aff));
         // wide form (csrc/igemm_c5w.hip): 16 x 16-pixel tiles of one image or 8 x 8-pixel tiles of four, one 8-wave block per
         // CU, loader / compute waves; FMRI_C5W=off disables
         static const char* c5w_env = getenv("FMRI_C5W");
@@ -331,8 +338,10 @@ int fmri_igemm_ep(const void* in, const void* w, void* out, const float* bias, c
                 if (w.st.tpg[0] > se.rows_cap) w.st.part = nullptr;
             }
             if (w.st.part || !se.part) {
+                w.aff = aff;
                 const int r = igemm_c5w_launch(w, copad, S(stream));
                 if (r == OK && ep_done && w.st.part) *ep_done = w.st.tpg[0];
+                if (r == OK && ep_done && w.aff.scale) *ep_done |= FMRI_EP_AFFINE_APPLIED;
                 if (r != E_UNSUPPORTED) return r;
             }
         }
@@ -384,6 +393,7 @@ int fmri_igemm_ep(const void* in, const void* w, void* out, const float* bias, c
         q.fdIW = make_fastdiv((uint32_t)q.IW);
         q.st = se;
         q.bb = bb;
+        memset(&q.aff, 0, sizeof(q.aff));
         // statistics: one row per tile; groups must not share a tile
         const int tpi5 = q.tiles_y * q.tiles_x;
         if (se.part) {
@@ -418,8 +428,10 @@ int fmri_igemm_ep(const void* in, const void* w, void* out, const float* bias, c
                 if (w.st.tpg[0] > se.rows_cap) w.st.part = nullptr;
             }
             if (w.st.part || !se.part) {
+                w.aff = aff;
                 const int r = igemm_tc5w_launch(w, copad, S(stream));
                 if (r == OK && ep_done && w.st.part) *ep_done = w.st.tpg[0];
+                if (r == OK && ep_done && w.aff.scale) *ep_done |= FMRI_EP_AFFINE_APPLIED;
                 if (r != E_UNSUPPORTED) return r;
             }
         }

@@ -79,6 +79,13 @@ struct StatEpi {
 // emits the StatEpi rows with (sum g, sum g*xhat) instead of (sum x, sum x^2).  Statistics group i (image / group_n:
 // cotangent streams or decoder calls stacked along the batch) reads x from image x_img0[i] on and uses the batch
 // statistics mean[i] / rstd[i] of the forward call it belongs to.
+// fmri_epilogue.aff_*: out = relu?(acc * scale[co] + shift[co]) (eval-mode BatchNorm folded into the producer); null scale: off
+struct AffEpi {
+    const float* scale;
+    const float* shift;
+    int32_t relu, pad0;
+};
+
 struct BnBwdEpi {
     const half_t* x;       // null: forward statistics (StatEpi only)
     const float* gamma;
@@ -196,6 +203,7 @@ struct Tc5Args {
     FastDiv fdTPI, fdTX, fdIHW, fdIW;
     StatEpi st;
     BnBwdEpi bb;
+    AffEpi aff;                                  // igemm_tc5w only
     Tc5Class cls[4];
 };
 
@@ -214,6 +222,7 @@ struct C5Args {
     FastDiv fdTPI, fdTX;
     StatEpi st;                                  // one row per BLOCK; tpg[0] = blocks per statistics group
     BnBwdEpi bb;
+    AffEpi aff;                                  // igemm_c5w only
 };
 
 // fused latent-discriminator MLP (mlp.hip): z -> H -> H -> H -> H -> 1, ReLU between the layers

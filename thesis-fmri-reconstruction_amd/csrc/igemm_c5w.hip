@@ -529,9 +529,23 @@ __global__ __launch_bounds__(512, 1) void igemm_c5w_kernel(const C5Args a) {
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
                 const int co = cw + tn * 16;
+                // AffEpi (eval-mode BatchNorm of the consumer folded in): scale / shift of the lane's four channels
+                f4 asc = (f4){1.f, 1.f, 1.f, 1.f}, ash = (f4){0.f, 0.f, 0.f, 0.f};
+                const bool aff = STATS == 0 && a.aff.scale != nullptr;
+                if (aff && co < a.CoStore) {
+                    asc = *(const f4*)(a.aff.scale + co);
+                    ash = *(const f4*)(a.aff.shift + co);
+                }
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm) {
-                    const f4 v = acc[tn][tm];
+                    f4 v = acc[tn][tm];
+                    if (aff) {
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg) {
+                            v[rg] = v[rg] * asc[rg] + ash[rg];
+                            if (a.aff.relu) v[rg] = fmaxf(v[rg], 0.f);
+                        }
+                    }
                     h4 hv;
 #pragma unroll
                     for (int rg = 0; rg < 4; ++rg) hv[rg] = (half_t)((FULL || co + rg < a.Co) ? v[rg] : 0.f);
@@ -636,7 +650,7 @@ static int launch_c5w(const C5Args& a, int copad, hipStream_t st) {
 // k5 s2 p2, Ci % 32 == 0, 128-channel tiles, 16 x 16-pixel tiles of one image, no bias / activation, no BnBwdEpi.
 // C5Args with tiles_y = ceil(Ho / 16), tiles_x = ceil(Wo / 16), ntiles = N * tiles_y * tiles_x.
 int igemm_c5w_launch(const C5Args& a, int copad, hipStream_t st) {
-    if (a.nsub < 1 || (copad & 127) || a.ntiles < 1 || a.tpb < 1 || a.bb.x) return E_UNSUPPORTED;
+    if (a.nsub < 1 || (copad & 127) || a.ntiles < 1 || a.tpb < 1 || a.bb.x || (a.aff.scale && a.st.part)) return E_UNSUPPORTED;
     if ((int64_t)a.N * a.Ho * a.Wo * a.CoStore * 2 >= 0x7fffffffLL) return E_UNSUPPORTED;      // 32-bit store offsets
     if (a.pw16) return a.st.part ? launch_c5w<16, 1>(a, copad, st) : launch_c5w<16, 0>(a, copad, st);
     return a.st.part ? launch_c5w<8, 1>(a, copad, st) : launch_c5w<8, 0>(a, copad, st);

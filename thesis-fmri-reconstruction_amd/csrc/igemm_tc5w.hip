@@ -417,9 +417,23 @@ __global__ __launch_bounds__(512, 1) void igemm_tc5w_kernel(const Tc5Args a) {
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
                 const int co = cw + tn * 16;
+                // AffEpi (eval-mode BatchNorm of the consumer folded in): scale / shift of the lane's four channels
+                f4 asc = (f4){1.f, 1.f, 1.f, 1.f}, ash = (f4){0.f, 0.f, 0.f, 0.f};
+                const bool aff = STATS == 0 && a.aff.scale != nullptr;
+                if (aff && co < a.CoStore) {
+                    asc = *(const f4*)(a.aff.scale + co);
+                    ash = *(const f4*)(a.aff.shift + co);
+                }
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm) {
-                    const f4 v = acc[tn][tm];
+                    f4 v = acc[tn][tm];
+                    if (aff) {
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg) {
+                            v[rg] = v[rg] * asc[rg] + ash[rg];
+                            if (a.aff.relu) v[rg] = fmaxf(v[rg], 0.f);
+                        }
+                    }
                     h4 hv;
 #pragma unroll
                     for (int rg = 0; rg < 4; ++rg) hv[rg] = (half_t)((FULL || co + rg < a.Co) ? v[rg] : 0.f);
@@ -527,7 +541,9 @@ static int launch_tc5w(const Tc5Args& a, int copad, hipStream_t st) {
 // tiles_y * tiles_x) or, for class grids and inputs of at most 8 x 8, one 8 x 8 tile of four images (IPB = 4: ntiles =
 // ceil(N / 4)); nchunks even; no bias / activation, no BnBwdEpi
 int igemm_tc5w_launch(const Tc5Args& a, int copad, hipStream_t st) {
-    if (a.bias != nullptr || a.act != ACT_NONE || a.bb.x || (copad & 127) || a.ntiles < 1 || (a.nchunks & 1)) return E_UNSUPPORTED;
+    if (a.bias != nullptr || a.act != ACT_NONE || a.bb.x || (copad & 127) || a.ntiles < 1 || (a.nchunks & 1) ||
+        (a.aff.scale && a.st.part))
+        return E_UNSUPPORTED;
     if ((int64_t)a.N * a.Ho * a.Wo * a.CoStore * 2 >= 0x7fffffffLL) return E_UNSUPPORTED;      // 32-bit store offsets
     if (a.IPB == 4) {
         if (a.Hi > 8 || a.Wi > 8 || a.tiles_x != 1 || a.tiles_y != 1) return E_BADARG;

@@ -82,10 +82,12 @@ class Epilogue(C.Structure):
     _fields_ = [("stat_part", C.c_void_p), ("stat_rows_cap", C.c_int32), ("stat_group_n", C.c_int32),
                 ("bn_x", C.c_void_p), ("bn_gamma", C.c_void_p), ("bn_beta", C.c_void_p),
                 ("bn_mean", C.c_void_p * 4), ("bn_rstd", C.c_void_p * 4), ("bn_x_img0", C.c_int32 * 4),
-                ("bn_relu", C.c_int32), ("reserved", C.c_int32), ("act_y", C.c_void_p)]
+                ("bn_relu", C.c_int32), ("reserved", C.c_int32), ("act_y", C.c_void_p),
+                ("aff_scale", C.c_void_p), ("aff_shift", C.c_void_p), ("aff_relu", C.c_int32), ("reserved2", C.c_int32)]
 
 
 EP_ACT_APPLIED = 0x40000000
+EP_AFFINE_APPLIED = 0x20000000
 
 
 EXPORTS = sorted(list(_SIGS) + ["fmri_version", "fmri_last_error_string", "fmri_test_fastdiv", "fmri_bn_ws_floats",

@@ -163,7 +163,16 @@ class EncoderNet:
         h = x16
         upd = (1 if train_stats else 0) if updates is None else updates
         for conv, bn in zip(self.convs, self.bns):
-            raw = conv.forward(h, bn_groups=0 if bn.eval_mode else 1)
+            if bn.eval_mode and not bn.perm:
+                # eval: the BatchNorm rides in the convolution's epilogue where its kernel has one (no raw tensor then)
+                out = conv.forward(h, affine=bn.eval_affine())
+                if conv.aff_applied:
+                    raws.append(None); svs.append(None); acts.append(out)
+                    h = out
+                    continue
+                raw = out
+            else:
+                raw = conv.forward(h, bn_groups=0 if bn.eval_mode else 1)
             h, sv = bn.forward(raw, relu=True, updates=upd, stat_acc=conv.take_stats())
             raws.append(raw)
             svs.append(sv)
@@ -280,7 +289,16 @@ class DecoderNet:
         h = act_fc.reshape(GB, f, f, self.size0)
         acts, raws, svs = [h], [], []
         for dc, bn in zip(self.deconvs, self.bns):
-            raw = dc.forward(h, bn_groups=0 if bn.eval_mode else groups)
+            if bn.eval_mode and not bn.perm:
+                # eval: the BatchNorm rides in the transposed convolution's epilogue where its kernel has one
+                out_e = dc.forward(h, affine=bn.eval_affine())
+                if dc.aff_applied:
+                    raws.append(None); svs.append([None] * groups); acts.append(out_e)
+                    h = out_e
+                    continue
+                raw = out_e
+            else:
+                raw = dc.forward(h, bn_groups=0 if bn.eval_mode else groups)
             act = torch.empty_like(raw)
             sl = [None] * groups
             for gi in order:
@@ -433,8 +451,16 @@ class DiscriminatorNet:
         a0 = self.c0.forward(x16, ACT_RELU)
         acts, raws, svs = [a0], [], []
         h = a0
-        for conv, bn in zip(self.convs, self.bns):
-            raw = conv.forward(h, bn_groups=0 if bn.eval_mode else 1)
+        for li, (conv, bn) in enumerate(zip(self.convs, self.bns)):
+            if bn.eval_mode and not bn.perm and li < 2:       # (the third block's RAW output is the 'REC' feature tensor)
+                out_e = conv.forward(h, affine=bn.eval_affine())
+                if conv.aff_applied:
+                    raws.append(None); svs.append(None); acts.append(out_e)
+                    h = out_e
+                    continue
+                raw = out_e
+            else:
+                raw = conv.forward(h, bn_groups=0 if bn.eval_mode else 1)
             h, sv = bn.forward(raw, relu=True, updates=conv_updates if train_stats else 0, stat_acc=conv.take_stats())
             raws.append(raw)
             svs.append(sv)

@@ -224,7 +224,7 @@ def igemm_kernel_label(N, Hi, Wi, Ci, Ho, Wo, CoStore, Co, k, stride, pad, mode,
 
 
 def run_igemm(x, pw: PackedWeight, out, bias, N, Hi, Wi, Ci, Ho, Wo, CoStore, Co, k, stride, pad, mode, act, out_f32,
-              splits, slab_stride, tile, flops=0.0, stats=None, bn_bwd=None, act_y=None) -> int:
+              splits, slab_stride, tile, flops=0.0, stats=None, bn_bwd=None, act_y=None, affine=None) -> int:
     """``stats`` = (partial-row tensor [groups][rows_cap][2][CoStore] fp32, rows_cap, images per group or 0): ask the
     kernel for the BatchNorm statistics of its output (fmri_igemm_ep).  ``bn_bwd`` = dict(x, gamma, beta, relu, groups =
     [(first image of x, BNSaved), ...]): the BatchNorm-BACKWARD form of that epilogue (masked cotangent + sum g,
@@ -238,7 +238,12 @@ def run_igemm(x, pw: PackedWeight, out, bias, N, Hi, Wi, Ci, Ho, Wo, CoStore, Co
                  flops=flops, bytes=2.0 * N * Hi * Wi * Ci + (4.0 if out_f32 else 2.0) * N * Ho * Wo * CoStore * splits
                  + 2.0 * w.numel())
     ep, done = None, ctypes.c_int(0)
-    if stats is None and act_y is not None:
+    if stats is None and affine is not None:
+        # eval-mode BatchNorm of the consumer folded into the epilogue (fmri_epilogue.aff_*); bit EP_AFFINE_APPLIED
+        e = lib.Epilogue()
+        e.aff_scale, e.aff_shift, e.aff_relu = _P(affine[0]), _P(affine[1]), 1 if affine[2] else 0
+        ep = ctypes.byref(e)
+    elif stats is None and act_y is not None:
         # ReLU backward of the layer below in the epilogue (fmri_epilogue.act_y); bit EP_ACT_APPLIED of the result
         e = lib.Epilogue()
         e.act_y = _P(act_y)
@@ -259,6 +264,8 @@ def run_igemm(x, pw: PackedWeight, out, bias, N, Hi, Wi, Ci, Ho, Wo, CoStore, Co
 
 # BatchNorm statistics out of the producing contraction's epilogue (fmri_igemm_ep): on/off
 _EPI_STATS = os.environ.get("FMRI_EPI_STATS") != "off"
+# eval-mode BatchNorm folded into the producing convolution's epilogue (fmri_epilogue.aff_*): on/off
+_EPI_AFFINE = os.environ.get("FMRI_EPI_AFFINE") != "off"
 # ... and the BatchNorm-BACKWARD form (ReLU mask + sum g, sum g*xhat out of the data gradient's epilogue): off by
 # default.  Measured on the B = 256 Stage-I step it removes 0.34 ms of reduction kernels but the epilogues' reads of the
 # saved forward tile (8 bytes per lane, latency exposed once per parity class) cost the data-gradient kernels 0.59 ms.
@@ -437,10 +444,12 @@ class ConvLayer:
         return f(hi), f(wi)
 
     def forward(self, x: torch.Tensor, act: int = ACT_NONE, out: Optional[torch.Tensor] = None,
-                bn_groups: int = 0) -> torch.Tensor:
+                bn_groups: int = 0, affine=None) -> torch.Tensor:
         """``bn_groups`` > 0: the output goes into a train-mode BatchNorm whose batch is each of ``bn_groups`` equal
         image ranges; the kernel's epilogue is asked for the batch statistics (fmri_igemm_ep) and ``take_stats(g)``
-        hands group g's accumulator to ``BatchNorm.forward`` (None if this geometry's kernel has no such epilogue)."""
+        hands group g's accumulator to ``BatchNorm.forward`` (None if this geometry's kernel has no such epilogue).
+        ``affine`` = (scale, shift, relu) of an EVAL-mode BatchNorm behind this layer (``BatchNorm.eval_affine``): asked
+        of the kernel's epilogue; ``self.aff_applied`` tells whether the output already is the BatchNorm's."""
         N, Hi, Wi, C = x.shape
         assert C == self.cinp and x.dtype == torch.float16 and x.is_contiguous()
         Ho, Wo = self.out_hw(Hi, Wi)
@@ -456,9 +465,13 @@ class ConvLayer:
                 part = self._stat_part = torch.empty(bn_groups, cap, 2, self.coutp, dtype=torch.float32,
                                                      device=x.device)
             stats = (part, part.shape[1], N // bn_groups if bn_groups > 1 else 0)
-        self._stat_rows = run_igemm(x, self.pw_f, out, self.b, N, Hi, Wi, self.cinp, Ho, Wo, self.coutp, self.cout,
-                                    self.k, self.stride, self.pad, mode, act, False, 1, 0, self.t_out,
-                                    self._flops(N, Hi, Wi, Ho, Wo), stats=stats)
+        if affine is not None and (stats is not None or self.b is not None or act != ACT_NONE or not _EPI_AFFINE):
+            affine = None
+        r = run_igemm(x, self.pw_f, out, self.b, N, Hi, Wi, self.cinp, Ho, Wo, self.coutp, self.cout,
+                      self.k, self.stride, self.pad, mode, act, False, 1, 0, self.t_out,
+                      self._flops(N, Hi, Wi, Ho, Wo), stats=stats, affine=affine)
+        self._stat_rows = (r & ~(lib.EP_ACT_APPLIED | lib.EP_AFFINE_APPLIED)) if stats is not None else 0
+        self.aff_applied = bool(r & lib.EP_AFFINE_APPLIED)
         return out
 
     def take_stats(self, g: int = 0) -> Optional[torch.Tensor]:
@@ -511,7 +524,7 @@ class ConvLayer:
         else:
             r = run_igemm(dy, self.pw_d, out, None, N, Ho, Wo, self.coutp, hi, wi, self.cinp, self.cin, self.k, 2,
                           self.pad, MODE_CONV, ACT_NONE, False, 1, 0, self.t_in, fl, stats=stats, bn_bwd=bb)
-        self._bwd_rows = (r & ~lib.EP_ACT_APPLIED) if stats is not None else 0
+        self._bwd_rows = (r & ~(lib.EP_ACT_APPLIED | lib.EP_AFFINE_APPLIED)) if stats is not None else 0
         self.act_applied = bool(r & lib.EP_ACT_APPLIED)
         return out
 
@@ -789,6 +802,15 @@ class BatchNorm:
         lib.call("fmri_bn_finalize", _P(sv.sums), C, sv.count, _P(gamma), _P(beta), 1e-5, 0.9, int(updates), _P(rm), _P(rv),
                  _P(junk[0]), _P(junk[1]), _P(junk[2]), _P(junk[3]), _P(self.nbt))
         self._running_out()
+
+    def eval_affine(self, relu: bool = True):
+        """(scale, shift, relu) of the eval-mode map y = relu(scale * x + shift) (running statistics): the ``affine``
+        argument of ``ConvLayer.forward``."""
+        gamma, beta, rm, rv = self._params()
+        self._running_in()
+        scale = (gamma * torch.rsqrt(rv + 1e-5)).contiguous()
+        shift = (beta - rm * scale).contiguous()
+        return scale, shift, relu
 
     def forward_eval(self, raw: torch.Tensor, relu: bool = True, out: Optional[torch.Tensor] = None):
         """Eval-mode BN (running statistics, models/vae_gan.py:288-297 path): y = relu(gamma*(x-rm)/sqrt(rv+eps)+beta)."""

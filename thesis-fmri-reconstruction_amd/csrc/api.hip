@@ -394,6 +394,7 @@ int fmri_igemm_ep(const void* in, const void* w, void* out, const float* bias, c
         q.st = se;
         q.bb = bb;
         memset(&q.aff, 0, sizeof(q.aff));
+        q.solo = 0; q.pad_solo = 0;
         // statistics: one row per tile; groups must not share a tile
         const int tpi5 = q.tiles_y * q.tiles_x;
         if (se.part) {
@@ -423,8 +424,13 @@ int fmri_igemm_ep(const void* in, const void* w, void* out, const float* bias, c
             w.fdTPI = make_fastdiv((uint32_t)(w.tiles_y * w.tiles_x));
             w.fdTX = make_fastdiv((uint32_t)w.tiles_x);
             w.st = se;
+            // few tiles: one parity class per block (FMRI_TC5W_SOLO=<max tiles x column blocks>, default 128)
+            static const char* solo_env = getenv("FMRI_TC5W_SOLO");
+            static const int solo_max = solo_env ? atoi(solo_env) : 128;
+            w.solo = (w.ntiles * (copad / 128) <= solo_max && !se.part) ? 1 : 0;      // (data gradients: no statistics rows)
+            w.pad_solo = 0;
             if (se.part) {
-                w.st.tpg[0] = se.group_n > 0 ? (se.group_n / w.IPB) * w.tiles_y * w.tiles_x : w.ntiles;
+                w.st.tpg[0] = (se.group_n > 0 ? (se.group_n / w.IPB) * w.tiles_y * w.tiles_x : w.ntiles) * (w.solo ? 4 : 1);
                 if (w.st.tpg[0] > se.rows_cap) w.st.part = nullptr;
             }
             if (w.st.part || !se.part) {

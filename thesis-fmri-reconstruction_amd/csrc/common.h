@@ -204,6 +204,7 @@ struct Tc5Args {
     StatEpi st;
     BnBwdEpi bb;
     AffEpi aff;                                  // igemm_tc5w only
+    int32_t solo, pad_solo;                      // igemm_tc5w: one parity class per block (grid.z = 4) for launches of few tiles
     Tc5Class cls[4];
 };
 

@@ -75,7 +75,8 @@ __device__ __forceinline__ void wait_vmt() {
 
 // PW: 16 = tiles of 16 x 16 class-grid positions of one image; 8 = 8 x 8 positions (class grids and inputs of at most 8 x 8)
 // of FOUR images, an MFMA row tile = one tile row of two images.  STATS: 0 none, 1 BatchNorm forward statistics (StatEpi)
-template <int PW, int STATS>
+// SOLO: one parity class per block (grid.z = 4), for launches of few tiles
+template <int PW, int STATS, bool SOLO = false>
 __global__ __launch_bounds__(512, 1) void igemm_tc5w_kernel(const Tc5Args a) {
     constexpr int BN = 128, WN = 2, TM = 8, TN = 4;
     constexpr int PH = PW, IPB = PW == 16 ? 1 : 4;
@@ -100,6 +101,9 @@ __global__ __launch_bounds__(512, 1) void igemm_tc5w_kernel(const Tc5Args a) {
     xcd_tile(bx, by);
     if (bx >= a.ntiles) return;
     const int co0 = by * BN;
+    // launches of few tiles (the encoder's N = 256 layers: 64 tiles for 256 CUs): one parity class per block, grid.z = 4
+    constexpr bool solo = SOLO;
+    const int cls0 = solo ? (int)blockIdx.z : 0;
 
     // ---- tile -> (image, tile row, tile column) of the class grid
     const int tpi = a.tiles_y * a.tiles_x;
@@ -246,7 +250,7 @@ __global__ __launch_bounds__(512, 1) void igemm_tc5w_kernel(const Tc5Args a) {
             constexpr int cls = decltype(CLS_)::value;
             constexpr int TH = (cls >> 1) ? 2 : 3, TW = (cls & 1) ? 2 : 3, T = TH * TW;
             constexpr int SPT = (NSL + T - 1) / T;            // window slices issued per tap
-            constexpr bool LAST = cls == 3;
+            constexpr bool LAST = solo || cls == 3;           // no class follows in this block
             uint32_t vwn = 0, swn = 0, rsn = 0;
             if constexpr (!LAST) class_w(cls + 1, vwn, swn, rsn);
             for (int chunk = 0; chunk < nch; chunk += 2) {
@@ -269,7 +273,7 @@ __global__ __launch_bounds__(512, 1) void igemm_tc5w_kernel(const Tc5Args a) {
                         if constexpr (t == 0) wait_vmt<0>();
                         else {
                             const bool win_prev = !LAST || more_win;
-                            if (chunk == 0) { if (win_prev) wait_vmt<prev_n + ns_prev>(); else wait_vmt<ns_prev>(); }
+                            if (chunk == 0 && !solo) { if (win_prev) wait_vmt<prev_n + ns_prev>(); else wait_vmt<ns_prev>(); }
                             else { if (win_prev) wait_vmt<prev_n>(); else wait_vmt<0>(); }
                         }
                         __builtin_amdgcn_s_barrier();
@@ -287,7 +291,7 @@ __global__ __launch_bounds__(512, 1) void igemm_tc5w_kernel(const Tc5Args a) {
                                         std::integral_constant<int, t * SPT>{}, std::integral_constant<int, t * SPT + SPT>{});
                         // outputs of the previous class
                         if constexpr (cls > 0) {
-                            if (chunk == 0)
+                            if (chunk == 0 && !solo)
                                 static_for_t<t5_st0(j, T), t5_st0(j, T) + t5_nst(j, T)>([&](auto I_) __attribute__((always_inline)) { put(I_); });
                         }
                         __builtin_amdgcn_sched_barrier(0);
@@ -298,12 +302,20 @@ __global__ __launch_bounds__(512, 1) void igemm_tc5w_kernel(const Tc5Args a) {
             take(cls);
         };
         // prologue: window of (class 0, chunk 0) and the first weight tile
+        if constexpr (solo) class_w(cls0, vw, sw, rs);
         load_slices(std::integral_constant<int, 0>{}, 0, std::integral_constant<int, 0>{}, std::integral_constant<int, NSL>{});
         load_w(std::integral_constant<int, 0>{}, vw, sw, rs);
-        feed_class(std::integral_constant<int, 0>{});
-        feed_class(std::integral_constant<int, 1>{});
-        feed_class(std::integral_constant<int, 2>{});
-        feed_class(std::integral_constant<int, 3>{});
+        if constexpr (solo) {
+            if (cls0 == 0) feed_class(std::integral_constant<int, 0>{});
+            else if (cls0 == 1) feed_class(std::integral_constant<int, 1>{});
+            else if (cls0 == 2) feed_class(std::integral_constant<int, 2>{});
+            else feed_class(std::integral_constant<int, 3>{});
+        } else {
+            feed_class(std::integral_constant<int, 0>{});
+            feed_class(std::integral_constant<int, 1>{});
+            feed_class(std::integral_constant<int, 2>{});
+            feed_class(std::integral_constant<int, 3>{});
+        }
         static_for_t<0, 16>([&](auto I_) __attribute__((always_inline)) { put(I_); });
     } else {
         // =====================================================================================================
@@ -484,10 +496,17 @@ __global__ __launch_bounds__(512, 1) void igemm_tc5w_kernel(const Tc5Args a) {
             clear_pending();
             zero_acc();
         };
-        run_class(std::integral_constant<int, 0>{});
-        run_class(std::integral_constant<int, 1>{});
-        run_class(std::integral_constant<int, 2>{});
-        run_class(std::integral_constant<int, 3>{});
+        if constexpr (solo) {
+            if (cls0 == 0) run_class(std::integral_constant<int, 0>{});
+            else if (cls0 == 1) run_class(std::integral_constant<int, 1>{});
+            else if (cls0 == 2) run_class(std::integral_constant<int, 2>{});
+            else run_class(std::integral_constant<int, 3>{});
+        } else {
+            run_class(std::integral_constant<int, 0>{});
+            run_class(std::integral_constant<int, 1>{});
+            run_class(std::integral_constant<int, 2>{});
+            run_class(std::integral_constant<int, 3>{});
+        }
     }
 
 #ifdef FMRI_STAMP
@@ -517,7 +536,9 @@ __global__ __launch_bounds__(512, 1) void igemm_tc5w_kernel(const Tc5Args a) {
                 s0 += src[0];
                 s1 += src[8];
             }
-            float* row = a.st.part + ((size_t)sgrp * a.st.rows_cap + (bx - sgrp * a.st.tpg[0])) * 2 * a.st.C;
+            // (solo: four rows per tile, one per class block; tpg[0] counts rows)
+            const int prow = solo ? (bx * 4 + cls0) - sgrp * a.st.tpg[0] : bx - sgrp * a.st.tpg[0];
+            float* row = a.st.part + ((size_t)sgrp * a.st.rows_cap + prow) * 2 * a.st.C;
             if (co0 + c < a.st.C) {
                 row[co0 + c] = s0;
                 row[a.st.C + co0 + c] = s1;
@@ -526,15 +547,23 @@ __global__ __launch_bounds__(512, 1) void igemm_tc5w_kernel(const Tc5Args a) {
     }
 }
 
-template <int PW, int STATS>
-static int launch_tc5w(const Tc5Args& a, int copad, hipStream_t st) {
-    auto kern = igemm_tc5w_kernel<PW, STATS>;
+template <int PW, int STATS, bool SOLO>
+static int launch_tc5w_(const Tc5Args& a, int copad, hipStream_t st) {
+    auto kern = igemm_tc5w_kernel<PW, STATS, SOLO>;
     constexpr int lds = PW == 16 ? 2 * 11 * 4096 + 2 * 128 * 128 + 32768 : 2 * 13 * 4096 + 2 * 128 * 128;
     // raising the dynamic-LDS limit is idempotent; every call sets it (no library-global state)
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return E_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3(a.ntiles, copad / 128, 1), dim3(512), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(a.ntiles, copad / 128, SOLO ? 4 : 1), dim3(512), lds, st, a);
     return hipGetLastError() == hipSuccess ? OK : E_LAUNCH;
+}
+
+template <int PW, int STATS>
+static int launch_tc5w(const Tc5Args& a, int copad, hipStream_t st) {
+    if constexpr (STATS == 0) {
+        if (a.solo) return launch_tc5w_<PW, 0, true>(a, copad, st);
+    }
+    return launch_tc5w_<PW, STATS, false>(a, copad, st);
 }
 
 // Tc5Args with 16 x 16-position tiles of one image (IPB = 1: tiles_y = ceil(Yc0 / 16), tiles_x = ceil(Xc0 / 16), ntiles = N *

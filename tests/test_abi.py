@@ -75,3 +75,19 @@ def test_argument_validation_without_gpu(lib):
     assert lib.fmri_igemm(z, z, z, None, z, 1, 4, 4, 8, 4, 4, 8, 8, 5, 1, 2, 0, 0, 0, 2, 0, 32, None) == -1
     assert L.load().fmri_bn_stats(None, 4, 8, None, None, 0, None) == -1
     assert L.load().fmri_bn_ws_floats(786432, 128) >= 2 * 128
+
+
+def test_no_store_data_hazard_in_the_code_objects(lib):
+    """gfx950: a VMEM store of more than 64 bits DIRECTLY followed by a multi-register VALU write of its data registers
+    (v_pk_add_f32 …) stores the new second dword (measured).  The compiler leaves no wait state there, so the
+    built code objects are scanned for the pattern."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("scan_store_hazard", os.path.join(ROOT, "tools", "scan_store_hazard.py"))
+    scan = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(scan)
+    if not os.path.exists(scan.OBJDUMP):
+        pytest.skip("llvm-objdump not installed")
+    from fmri_hip import build
+    hits, nstores, nkern, nobj = scan.scan(build.LIB)
+    assert nobj >= 10 and nstores > 500, (nobj, nstores)       # the scan saw the kernels
+    assert not hits, hits

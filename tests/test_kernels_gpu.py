@@ -252,6 +252,9 @@ EPI_STAT_CASES = [
     ("deconv", 256, 256, 2, 8, 1, 6, 2, False),     # a tile would hold images of two batches: no epilogue
     ("deconv", 256, 256, 2, 13, 0, 3, 1, True),     # partial tiles, output_padding = 0
     ("deconv", 128, 64, 2, 25, 1, 2, 2, True),      # 64-channel tile
+    ("deconv", 256, 128, 2, 16, 1, 6, 1, True),     # igemm_tc5w<16>, one class per block (few tiles), statistics
+    ("deconv", 128, 128, 2, 32, 1, 12, 3, True),    # the same with four tiles per image, three BatchNorm batches
+    ("deconv", 256, 128, 2, 16, 1, 160, 1, True),   # igemm_tc5w<16>, four classes per block (many tiles)
 ]
 
 
@@ -272,6 +275,12 @@ def test_conv_epilogue_batchnorm_statistics(kind, cin, cout, stride, H, op, N, g
     y16 = layer.forward(x16, bn_groups=groups)
     B = N // groups
     assert (layer.take_stats(0) is not None) == expect
+    # the stored output itself (the one-class-per-block tc5w instantiation once stored wrong dwords with statistics on:
+    # the gfx950 store-data hazard)
+    xr, wr = x16[..., :cin].float().permute(0, 3, 1, 2), g.views["w"].float()
+    ref = (F.conv2d(xr, wr, None, stride, 2) if kind == "conv" else
+           F.conv_transpose2d(xr, wr, None, 2, 2, output_padding=op)).permute(0, 2, 3, 1)
+    _close(y16[..., :cout], ref, "stored output")
     if not expect:
         return
     bn = BatchNorm(g, "bn.", layer.coutp) if layer.coutp == cout else None

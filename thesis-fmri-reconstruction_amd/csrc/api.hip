@@ -427,7 +427,7 @@ int fmri_igemm_ep(const void* in, const void* w, void* out, const float* bias, c
             // few tiles: one parity class per block (FMRI_TC5W_SOLO=<max tiles x column blocks>, default 128)
             static const char* solo_env = getenv("FMRI_TC5W_SOLO");
             static const int solo_max = solo_env ? atoi(solo_env) : 128;
-            w.solo = (w.ntiles * (copad / 128) <= solo_max && !se.part) ? 1 : 0;      // (data gradients: no statistics rows)
+            w.solo = w.ntiles * (copad / 128) <= solo_max ? 1 : 0;
             w.pad_solo = 0;
             if (se.part) {
                 w.st.tpg[0] = (se.group_n > 0 ? (se.group_n / w.IPB) * w.tiles_y * w.tiles_x : w.ntiles) * (w.solo ? 4 : 1);

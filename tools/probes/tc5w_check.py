@@ -30,3 +30,15 @@ for n in range(N):
                 rows = sorted(set(b.any(dim=2).nonzero()[:, 0].tolist())); cols = sorted(set(b.any(dim=2).nonzero()[:, 1].tolist()))
                 ch = b.any(dim=0).any(dim=0).nonzero().flatten().tolist()
                 print(f"image {n} class ({cy},{cx}): rows {rows} cols {cols[:6]}..{len(cols)} channels {ch[:8]}..{len(ch)}")
+if os.environ.get("DUMP") and bad.any():
+    # raw bits of the first wrong elements beside the expected ones (a register overwritten before the store read it shows up
+    # as the halves of an fp32 number)
+    import struct
+    idx = bad.nonzero()[: int(os.environ["DUMP"])]
+    for n, yy, xx, c in idx.tolist():
+        c0 = c & ~7
+        got = y[n, yy, xx, c0:c0 + 8].view(torch.int16).tolist()
+        exp = ref[n, yy, xx, c0:c0 + 8].half().view(torch.int16).tolist()
+        f = lambda v: " ".join(f"{u & 0xffff:04x}" for u in v)
+        lo = struct.unpack("<I", struct.pack("<f", ref[n, yy, xx, c0 + 2].half().float().item()))[0]
+        print(f"n{n} y{yy} x{xx} c{c0}: got {f(got)} | exp {f(exp)} | f32(ch2) {lo:08x}")

@@ -431,6 +431,7 @@ __global__ __launch_bounds__(512, 1) void igemm_tc5w_kernel(const Tc5Args a) {
         // of a write over the banks).  Channels >= Co are written as zeros.
         const bool full_co = ((a.Co | a.CoStore) & 127) == 0;
         const uint32_t sbase = (uint32_t)(STG0 + frow * 256 + (((wn * 8 + (fq >> 1)) ^ frow) << 4) + (fq & 1) * 8);
+        const bool aff_on = STATS == 0 && a.aff.scale != nullptr, aff_relu = a.aff.relu != 0;
         auto hand_body = [&](int cls, auto FULL_) __attribute__((always_inline)) {
             constexpr bool FULL = decltype(FULL_)::value;
             (void)cls;                                       // positions outside the class grid are handed over too (the loader waves drop them)
@@ -440,7 +441,7 @@ __global__ __launch_bounds__(512, 1) void igemm_tc5w_kernel(const Tc5Args a) {
                 const int co = cw + tn * 16;
                 // AffEpi (eval-mode BatchNorm of the consumer folded in): scale / shift of the lane's four channels
                 f4 asc = (f4){1.f, 1.f, 1.f, 1.f}, ash = (f4){0.f, 0.f, 0.f, 0.f};
-                const bool aff = STATS == 0 && a.aff.scale != nullptr;
+                const bool aff = aff_on;
                 if (aff && co < a.CoStore) {
                     asc = *(const f4*)(a.aff.scale + co);
                     ash = *(const f4*)(a.aff.shift + co);
@@ -452,7 +453,7 @@ __global__ __launch_bounds__(512, 1) void igemm_tc5w_kernel(const Tc5Args a) {
 #pragma unroll
                         for (int rg = 0; rg < 4; ++rg) {
                             v[rg] = v[rg] * asc[rg] + ash[rg];
-                            if (a.aff.relu) v[rg] = fmaxf(v[rg], 0.f);
+                            if (aff_relu) v[rg] = fmaxf(v[rg], 0.f);
                         }
                     }
                     h4 hv;

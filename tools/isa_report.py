@@ -21,6 +21,10 @@ COUNT = [("mfma", r"v_mfma_"), ("readlane", r"v_readlane_b32"), ("writelane", r"
 
 
 def short(name):
+    m = re.match(r"_ZN4fmri(\d+)", name)          # (c++filt does not know the _Float16 mangling: keep the bare name)
+    if m:
+        n0 = m.end()
+        name = name[n0:n0 + int(m.group(1))] + ("<" + ",".join(re.findall(r"Li(\d+)E", name)) + ">" if "ILi" in name else "")
     name = re.sub(r"\(.*$", "", name)
     return name.replace("void ", "").replace("fmri::", "")
 

@@ -336,6 +336,9 @@ def main():
     force_dist = os.environ.get("FMRI_FORCE_DIST") == "1"      # 1-rank rehearsal of the RCCL path
     if world > 1 or force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:                 # plain `FMRI_FORCE_DIST=1 python bench.py`: a one-rank env:// rendezvous
+            for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29577")):
+                os.environ.setdefault(k, v)
         backend = os.environ.get("FMRI_DIST_BACKEND", "nccl")          # "nccl" is RCCL on ROCm
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)

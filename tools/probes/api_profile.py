@@ -24,6 +24,7 @@ def step():
     model.zero_grad(); lg.backward(retain_graph=True); od.step()
     model.discriminator.zero_grad(); ld.backward(); os_.step()
     return le
+torch.autograd.set_multithreading_enabled(False)      # backward on this thread: cProfile sees the bridge's Python
 for _ in range(15): step()
 torch.cuda.synchronize()
 pr = cProfile.Profile(); pr.enable()

@@ -450,9 +450,11 @@ __global__ __launch_bounds__(512, 1) void igemm_c5w_kernel(const C5Args a) {
             unsigned long long tb, tc, td;
             FMRI_STAMP_AT(tb);
 #endif
-            pending_mfmas();
+            // (t0 == 0: the previous step was the lone 25th tap or the start of the kernel -- nothing is pending, and 32 MFMAs
+            // on zeros would only cover the first slot's read latency at twice its price)
+            if constexpr (t0 != 0) pending_mfmas();
 #if C5W_HALFA
-            if constexpr (C5W_ABL != 2) {
+            if constexpr (C5W_ABL != 2 && t0 != 0) {
                 // the reads one by one between the first MFMAs, not as a burst in front of them
 #pragma unroll
                 for (int i = 0; i < TM + TN; ++i) {
@@ -576,7 +578,6 @@ __global__ __launch_bounds__(512, 1) void igemm_c5w_kernel(const C5Args a) {
             run_sub();
             ++sub;
             if (last_sub) {
-                pending_mfmas();                                     // the last step's second tap slot
 #if defined(FMRI_STAMP) && FMRI_STAMP >= 2
                 unsigned long long te0, te1;
                 FMRI_STAMP_AT(te0);

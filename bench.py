@@ -385,14 +385,18 @@ def main():
                         buf.copy_(r[j])
                 return replay()
             return run
-        try:
-            g = st.capture(*sbuf)
-            modes["graph"] = staged(g)
-            modes["graph"](0)
-            log("step captured into HIP graph(s)")
-        except Exception as e:               # capture is an optimisation: fall back to eager launches
-            log(f"graph capture failed ({type(e).__name__}: {e}); continuing with eager launches")
-            modes.pop("graph", None)
+        # multi-process runs: the full step as graph segments between eager collectives is recorded only on request
+        # (--graph).  It has never measured faster than the eager / hybrid step there, and a failed stream capture next to
+        # the collective backend's watchdog thread ends the process rather than raising (steps._SegmentRecorder).
+        if single or a.graph:
+            try:
+                g = st.capture(*sbuf)
+                modes["graph"] = staged(g)
+                modes["graph"](0)
+                log("step captured into HIP graph(s)")
+            except Exception as e:               # capture is an optimisation: fall back to eager launches
+                log(f"graph capture failed ({type(e).__name__}: {e}); continuing with eager launches")
+                modes.pop("graph", None)
         if (a.workload == "stage1" and (single or not a.sync_bn) and ops._SIDE["on"] and not a.graph):
             # hybrid: recorded forward + eagerly issued two-stream backward (half the Python work of a step)
             try:

@@ -114,6 +114,19 @@ class _SegmentRecorder:
         self.pool = torch.cuda.graph_pool_handle()
         self.items = []          # torch.cuda.CUDAGraph or a zero-argument callable
         self.cur = None
+        # The collectives run on a stream of their own, never on the one being recorded: the backend records its work
+        # events on the stream a blocking collective is issued from, its watchdog THREAD polls them, and HIP refuses to
+        # query an event whose stream has meanwhile entered capture (hipErrorCapturedEvent) -- the watchdog then
+        # takes the process down (seen once in ~6 runs of the one-rank RCCL test, at the capture that follows a
+        # SyncBN exchange).
+        self.comm = torch.cuda.Stream()
+
+    def _on_comm(self, fn):
+        cur = torch.cuda.current_stream()
+        self.comm.wait_stream(cur)
+        with torch.cuda.stream(self.comm):
+            fn()
+        cur.wait_stream(self.comm)
 
     def begin(self):
         self.cur = torch.cuda.CUDAGraph()
@@ -127,8 +140,9 @@ class _SegmentRecorder:
 
     def collective(self, fn):
         self.end()
-        fn()                     # communicator warm, same call order as at replay; operates on not-yet-computed data
-        self.items.append(fn)
+        run = lambda: self._on_comm(fn)
+        run()                    # communicator warm, same call order as at replay; operates on not-yet-computed data
+        self.items.append(run)
         self.begin()
 
     def replay(self):

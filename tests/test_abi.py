@@ -91,3 +91,38 @@ def test_no_store_data_hazard_in_the_code_objects(lib):
     hits, nstores, nkern, nobj = scan.scan(build.LIB)
     assert nobj >= 10 and nstores > 500, (nobj, nstores)       # the scan saw the kernels
     assert not hits, hits
+
+
+def test_store_hazard_scanner_recognises_the_measured_pattern():
+    """The two instruction pairs of the broken build (profiles/r03_store_hazard.txt) are hits; the harmless neighbours
+    (a single-register writer, a packed writer of OTHER registers, one instruction in between) are not."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("scan_store_hazard", os.path.join(ROOT, "tools", "scan_store_hazard.py"))
+    scan = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(scan)
+    dis = """
+0000000000001000 <_ZN4fmri6brokenEv>:
+\tbuffer_store_dwordx4 v[14:17], v95, s[24:27], s20 offen  // 000000001000: E07C1000 14065F0E
+\tv_pk_add_f32 v[14:15], v[56:57], v[52:53]                // 000000001008: D3B2400E 1802693
+\tbuffer_store_dwordx4 v[6:9], v97, s[24:27], s22 offen
+\tv_pk_mul_f32 v[6:7], v[70:71], v[70:71]
+\tglobal_store_dwordx4 v[92:93], v[34:37], off
+\tv_lshl_add_u64 v[36:37], s[28:29], 0, v[82:83]
+0000000000002000 <_ZN4fmri4fineEv>:
+\tbuffer_store_dwordx4 v[34:37], v44, s[52:55], s96 offen
+\tv_cndmask_b32_e64 v34, v93, v94, s[18:19]
+\tbuffer_store_dwordx4 v[26:29], v90, s[24:27], s28 offen
+\tv_pk_add_f32 v[32:33], v[40:41], v[32:33]
+\tbuffer_store_dwordx4 v[10:13], v96, s[24:27], s21 offen
+\ts_nop 1
+\tv_pk_add_f32 v[10:11], v[64:65], v[52:53]
+\tbuffer_store_dwordx2 v[2:3], v96, s[24:27], s21 offen
+\tv_pk_add_f32 v[2:3], v[64:65], v[52:53]
+"""
+    hits, nstores, nkern = scan.scan_text(dis)
+    assert nstores == 6 and nkern == 2
+    assert [h[0] for h in hits] == ["_ZN4fmri6brokenEv"] * 3, hits
+    assert "v[14:15]" in hits[0][2] and "v[6:7]" in hits[1][2] and "v_lshl_add_u64" in hits[2][2]
+    # a window of two instructions also reports the pair with the s_nop between; every VALU writer: the v_cndmask
+    assert len(scan.scan_text(dis, window=2)[0]) == 4
+    assert len(scan.scan_text(dis, packed_only=False)[0]) == 4

@@ -9,7 +9,7 @@ the second dword of the 16 bytes is the VALU result, not the register's content 
 
 This script disassembles every gfx950 code object of libfmri_hip.so and reports each VMEM store of more than 64 bits that
 is followed, within WINDOW instructions (default 1: the observed case), by a VALU instruction writing any of its data
-registers.  Exit status 1 if any is found.  tests/test_build.py runs it so that a scheduling change cannot ship the pattern.
+registers.  Exit status 1 if any is found.  tests/test_abi.py runs it so that a scheduling change cannot ship the pattern.
 
 usage: tools/scan_store_hazard.py [path/to/libfmri_hip.so] [--window N] [--all-valu]
 """
@@ -57,32 +57,42 @@ def code_objects(lib):
     return tmp, sorted(os.path.join(tmp, f) for f in os.listdir(tmp) if "gfx950" in f)
 
 
+def scan_text(dis, window=1, packed_only=True):
+    """Hits in one llvm-objdump -d listing: ([(kernel, store, valu)], wide stores seen, symbols seen)."""
+    hits, nstores, nkern = [], 0, 0
+    kern, pend = "?", []          # pend: [(store text, data regs, instructions left)]
+    for line in dis.splitlines():
+        lm = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+        if lm:
+            kern, pend = lm.group(1), []
+            nkern += not kern.startswith(("L", "."))
+            continue
+        body = line.split("//")[0]
+        if not body.strip() or body.strip().startswith((";", ".")):
+            continue
+        op, dst = valu_dst(body)
+        if op and dst and (not packed_only or op.startswith("v_pk_") or len(dst) > 1):
+            for st, regs, _ in pend:
+                if regs & dst:
+                    hits.append((kern, st.strip(), body.strip()))
+        pend = [(s, r, n - 1) for s, r, n in pend if n > 1]
+        sm = STORE.match(body)
+        if sm:
+            nstores += 1
+            pend.append((body, store_data(sm.group(1), sm.group(2)), window))
+    return hits, nstores, nkern
+
+
 def scan(lib, window=1, packed_only=True):
     tmp, objs = code_objects(lib)
     hits, nstores, nkern = [], 0, 0
     try:
         for o in objs:
             dis = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", o], check=True, capture_output=True, text=True).stdout
-            kern, pend = "?", []          # pend: [(store text, data regs, instructions left)]
-            for line in dis.splitlines():
-                lm = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
-                if lm:
-                    kern, pend = lm.group(1), []
-                    nkern += not kern.startswith(("L", "."))
-                    continue
-                body = line.split("//")[0]
-                if not body.strip() or body.strip().startswith((";", ".")):
-                    continue
-                op, dst = valu_dst(body)
-                if op and dst and (not packed_only or op.startswith("v_pk_") or len(dst) > 1):
-                    for st, regs, _ in pend:
-                        if regs & dst:
-                            hits.append((kern, st.strip(), body.strip()))
-                pend = [(s, r, n - 1) for s, r, n in pend if n > 1]
-                sm = STORE.match(body)
-                if sm:
-                    nstores += 1
-                    pend.append((body, store_data(sm.group(1), sm.group(2)), window))
+            h, ns, nk = scan_text(dis, window, packed_only)
+            hits += h
+            nstores += ns
+            nkern += nk
     finally:
         for f in os.listdir(tmp):
             os.unlink(os.path.join(tmp, f))

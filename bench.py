@@ -53,31 +53,43 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(batch: int, steps: int):
-    """Oracle (CPU restatement pinned to the reference) timed on this host's cores: the 'literal' variant
-    (three full backward traversals, what train_vgan_stage1.py:410-432 does)."""
-    from oracle import vaegan_oracle as O
-    cores = host_cores()
-    torch.set_num_threads(cores)
-    cfg = O.ArchCfg.px64()
+def _time_oracle(O, cfg, batch, literal, budget_s, max_steps):
+    """images/sec of the CPU oracle's Stage-I step at ``batch`` (one untimed warm-up step, then as many timed steps as fit
+    ``budget_s`` seconds, at least one)."""
     P = O.fill_state(O.vaegan_spec(cfg), 0, False)
     data = O.synth_batch(batch, cfg, seed=1234, steps=1)
     opts = {n: O.OptState(kind="rmsprop", lr=1e-4) for n in ("encoder", "decoder", "discriminator")}
     args = (data["x"], data["noise"][0, 0], data["noise"][0, 1], cfg)
-    log(f"cpu baseline: {cores} threads, batch {batch}")
     t0 = time.perf_counter()
-    O.stage1_step(P, opts, *args, literal=True)            # warm-up
+    O.stage1_step(P, opts, *args, literal=literal)           # warm-up
     warm = time.perf_counter() - t0
-    log(f"cpu baseline warm-up step {warm:.1f}s")
-    steps = max(1, min(steps, int(25.0 / max(warm, 1e-3))))   # bound the sample to ~25 s of CPU work
+    steps = max(1, min(max_steps, int(budget_s / max(warm, 1e-3))))
     t0 = time.perf_counter()
     for i in range(steps):
-        O.stage1_step(P, opts, *args, literal=True)
-        log(f"cpu baseline step {i + 1}/{steps}")
+        O.stage1_step(P, opts, *args, literal=literal)
     dt = time.perf_counter() - t0
-    return dict(value=round(batch * steps / dt, 3), unit="images/sec", cores=cores, kind="port",
-                sample=f"{steps} literal Stage-I steps (3 full backward traversals) of the CPU oracle at batch {batch} "
-                       f"(BASELINE configs[0]) after 1 warm-up, torch {torch.__version__} fp32, {cores} threads")
+    log(f"cpu baseline: batch {batch} {'literal' if literal else 'pruned'}: warm-up {warm:.1f}s, {steps} steps in {dt:.1f}s")
+    return batch * steps / dt, steps
+
+
+def cpu_baseline(batch: int, steps: int):
+    """Oracle (CPU restatement pinned to the reference) timed on this host's cores.  ``value`` = the 'literal' variant
+    (three full backward traversals, what train_vgan_stage1.py:410-432 does) at BASELINE configs[0]'s batch 32; the other
+    rows SURVEY 8(d) asks for ride along in ``variants``: the 'pruned' restatement (one traversal per gradient set, each
+    through its own sub-network only) at batch 32 and the literal step at the headline batch 256."""
+    from oracle import vaegan_oracle as O
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    cfg = O.ArchCfg.px64()
+    log(f"cpu baseline: {cores} threads")
+    v_lit, n_lit = _time_oracle(O, cfg, batch, True, 14.0, steps)
+    v_pru, n_pru = _time_oracle(O, cfg, batch, False, 7.0, steps)
+    v_big, n_big = _time_oracle(O, cfg, 256, True, 5.0, 1)
+    return dict(value=round(v_lit, 3), unit="images/sec", cores=cores, kind="port",
+                sample=f"{n_lit} literal Stage-I steps (3 full backward traversals) of the CPU oracle at batch {batch} "
+                       f"(BASELINE configs[0]) after 1 warm-up, torch {torch.__version__} fp32, {cores} threads",
+                variants=[dict(variant="pruned", batch=batch, steps=n_pru, value=round(v_pru, 3)),
+                          dict(variant="literal", batch=256, steps=n_big, value=round(v_big, 3))])
 
 
 def pmc_traffic(family):
@@ -85,7 +97,7 @@ def pmc_traffic(family):
     arguments), launch-weighted over its instantiations, from the committed rocprofv3 PMC passes of this same command
     (tools/pmc_traffic.py); None when no committed pass holds the family."""
     want = family.replace(" ", "")
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
         try:
             with open(path) as f:
@@ -296,6 +308,26 @@ def hbm_rows(dev, B):
     return out
 
 
+def _launch_ranks(n: int, json_fd: int) -> int:
+    """Run this script under ``python -m torch.distributed.run`` with ``n`` ranks on 127.0.0.1 as a child process (never
+    an exec: the launcher must stay a child of a process that owns no GPU state), pass the child's stdout -- rank 0's one
+    JSON line -- through, return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("launching: " + " ".join(cmd))
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    if r.stdout:
+        os.write(json_fd, r.stdout)
+    return r.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -327,7 +359,11 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.gpus > 1 and world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})")
+        if "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+            raise SystemExit(f"--gpus {a.gpus} under a launcher with WORLD_SIZE={world}: the rank count must match")
+        # plain `python bench.py --gpus N`: this process has not touched the GPU; it starts the N ranks as a CHILD
+        # (torch.distributed.run, one process per GPU), relays the ranks' single JSON line and exits with the child's code
+        sys.exit(_launch_ranks(a.gpus, json_fd))
     if os.environ.get("FMRI_REHEARSE_ON_ONE_GPU") == "1":
         local = 0                      # all ranks share device 0 (with FMRI_DIST_BACKEND=gloo): control-flow rehearsal
     torch.cuda.set_device(local)

@@ -131,10 +131,26 @@ int fmri_wgrad(const void* P, const void* Q, float* out, const void* zero16, int
  * parity planes; the number of slabs it writes is fmri_wgrad_slabs().
  * atomic = 3: 5x5 stride-1 layers with A = 32, Bc = 8 only (csrc/wgrad_narrow.hip, else FMRI_E_UNSUPPORTED): out
  * holds `splits` pre-zeroed slabs of apad*ldo floats that the blocks add into round-robin; fmri_unpack_grad sums
- * them.
+ * them (`splits` = the number of blocks the kernel is launched with, fmri_wgrad_narrow_blocks(): one slab per block,
+ * every element added exactly once onto zero -- bit-reproducible).
+ * atomic = 4: per-split slabs of the generic kernel (csrc/wgrad.hip): out holds `splits` ZERO-FILLED slabs of apad*ldo
+ * floats, split z stores its partial result to slab z with plain stores (the kernel may use fewer splits than asked
+ * for; the remaining slabs stay zero); fmri_unpack_grad sums them in slab order -- bit-reproducible.
  * flip = 0: Q pixel = m*stride + tap - pad.  flip = 1 (stride 1 only): Q pixel = m + pad - tap, i.e. the roles of
  * the two activations are exchanged so that the GATHERED operand is the one with fewer channels. */
 int fmri_wgrad_slabs(int N, int Yc, int Xc, int k, int pad, int splits);
+/* number of blocks fmri_wgrad(..., atomic = 3) launches for this geometry */
+int fmri_wgrad_narrow_blocks(int N, int Yc, int Xc);
+
+/* ---- deterministic-reduction mode (process-wide; initial value: environment FMRI_DETERMINISTIC=1).  When on, the
+ * loss / norm kernels that end in an atomic add onto a device scalar (fmri_latent_fwd, fmri_feat_mse, fmri_pixel_sq,
+ * fmri_gan_head*, fmri_wae_logloss, fmri_sumsq, fmri_pcc) are launched as ONE block each, i.e. every total is a
+ * fixed-order sum.  Together with the slab forms of fmri_wgrad (atomic = 2, 3 with one slab per block, 4) and
+ * dbias5 = NULL in fmri_mlp_bwd -- which the caller selects -- two runs of the same training step on the same inputs
+ * then produce bit-identical parameters.  A verification mode (the one-block sums cost a few hundred microseconds at
+ * batch 256); the default trades the fixed order for atomics.  Returns the previous value. */
+int fmri_set_deterministic(int on);
+int fmri_get_deterministic(void);
 
 /* ---- batch ingest: uint8 [N][H][W][C = 1|3] (already cropped / resized) -> normalised fp16 NHWC8 (engine input)
  * and / or fp32 NCHW (module API input).  Per image: optional horizontal flip (flip_dev[n] != 0, may be NULL), then an

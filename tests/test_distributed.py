@@ -185,6 +185,7 @@ def _worker_gpu(rank, world, port, q):
 
 
 @pytest.mark.gpu
+@pytest.mark.selfcheck
 def test_two_rank_stage1_step_equals_single_process_global_batch():
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
@@ -274,6 +275,7 @@ def _worker_hybrid(rank, world, port, q):
 
 
 @pytest.mark.gpu
+@pytest.mark.selfcheck
 def test_two_rank_hybrid_step_equals_eager_step_local_bn():
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
@@ -342,6 +344,7 @@ def _worker_segments(port, q):
 
 
 @pytest.mark.gpu
+@pytest.mark.selfcheck
 def test_graph_segments_with_eager_collectives_equal_eager_steps():
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
@@ -400,6 +403,7 @@ def _worker_other(rank, world, port, kind, q):
 
 
 @pytest.mark.gpu
+@pytest.mark.selfcheck
 @pytest.mark.parametrize("kind", ["stage2", "stage3", "wae1", "wae2", "wae3", "dual1"])
 def test_two_rank_other_steps_equal_single_process_global_batch(kind):
     """CognitiveStep (Stage II / III), WaeStep and DualStage1Step with distributed=True on two half batches (asynchronous

@@ -370,6 +370,48 @@ def test_dgrad_epilogue_batchnorm_backward(kind, cin, cout, H, op, N, groups):
         assert torch.equal(rows(d_mask, e), torch.where(on, rows(d_plain, e), torch.zeros_like(rows(d_plain, e))))
 
 
+def test_bn_backward_epilogue_request_is_never_answered_with_forward_statistics():
+    """fmri_igemm_ep with ``bn_x`` set (BatchNorm-BACKWARD epilogue) and a row capacity the kernel that has this epilogue
+    cannot meet (igemm_c5<16>: 4 rows) but the wide kernel's FORWARD-statistics rows would (igemm_c5w<16>: 2 rows): the
+    call must come back with *ep_done = 0, no row written and the plain data gradient in ``out`` -- never with
+    sum x / sum x^2 rows that the caller would fold as (sum g, sum g*xhat).  (Round-3 advisor finding: the wide kernels
+    were gated on the already-cleared copy of the request.)"""
+    from fmri_hip import ops
+    from fmri_hip.ops import ConvLayer, BatchNorm
+    torch.manual_seed(5)
+    cin, cout, H, N, G = 256, 128, 16, 4, 2
+    g = _G({"w": _h(torch.randn(cin, cout, 5, 5) * 0.05), "bn.weight": torch.rand(cin) + 0.5, "bn.bias": torch.randn(cin) * 0.3})
+    g.bufs = {"bn.running_mean": torch.zeros(cin, device=DEV), "bn.running_var": torch.ones(cin, device=DEV),
+              "bn.num_batches_tracked": torch.zeros((), dtype=torch.int64, device=DEV)}
+    layer = ConvLayer(g, "w", None, "deconv", cin, cout, 5, 2, 2, 1)
+    bn = BatchNorm(g, "bn.", cin)
+    B = N // G
+    raw = torch.randn(B, H, H, cin, device=DEV).half()
+    sv = bn.forward(raw, True, 0)[1]
+    Ho, Wo = layer.out_hw(H, H)
+    dy = (torch.randn(N, Ho, Wo, layer.coutp, device=DEV) * 0.5).half()
+    plain = layer.dgrad(dy, H, H)
+    cap = 3
+    part = torch.full((G, cap, 2, cin), float("nan"), dtype=torch.float32, device=DEV)
+    out = torch.empty_like(plain)
+    gamma, beta, _, _ = bn._params()
+    r = ops.run_igemm(dy, layer.pw_d, out, None, N, Ho, Wo, layer.coutp, H, H, layer.cinp, layer.cin, 5, 2, 2,
+                      ops.MODE_CONV, ops.ACT_NONE, False, 1, 0, layer.t_in, stats=(part, cap, B),
+                      bn_bwd=dict(x=raw, gamma=gamma, beta=beta, relu=True, groups=[(0, sv)] * G))
+    torch.cuda.synchronize()
+    assert r == 0, r
+    assert bool(torch.isnan(part).all()), "statistics rows were written although the request was declined"
+    assert torch.equal(out, plain)
+    # with room for its rows the epilogue is honoured
+    part = torch.full((G, 8, 2, cin), float("nan"), dtype=torch.float32, device=DEV)
+    r = ops.run_igemm(dy, layer.pw_d, out, None, N, Ho, Wo, layer.coutp, H, H, layer.cinp, layer.cin, 5, 2, 2,
+                      ops.MODE_CONV, ops.ACT_NONE, False, 1, 0, layer.t_in, stats=(part, 8, B),
+                      bn_bwd=dict(x=raw, gamma=gamma, beta=beta, relu=True, groups=[(0, sv)] * G))
+    torch.cuda.synchronize()
+    assert r == 4, r
+    assert not bool(torch.isnan(part[:, :4]).any())
+
+
 def test_conv_bias_relu_tanh_epilogues():
     from fmri_hip.ops import ConvLayer, ACT_RELU, ACT_TANH
     torch.manual_seed(5)

@@ -306,49 +306,3 @@ def test_latent_discriminator_fused_kernels(M, train, need_dz):
             assert _terr(gf[k], gu[k]) < 4e-3, k
     else:
         assert all(float(v.abs().max()) == 0.0 for v in gf.values())
-
-
-@pytest.mark.parametrize("stage", [1, 3])
-def test_wae_step_recorded_into_a_hip_graph_equals_eager_steps(stage):
-    """WaeStep.capture: the whole step (Adam with its step count on the device) replayed from a HIP graph follows the
-    eagerly issued steps -- same losses and parameters after 2 warm-up + 3 replayed steps."""
-    from fmri_hip.params import ArchConfig
-    from fmri_hip.wae_steps import WaeStep
-    cfg, V, B = ArchConfig.px64(), 512, 8
-    rs = np.random.RandomState(11)
-    x = torch.tanh(torch.from_numpy(rs.standard_normal((B, 3, 64, 64)).astype(np.float32))).to(DEV)
-    zf = torch.from_numpy(rs.standard_normal((B, cfg.latent_dim)).astype(np.float32)).to(DEV)
-    fm = torch.from_numpy(rs.standard_normal((B, V)).astype(np.float32)).to(DEV)
-    args = (x, zf) if stage == 1 else (x, None, fm)
-
-    def make():
-        st = WaeStep(cfg, DEV, stage, V if stage > 1 else 0)
-        st.load_recipe(5, False if stage == 1 else None)
-        return st
-    a, b = make(), make()
-    s0 = {k: v.clone() for k, v in a.state_dict().items()}
-    for _ in range(5):
-        a.step(*args)
-    run = b.capture(*args)            # two eager warm-up steps inside
-    for _ in range(3):
-        run()
-    torch.cuda.synchronize()
-    la, lb = a.logs(), b.logs()
-    for k in WAE_KEYS:
-        assert _rel(lb[k], la[k]) < 2e-3, (k, lb[k], la[k])
-    sa, sb = a.state_dict(), b.state_dict()
-    # Adam's first steps are sign-like (+-lr per element) and elements with near-zero gradients flip with the run-to-run
-    # spread of the fp32 atomics: the five-step UPDATES of every large tensor must point the same way
-    for k in sa:
-        if not sa[k].dtype.is_floating_point or sa[k].numel() < 1024 or "running" in k:
-            continue
-        ua, ub = (sa[k] - s0[k]).double().reshape(-1), (sb[k] - s0[k]).double().reshape(-1)
-        if float(ua.norm()) == 0.0:
-            assert float(ub.norm()) == 0.0, k
-            continue
-        cos = float((ua @ ub) / (ua.norm() * ub.norm() + 1e-30))
-        assert cos > 0.9, (k, cos)
-    for k in sa:
-        if "running" in k:
-            assert _terr(sb[k], sa[k]) < 6e-2, k       # batch statistics of 8 samples after diverging sign-like steps
-    assert all(int(sa[k]) == int(sb[k]) for k in sa if "num_batches" in k)

@@ -1,0 +1,289 @@
+"""Engine-vs-engine comparisons (HIP engine against itself in another launch mode), collected AFTER every
+HIP-vs-oracle / HIP-vs-golden test (marker ``selfcheck``, tests/conftest.py).
+
+They run in the engine's deterministic-reduction mode (``fmri_hip.ops.set_deterministic``: per-split slabs summed in
+slab order for every weight gradient, one-block launches of the scalar loss sums, no fp32 atomics anywhere on the
+step), where two executions of the same step are bit-identical -- so every comparison below is EXACT: a launch mode that
+back-propagates the wrong batch, skips an update, reads stale fp16 weights or races with the side stream cannot hide
+inside a tolerance.  One test keeps the default (atomic) reductions and the element-count criterion of round 3.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = [pytest.mark.gpu, pytest.mark.selfcheck]
+DEV = "cuda:0"
+LOSS_KEYS = ("loss_encoder", "loss_decoder", "loss_discriminator", "nle", "kl", "mse", "bce_orig", "bce_pred", "bce_samp")
+
+
+def _assert_same_bits(sa, sb, what=""):
+    """Every tensor of two state dicts (or dicts of tensors) equal bit for bit."""
+    assert sa.keys() == sb.keys()
+    for k in sa:
+        a, b = sa[k], sb[k]
+        if not torch.equal(a, b):
+            d = (a.double() - b.double()).abs()
+            raise AssertionError(f"{what}: {k} differs in {int((d > 0).sum())} of {a.numel()} elements, "
+                                 f"max |diff| {float(d.max()):.3e}")
+
+
+def _assert_same_logs(la, lb, what=""):
+    for k in la:
+        assert la[k] == lb[k], (what, k, la[k], lb[k])
+
+
+def _same_update(sa, sb, what=""):
+    """DEFAULT (atomic) reductions: two runs of the same step leave the same parameters up to the run-to-run spread of
+    the fp32 atomics in the weight-gradient sums.  RMSprop's first update is lr*g/(sqrt(0.1 g^2)+1e-8): +-3.16e-4 for
+    every element whose gradient is well above 1e-8, proportional to g below that -- so the spread shows as up to ~1e-1
+    of a step on elements with near-zero gradients and as single elements whose gradient changes sign (a full 6.3e-4).
+    A wrong or missing update moves (nearly) EVERY element of a tensor by a step.  Hence: elements may differ by a
+    quarter step (8e-5; or 2e-5 of the tensor's largest entry, for the running statistics), and at most max(4, 1 %)
+    of a tensor's elements by more."""
+    for k in sa:
+        a, b = sa[k].float().cpu().reshape(-1), sb[k].float().cpu().reshape(-1)
+        lim = max(2e-5 * float(b.abs().max()), 8e-5)
+        bad = int(((a - b).abs() > lim).sum())
+        assert bad <= max(4, a.numel() // 100), (what, k, bad, a.numel(), float((a - b).abs().max()))
+
+
+def _stage1_pair(B, seed=0):
+    """Two Stage-I engines with the same parameters and optimizer state + one seeded batch."""
+    from oracle import vaegan_oracle as O
+    from fmri_hip.params import ArchConfig
+    from fmri_hip.steps import Stage1Step
+    data = O.synth_batch(B, O.ArchCfg.px64(), seed=1234, steps=1)
+    x, e, zp = data["x"].to(DEV), data["noise"][0, 0].to(DEV), data["noise"][0, 1].to(DEV)
+    a = Stage1Step(ArchConfig.px64(), DEV)
+    a.load_recipe(seed, True)
+    b = Stage1Step(ArchConfig.px64(), DEV)
+    b.load_state_dict(a.state_dict())
+    return a, b, (x, e, zp), data
+
+
+def _sync_optimizers(a, b):
+    for n in ("opt_enc", "opt_dec", "opt_dis"):
+        getattr(b, n).s1.copy_(getattr(a, n).s1)
+
+
+def _finish():
+    from fmri_hip import ops
+    ops.join_side()
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("B", [8, 256])
+def test_two_runs_of_a_step_are_bit_identical(deterministic, B):
+    """The property the other tests of this file stand on: in deterministic mode two engines fed the same batch leave
+    the same bits after three steps -- at B = 8 (generic split-K weight gradients as slabs) and at BASELINE configs[1]'s
+    B = 256 (window kernel with many K pieces as slabs, the narrow 5x5 kernel with one slab per block)."""
+    a, b, args, _ = _stage1_pair(B)
+    for _ in range(3):
+        a.step(*args)
+        b.step(*args)
+    _finish()
+    _assert_same_logs(a.logs(), b.logs(), f"B={B}")
+    _assert_same_bits(a.state_dict(), b.state_dict(), f"two runs, B={B}")
+
+
+def test_default_mode_runs_agree_to_the_atomic_spread():
+    """The DEFAULT reductions (fp32 atomics in the many-split weight gradients): one step of two engines on the same
+    batch agrees to the element-count criterion of ``_same_update`` and to 1e-5 on the logged losses."""
+    a, b, args, _ = _stage1_pair(8)
+    a.step(*args)
+    b.step(*args)
+    _finish()
+    la, lb = a.logs(), b.logs()
+    for k in LOSS_KEYS:
+        assert abs(la[k] - lb[k]) <= 1e-5 * abs(lb[k]), (k, la[k], lb[k])
+    _same_update(a.state_dict(), b.state_dict(), "default mode, two runs")
+
+
+def test_fused_step_equals_separate_calls(deterministic):
+    """``Stage1Step.step`` (weight gradients, discriminator / decoder optimizer updates and weight repacks queued on the
+    side stream under the rest of the backward pass) against the same step issued as forward / gate / backward / apply
+    on one stream: the same bits after two steps."""
+    from fmri_hip import ops
+    a, b, args, _ = _stage1_pair(8)
+    side_was = ops._SIDE["on"]
+    try:
+        for _ in range(2):
+            ops._SIDE["on"] = True
+            a.step(*args)
+            _finish()
+            ops._SIDE["on"] = False
+            b.forward(*args)
+            b.gate(8)
+            b.backward()
+            b.apply()
+            _finish()
+    finally:
+        ops._SIDE["on"] = side_was
+    _assert_same_logs(a.logs(), b.logs(), "fused vs separate")
+    _assert_same_bits(a.state_dict(), b.state_dict(), "fused vs separate")
+
+
+def test_hybrid_recorded_forward_step_equals_eager_step(deterministic):
+    """``Stage1Step.capture_forward``: forward + gate replayed from a HIP graph, backward / updates issued eagerly on two
+    streams -- against the plain ``step`` of a second engine started from the same parameters and RMSprop state: the
+    same bits after each of three steps (every replay must see the weights the previous one's early updates produced)."""
+    a, b, args, _ = _stage1_pair(8)
+    run = a.capture_forward(*args, warmup=1)
+    b.load_state_dict(a.state_dict())
+    _sync_optimizers(a, b)
+    for it in range(3):
+        run()
+        b.step(*args)
+        _finish()
+        _assert_same_logs(a.logs(), b.logs(), f"hybrid vs eager, step {it}")
+        _assert_same_bits(a.state_dict(), b.state_dict(), f"hybrid vs eager, step {it}")
+
+
+def test_recorded_forward_survives_an_eager_step_in_between(deterministic):
+    """capture_forward(): an eager step() at another batch size between two run() calls (the last, partial batch of an
+    epoch) must not leave run() back-propagating the eager batch (it rebinds the recorded forward's tensors).  After the
+    eager B = 4 step ONE run() is compared with ONE eager step of an engine that made the same three steps eagerly: a
+    run() that back-propagated the eager batch's tensors would differ in every element."""
+    a, b, args, _ = _stage1_pair(8)
+    x, e, zp = args
+    run = a.capture_forward(*args, warmup=1)
+    b.load_state_dict(a.state_dict())
+    _sync_optimizers(a, b)
+    for what in ("run", "eager", "run"):
+        if what == "run":
+            run()
+            b.step(*args)
+        else:
+            a.step(x[:4], e[:4], zp[:4])
+            b.step(x[:4], e[:4], zp[:4])
+        _finish()
+        _assert_same_logs(a.logs(), b.logs(), f"after {what}")
+        _assert_same_bits(a.state_dict(), b.state_dict(), f"after {what}")
+
+
+def test_recorded_step_follows_hyper_parameter_schedule(deterministic):
+    """lr, lambda, equilibrium and margin live in device memory: two replays of ONE captured step with the epoch-end
+    updates of train_vgan_stage1.py:448-458 applied in between equal two eagerly issued steps with the same schedule
+    (bit for bit); the gate of the second replay is the ORACLE's gate under the new equilibrium / margin and the size of
+    its update is the oracle's under the new learning rate."""
+    from oracle import vaegan_oracle as O
+    from fmri_hip import ops
+    a, b, args, data = _stage1_pair(8)
+    cfg_o = O.ArchCfg.px64()
+    # "epoch end": lr halved, lambda x 100, equilibrium far above every bce mean -> train_dis = False, train_dec = True
+    sched = dict(lr=0.5e-4, margin=0.01, equilibrium=10.0, lambda_mse=1e-4)
+    run = a.capture(*args, warmup=1)                  # one real (warm-up) step, then the recording (executes nothing)
+    b.load_state_dict(a.state_dict())
+    _sync_optimizers(a, b)
+    flags, before = [], None
+    for it in range(2):
+        if it == 1:
+            a.set_hyper(**sched)
+            b.set_hyper(**sched)
+            before = {k: v.clone() for k, v in a.state_dict().items()}
+        run()
+        side_was = ops._SIDE["on"]
+        ops._SIDE["on"] = False                       # capture() records a one-stream step
+        try:
+            b.step(*args)
+        finally:
+            ops._SIDE["on"] = side_was
+        _finish()
+        la, lb = a.logs(), b.logs()
+        flags.append((la["train_dis"], la["train_dec"]))
+        _assert_same_logs(la, lb, f"replay vs eager, step {it}")
+        _assert_same_bits(a.state_dict(), b.state_dict(), f"replay vs eager, step {it}")
+    assert flags[1] == (False, True), flags
+    after = a.state_dict()
+    # oracle: warm-up step, default step, scheduled step
+    P = O.fill_state(O.vaegan_spec(cfg_o), 0, True)
+    opts = {n: O.OptState(kind="rmsprop", lr=1e-4) for n in ("encoder", "decoder", "discriminator")}
+    hp = O.GanHyper()
+    oargs = (data["x"], data["noise"][0, 0], data["noise"][0, 1], cfg_o)
+    O.stage1_step(P, opts, *oargs, hp=hp)
+    ref = O.stage1_step(P, opts, *oargs, hp=hp)
+    assert flags[0] == (ref["logs"]["train_dis"], ref["logs"]["train_dec"]), flags
+    hp = O.GanHyper(lr=sched["lr"], lambda_mse=sched["lambda_mse"], margin=sched["margin"],
+                    equilibrium=sched["equilibrium"])
+    for o in opts.values():
+        o.lr = sched["lr"]
+    P2 = {k: v.clone() for k, v in P.items()}
+    ref = O.stage1_step(P, opts, *oargs, hp=hp)
+    assert flags[1] == (ref["logs"]["train_dis"], ref["logs"]["train_dec"]), flags
+    for k in ("encoder.fc.0.weight", "decoder.conv.0.conv.weight", "discriminator.conv.2.conv.weight"):
+        du_e = (after[k].float().cpu() - before[k].float().cpu()).norm().item()
+        du_o = (P[k] - P2[k]).norm().item()
+        print(k, du_e, du_o)
+        if k.startswith("discriminator."):
+            assert du_e == 0.0 and du_o == 0.0, k          # gated off by the new equilibrium
+        else:
+            assert abs(du_e - du_o) < 0.1 * du_o, (k, du_e, du_o)    # half the step of lr = 1e-4
+
+
+def test_decoder_fc_running_statistics_lazy_shadow_round_trips(deterministic):
+    """decoder.fc.1 (the (C,H,W)-permuted BatchNorm1d) keeps its running statistics in engine order inside the fused steps
+    and writes them back only when the state dict is read: state_dict() before any step returns what was loaded, after
+    steps (eager and replayed from a HIP graph) exactly what an eagerly synchronised BatchNorm holds, and
+    load_state_dict() in between reaches the next step."""
+    from fmri_hip import ops
+    a, b, args, _ = _stage1_pair(4)
+    keys = ("decoder.fc.1.running_mean", "decoder.fc.1.running_var")
+    sd0 = a.state_dict()
+    assert float(sd0[keys[0]].abs().max()) == 0.0 and float((sd0[keys[1]] - 1.0).abs().max()) == 0.0   # as loaded
+    b.dec.fc_bn._lazy = False                         # reference behaviour: synchronised around every call
+    a.step(*args)
+    b.step(*args)
+    _finish()
+    _assert_same_bits(a.state_dict(), b.state_dict(), "lazy vs synchronised, eager step")
+    # an outside write of the buffers reaches the next step
+    sd = a.state_dict()
+    sd[keys[0]] = torch.full_like(sd[keys[0]], 3.0)
+    a.load_state_dict(sd)
+    b.load_state_dict(sd)
+    _sync_optimizers(a, b)
+    run = a.capture(*args, warmup=1)
+    run()
+    side_was, ops._SIDE["on"] = ops._SIDE["on"], False
+    try:
+        b.step(*args)
+        b.step(*args)
+    finally:
+        ops._SIDE["on"] = side_was
+    _finish()
+    sa, sb = a.state_dict(), b.state_dict()
+    assert float((sa[keys[0]] - 3.0).abs().max()) > 0.0          # the statistics moved on from the written value
+    _assert_same_bits(sa, sb, "lazy vs synchronised, replayed steps")
+
+
+@pytest.mark.parametrize("stage", [1, 3])
+def test_wae_step_recorded_into_a_hip_graph_equals_eager_steps(deterministic, stage):
+    """WaeStep.capture: the whole step (Adam with its step count on the device, the fused latent-discriminator kernels)
+    replayed from a HIP graph equals the eagerly issued steps bit for bit -- 2 warm-up + 3 replayed steps against 5
+    eager ones."""
+    from fmri_hip.params import ArchConfig
+    from fmri_hip.wae_steps import WaeStep
+    cfg, V, B = ArchConfig.px64(), 512, 8
+    rs = np.random.RandomState(11)
+    x = torch.tanh(torch.from_numpy(rs.standard_normal((B, 3, 64, 64)).astype(np.float32))).to(DEV)
+    zf = torch.from_numpy(rs.standard_normal((B, cfg.latent_dim)).astype(np.float32)).to(DEV)
+    fm = torch.from_numpy(rs.standard_normal((B, V)).astype(np.float32)).to(DEV)
+    args = (x, zf) if stage == 1 else (x, None, fm)
+
+    def make():
+        st = WaeStep(cfg, DEV, stage, V if stage > 1 else 0)
+        st.load_recipe(5, False if stage == 1 else None)
+        return st
+    a, b = make(), make()
+    s0 = {k: v.clone() for k, v in a.state_dict().items()}
+    for _ in range(5):
+        a.step(*args)                 # two streams (weight gradients on the side stream)
+    run = b.capture(*args)            # two eager warm-up steps inside; records a one-stream step
+    for _ in range(3):
+        run()
+    _finish()
+    _assert_same_logs(a.logs(), b.logs(), f"wae stage {stage}")
+    sa, sb = a.state_dict(), b.state_dict()
+    _assert_same_bits(sa, sb, f"wae stage {stage}, graph vs eager")
+    moved = [k for k in sa if sa[k].dtype.is_floating_point and sa[k].numel() >= 1024 and "running" not in k
+             and not torch.equal(sa[k], s0[k])]
+    assert moved, "no parameter moved in five steps"

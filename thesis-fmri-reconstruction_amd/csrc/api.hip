@@ -320,7 +320,11 @@ int fmri_igemm_ep(const void* in, const void* w, void* out, const float* bias, c
         static const bool no_c5w = c5w_env && !strcmp(c5w_env, "off");
         static const bool no_c5w8 = c5w_env && !strcmp(c5w_env, "16");          // FMRI_C5W=16: the 16-wide form only
         const int ipbw = q.pw16 ? 1 : 4;
-        if (!no_c5w && !(no_c5w8 && !q.pw16) && !q.bb.x && (q.pw16 ? Ho > 8 : true) && !(se.part && se.group_n > 0 && (se.group_n % ipbw))) {
+        // (gated on the caller's REQUEST for the BatchNorm-backward epilogue, bb.x: the wide kernel has none, and q.bb.x is
+        // also cleared when the narrow form's rows did not fit -- the wide form, needing fewer rows, would then emit
+        // FORWARD statistics rows that the caller reads as (sum g, sum g*xhat))
+        if (!no_c5w && !(no_c5w8 && !q.pw16) && !bb.x && (q.pw16 ? Ho > 8 : true) &&
+            !(se.part && se.group_n > 0 && (se.group_n % ipbw))) {
             C5Args w = q;
             const int ph = q.pw16 ? 16 : 8;
             w.tiles_y = (Ho + ph - 1) / ph;
@@ -409,7 +413,7 @@ int fmri_igemm_ep(const void* in, const void* w, void* out, const float* bias, c
         static const bool no_tc5w = tc5w_env && !strcmp(tc5w_env, "off");
         const bool wide16 = Xc0 > 8 && Yc0 > 8;
         const bool wide8 = Xc0 <= 8 && Yc0 <= 8 && Hi <= 8 && Wi <= 8 && !(se.part && se.group_n > 0 && (se.group_n & 3));
-        if (ok && !no_tc5w && bn_tile == 128 && (wide16 || wide8) && !q.bb.x && !(q.nchunks & 1)) {
+        if (ok && !no_tc5w && bn_tile == 128 && (wide16 || wide8) && !bb.x && !(q.nchunks & 1)) {      // bb.x: as above
             Tc5Args w = q;
             if (wide16) {
                 w.pw_log2 = 4; w.ph_log2 = 4; w.PH = 16; w.IPB = 1; w.IH = 18; w.IW = 18; w.nslice = 11;
@@ -636,6 +640,24 @@ int fmri_wgrad_slabs(int N, int Yc, int Xc, int k, int pad, int splits) {
     return wgrad_plane_pieces(N, Yc, Xc, k, pad, splits, tps);
 }
 
+static int wgrad_narrow_blocks(int N, int Yc, int Xc) {
+    const int64_t ntiles = (int64_t)N * ((Yc + 7) / 8) * ((Xc + 7) / 8);
+    int64_t nb = (ntiles + 31) / 32;                // >= 16 tiles per wave PAIR, at most three 4-wave blocks per CU
+    if (nb > 768) nb = 768;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+int fmri_wgrad_narrow_blocks(int N, int Yc, int Xc) {
+    return (N < 1 || Yc < 1 || Xc < 1) ? 0 : wgrad_narrow_blocks(N, Yc, Xc);
+}
+
+int fmri_set_deterministic(int on) {
+    const int was = g_deterministic;
+    g_deterministic = on ? 1 : 0;
+    return was;
+}
+int fmri_get_deterministic(void) { return g_deterministic; }
+
 int fmri_wgrad(const void* P, const void* Q, float* out, const void* zero16, int N, int Yc, int Xc, int A, int Hq,
                int Wq, int Bc, int k, int stride, int pad, int flip, int apad, int ba_tile, int ldo, int splits,
                int atomic, void* stream) {
@@ -647,7 +669,7 @@ int fmri_wgrad(const void* P, const void* Q, float* out, const void* zero16, int
     const int T = k * k;
     if (ldo % 128 || ldo < T * Bc) return FMRI_E_BADARG;
     if (splits > 1 && !atomic) return FMRI_E_BADARG;
-    if (atomic < 0 || atomic > 3) return FMRI_E_BADARG;
+    if (atomic < 0 || atomic > 4) return FMRI_E_BADARG;
     const int64_t M = (int64_t)N * Yc * Xc;
     if (M < 1 || M > 0x7fffff00LL) return FMRI_E_BADARG;
     // stride-2 sampling, >= 128 rows, 32-channel column blocks, pre-zeroed fp32 output (atomic accumulation):
@@ -700,15 +722,13 @@ int fmri_wgrad(const void* P, const void* Q, float* out, const void* zero16, int
         w.N = N; w.H = Yc; w.W = Xc; w.ldo = ldo; w.flip = flip;
         w.tiles_y = (Yc + 7) / 8; w.tiles_x = (Xc + 7) / 8;
         w.ntiles = N * w.tiles_y * w.tiles_x;
-        int nb = (w.ntiles + 31) / 32;              // >= 16 tiles per wave PAIR, at most three 4-wave blocks per CU
-        if (nb > 768) nb = 768;
-        if (nb < 1) nb = 1;
+        const int nb = wgrad_narrow_blocks(N, Yc, Xc);
         w.nslabs = splits < 1 ? 1 : splits;         // the caller allocated `splits` zeroed slabs of apad x ldo
         w.pad0 = 0;
         w.slab_stride = (int64_t)apad * ldo;
         return wgrad_narrow_launch(w, nb, S(stream));
     }
-    if (atomic == 2) return FMRI_E_UNSUPPORTED;      // per-split slabs exist only in the window-resident kernel
+    if (atomic == 2) return FMRI_E_UNSUPPORTED;      // plane-piece slabs exist only in the window-resident kernel
     WgradArgs a;
     a.P = (const half_t*)P; a.Q = (const half_t*)Q; a.out = out; a.zero = (const half_t*)zero16;
     a.N = N; a.Yc = Yc; a.Xc = Xc; a.A = A; a.Hq = Hq; a.Wq = Wq; a.Bc = Bc;
@@ -719,7 +739,11 @@ int fmri_wgrad(const void* P, const void* Q, float* out, const void* zero16, int
     if (splits > steps) splits = steps;
     a.steps_per_split = (steps + splits - 1) / splits;
     a.splits = (steps + a.steps_per_split - 1) / a.steps_per_split;
-    a.atomic = atomic;
+    // atomic == 4: per-split slabs of the generic kernel -- the caller allocated `splits` (as passed in) slabs of
+    // apad x ldo; the kernel writes every element of the first a.splits (<= splits) of them with plain stores, the
+    // rest stay as the caller left them (zero-filled)
+    a.atomic = atomic == 4 ? 2 : atomic;
+    a.slab_stride = (int64_t)apad * ldo;
     a.ncol_chunks = T * Bc / 8;
     a.fdX = make_fastdiv((uint32_t)Xc);
     a.fdYX = make_fastdiv((uint32_t)(Yc * Xc));

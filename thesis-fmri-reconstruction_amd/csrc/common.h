@@ -264,6 +264,7 @@ struct WgradArgs {
     int32_t M, ldo;
     int32_t splits, steps_per_split, atomic;
     int32_t ncol_chunks;   // T*Bc/8
+    int64_t slab_stride;   // atomic == 2: floats between the per-split output slabs
     FastDiv fdX, fdYX, fdTW, fdBc8;
 };
 

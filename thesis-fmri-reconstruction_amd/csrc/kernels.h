@@ -95,6 +95,9 @@ int bn_bwd_apply_launch(const half_t* x, const half_t* dy, half_t* dx, int M, in
 int act_bwd_launch(const half_t* y, const half_t* dy, half_t* dpre, int M, int C, int act, float* colsum, float* ws,
                    int64_t ws_floats, hipStream_t st);
 
+// loss.hip: process-wide deterministic-reduction switch (fmri_set_deterministic)
+extern int g_deterministic;
+
 int latent_fwd_launch(const float* head, const float* eps, int B, int Z, int zp, half_t* z16, float* kl_rows,
                       float* kl_total, int sample, hipStream_t st);
 int latent_bwd_launch(const float* head, const float* eps, const float* dz, int ldz, float dz_unscale, float kl_w,

@@ -11,6 +11,8 @@
 // unit RMS at its starting point (norm factors nA, nB in the scalar block, derived from all-reduced sums so
 // every data-parallel rank uses the same factor); everything downstream is linear, so the factor is divided
 // out again by the fused optimizer kernels.  No host synchronisation is involved.
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace fmri {
@@ -46,30 +48,35 @@ __device__ __forceinline__ float block_sum_256(float v, float* sh /* >= 4 floats
 }
 
 // ---- latent: heads (mu | logvar, fp32 [B][2z]) + eps -> z (fp16, padded), per-sample KL, total KL
-// one wave per sample row.
+// one wave per sample row (grid-stride over the rows); a block adds the sum of its rows to *kl_total ONCE, its four
+// waves' sums in a fixed order -- launched as one block (deterministic mode) the total is a fixed-order sum.
 __global__ __launch_bounds__(256) void latent_fwd_kernel(const float* __restrict__ head, const float* __restrict__ eps,
                                                          int B, int Z, int zp, half_t* __restrict__ z16,
                                                          float* __restrict__ kl_rows, float* __restrict__ kl_total,
                                                          int sample /* 0: z = mu (WAE) */) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ float sh[4];
     const int lane = threadIdx.x & 63;
-    if (row >= B) return;
-    float kl = 0.f;
-    for (int j = lane; j < zp; j += 64) {
-        float zz = 0.f;
-        if (j < Z) {
-            const float mu = head[(int64_t)row * 2 * Z + j];
-            const float lv = head[(int64_t)row * 2 * Z + Z + j];
-            zz = sample ? eps[(int64_t)row * Z + j] * __expf(0.5f * lv) + mu : mu;
-            kl += -0.5f * (-__expf(lv) - mu * mu + lv + 1.f);
+    const int wave = threadIdx.x >> 6;
+    float klw = 0.f;
+    for (int row = blockIdx.x * 4 + wave; row < B; row += gridDim.x * 4) {
+        float kl = 0.f;
+        for (int j = lane; j < zp; j += 64) {
+            float zz = 0.f;
+            if (j < Z) {
+                const float mu = head[(int64_t)row * 2 * Z + j];
+                const float lv = head[(int64_t)row * 2 * Z + Z + j];
+                zz = sample ? eps[(int64_t)row * Z + j] * __expf(0.5f * lv) + mu : mu;
+                kl += -0.5f * (-__expf(lv) - mu * mu + lv + 1.f);
+            }
+            z16[(int64_t)row * zp + j] = (half_t)zz;
         }
-        z16[(int64_t)row * zp + j] = (half_t)zz;
+        kl = wave_sum(kl);
+        if (lane == 0 && kl_rows) kl_rows[row] = kl;
+        klw += kl;
     }
-    kl = wave_sum(kl);
-    if (lane == 0) {
-        if (kl_rows) kl_rows[row] = kl;
-        if (kl_total) atomicAdd(kl_total, kl);
-    }
+    if (lane == 0) sh[wave] = klw;
+    __syncthreads();
+    if (threadIdx.x == 0 && kl_total) atomicAdd(kl_total, (sh[0] + sh[1]) + (sh[2] + sh[3]));
 }
 
 // backward: dhead[row] = ([ g + w*mu | g*eps*0.5*exp(0.5 lv) + w*0.5*(exp(lv)-1) ]) * out_scale
@@ -102,28 +109,30 @@ __global__ void latent_bwd_kernel(const float* __restrict__ head, const float* _
     }
 }
 
-// ---- feature-matching term: mse_b = sum_f 0.5 (f_o - f_p)^2 over the raw conv-3 features. one block / sample
+// ---- feature-matching term: mse_b = sum_f 0.5 (f_o - f_p)^2 over the raw conv-3 features.  A block takes samples
+// blockIdx.x, blockIdx.x + gridDim.x, ... and adds the sum of its samples to *mse_total once (one block = deterministic)
 __global__ __launch_bounds__(256) void feat_mse_kernel(const half_t* __restrict__ feat, int B, int F,
                                                        float* __restrict__ mse_rows, float* __restrict__ mse_total) {
     __shared__ float sh[4];
-    const int b = blockIdx.x;
-    const half_t* fo = feat + (int64_t)b * F;
-    const half_t* fp = feat + (int64_t)(B + b) * F;
-    float s = 0.f;
-    for (int i = threadIdx.x * 8; i < F; i += 256 * 8) {
-        const h8 o = *(const h8*)(fo + i);
-        const h8 p = *(const h8*)(fp + i);
+    float tot = 0.f;
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        const half_t* fo = feat + (int64_t)b * F;
+        const half_t* fp = feat + (int64_t)(B + b) * F;
+        float s = 0.f;
+        for (int i = threadIdx.x * 8; i < F; i += 256 * 8) {
+            const h8 o = *(const h8*)(fo + i);
+            const h8 p = *(const h8*)(fp + i);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float df = (float)o[j] - (float)p[j];
-            s += 0.5f * df * df;
+            for (int j = 0; j < 8; ++j) {
+                const float df = (float)o[j] - (float)p[j];
+                s += 0.5f * df * df;
+            }
         }
+        s = block_sum_256(s, sh);
+        if (threadIdx.x == 0 && mse_rows) mse_rows[b] = s;
+        tot += s;
     }
-    s = block_sum_256(s, sh);
-    if (threadIdx.x == 0) {
-        if (mse_rows) mse_rows[b] = s;
-        if (mse_total) atomicAdd(mse_total, s);
-    }
+    if (threadIdx.x == 0 && mse_total) atomicAdd(mse_total, tot);
 }
 
 // cotangent of sum(mse) w.r.t. the 3B feature rows: orig +d, pred -d, sampled 0; times gscale * (*norm)
@@ -152,21 +161,41 @@ __global__ __launch_bounds__(256) void feat_mse_bwd_kernel(const half_t* __restr
 }
 
 // ---- pixel term: nle_total = sum 0.5 (x - x_tilde)^2 over real channels of NHWC-padded images;
-// optional cotangent d nle / d x_tilde = -(x - x_tilde) * gscale.
+// optional cotangent d nle / d x_tilde = -(x - x_tilde) * gscale.  Cp == 8 (every image tensor of the engine): one
+// 16-byte load per pixel and operand.
 __global__ __launch_bounds__(256) void pixel_sq_kernel(const half_t* __restrict__ x, const half_t* __restrict__ xt,
                                                        int64_t npix, int C, int Cp, float* __restrict__ total,
                                                        half_t* __restrict__ dxt, float gscale) {
     __shared__ float sh[4];
     float s = 0.f;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < npix;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        for (int c = 0; c < Cp; ++c) {
-            float df = 0.f;
-            if (c < C) {
-                df = (float)x[i * Cp + c] - (float)xt[i * Cp + c];
-                s += 0.5f * df * df;
+    if (Cp == 8) {
+        for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < npix;
+             i += (int64_t)gridDim.x * blockDim.x) {
+            const h8 a = *(const h8*)(x + i * 8);
+            const h8 b = *(const h8*)(xt + i * 8);
+            h8 d;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                float df = 0.f;
+                if (c < C) {
+                    df = (float)a[c] - (float)b[c];
+                    s += 0.5f * df * df;
+                }
+                d[c] = (half_t)(-df * gscale);
             }
-            if (dxt) dxt[i * Cp + c] = (half_t)(-df * gscale);
+            if (dxt) *(h8*)(dxt + i * 8) = d;
+        }
+    } else {
+        for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < npix;
+             i += (int64_t)gridDim.x * blockDim.x) {
+            for (int c = 0; c < Cp; ++c) {
+                float df = 0.f;
+                if (c < C) {
+                    df = (float)x[i * Cp + c] - (float)xt[i * Cp + c];
+                    s += 0.5f * df * df;
+                }
+                if (dxt) dxt[i * Cp + c] = (half_t)(-df * gscale);
+            }
         }
     }
     s = block_sum_256(s, sh);
@@ -379,6 +408,19 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     }
 }
 
+// Process-wide reduction mode (fmri_set_deterministic; FMRI_DETERMINISTIC=1 sets the initial value): when on, every
+// kernel of this file that ends in an atomic add onto a scalar is launched as ONE block, so that each total is a
+// fixed-order sum and two runs of the same step produce the same bits.  Slower (the feature / pixel sums of a
+// 256-image batch take a few hundred microseconds on one CU): a verification mode, not the default.
+static int env_deterministic() {
+    const char* e = getenv("FMRI_DETERMINISTIC");
+    return (e && e[0] == '1') ? 1 : 0;
+}
+int g_deterministic = env_deterministic();
+
+// grid of a reduction kernel whose blocks meet in an atomic add
+static inline int rblk(int blocks) { return g_deterministic ? 1 : blocks; }
+
 static inline int nblk(int64_t total, int cap = 4096) {
     int64_t b = (total + 255) / 256;
     if (b > cap) b = cap;
@@ -389,8 +431,9 @@ static inline int nblk(int64_t total, int cap = 4096) {
 
 int latent_fwd_launch(const float* head, const float* eps, int B, int Z, int zp, half_t* z16, float* kl_rows,
                       float* kl_total, int sample, hipStream_t st) {
-    hipLaunchKernelGGL(latent_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, head, eps, B, Z, zp, z16, kl_rows,
-                       kl_total, sample);
+    const int grid = kl_total ? rblk((B + 3) / 4) : (B + 3) / 4;
+    hipLaunchKernelGGL(latent_fwd_kernel, dim3(grid), dim3(256), 0, st, head, eps, B, Z, zp, z16, kl_rows, kl_total,
+                       sample);
     return LAUNCH_OK();
 }
 int latent_bwd_launch(const float* head, const float* eps, const float* dz, int ldz, float dz_unscale, float kl_w,
@@ -401,7 +444,8 @@ int latent_bwd_launch(const float* head, const float* eps, const float* dz, int 
     return LAUNCH_OK();
 }
 int feat_mse_launch(const half_t* feat, int B, int F, float* mse_rows, float* mse_total, hipStream_t st) {
-    hipLaunchKernelGGL(feat_mse_kernel, dim3(B), dim3(256), 0, st, feat, B, F, mse_rows, mse_total);
+    hipLaunchKernelGGL(feat_mse_kernel, dim3(mse_total ? rblk(B) : B), dim3(256), 0, st, feat, B, F, mse_rows,
+                       mse_total);
     return LAUNCH_OK();
 }
 int feat_mse_bwd_launch(const half_t* feat, int B, int F, half_t* dfeat, float gscale, const float* norm,
@@ -411,13 +455,13 @@ int feat_mse_bwd_launch(const half_t* feat, int B, int F, half_t* dfeat, float g
 }
 int pixel_sq_launch(const half_t* x, const half_t* xt, int64_t npix, int C, int Cp, float* total, half_t* dxt,
                     float gscale, hipStream_t st) {
-    hipLaunchKernelGGL(pixel_sq_kernel, dim3(nblk(npix, 1024)), dim3(256), 0, st, x, xt, npix, C, Cp, total, dxt,
-                       gscale);
+    const int grid = total ? rblk(nblk(npix, 1024)) : nblk(npix, 1024);
+    hipLaunchKernelGGL(pixel_sq_kernel, dim3(grid), dim3(256), 0, st, x, xt, npix, C, Cp, total, dxt, gscale);
     return LAUNCH_OK();
 }
 int gan_head_launch(const float* logit, int ldl, int B, float* prob, float* scal, int parts, hipStream_t st) {
-    hipLaunchKernelGGL(gan_head_kernel, dim3(nblk(3 * (int64_t)B, 64)), dim3(256), 0, st, logit, ldl, B, prob, scal,
-                       parts);
+    hipLaunchKernelGGL(gan_head_kernel, dim3(rblk(nblk(3 * (int64_t)B, 64))), dim3(256), 0, st, logit, ldl, B, prob,
+                       scal, parts);
     return LAUNCH_OK();
 }
 int gan_head_bwd_launch(const float* logit, int ldl, int B, half_t* dlogit, int ldg, float gscale, const float* norm,
@@ -428,8 +472,9 @@ int gan_head_bwd_launch(const float* logit, int ldl, int B, half_t* dlogit, int 
 }
 int wae_logloss_launch(const float* logit, int ldl, int n, int one_minus, float w, float* total, float* prob,
                        half_t* dlogit, int ldg, float gscale, hipStream_t st) {
-    hipLaunchKernelGGL(wae_logloss_kernel, dim3(nblk(n, 64)), dim3(256), 0, st, logit, ldl, n, one_minus, w, total,
-                       prob, dlogit, ldg, gscale);
+    const int grid = total ? rblk(nblk(n, 64)) : nblk(n, 64);
+    hipLaunchKernelGGL(wae_logloss_kernel, dim3(grid), dim3(256), 0, st, logit, ldl, n, one_minus, w, total, prob,
+                       dlogit, ldg, gscale);
     return LAUNCH_OK();
 }
 int compose_gate_launch(float* scal, int* flags, float batch, float nfeat, float npix, float lambda_mse,
@@ -452,7 +497,7 @@ int axpby_f16_launch(const half_t* x, const half_t* y, half_t* out, int64_t n, f
     return LAUNCH_OK();
 }
 int sumsq_launch(const float* x, int64_t n, float* acc, hipStream_t st) {
-    hipLaunchKernelGGL(sumsq_kernel, dim3(nblk(n, 256)), dim3(256), 0, st, x, n, acc);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(rblk(nblk(n, 256))), dim3(256), 0, st, x, n, acc);
     return LAUNCH_OK();
 }
 int renorm_launch(const float* x, half_t* out, int64_t n, float scale, const float* sumsq, float count,

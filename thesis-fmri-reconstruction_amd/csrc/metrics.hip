@@ -113,7 +113,7 @@ int pcc_launch(const float* x, const float* y, int64_t n, double* sums5, float* 
     (void)hipMemsetAsync(sums5, 0, 5 * sizeof(double), st);
     int blocks = (int)((n + 256 * 16 - 1) / (256 * 16));
     if (blocks > 1024) blocks = 1024;
-    if (blocks < 1) blocks = 1;
+    if (blocks < 1 || g_deterministic) blocks = 1;        // one block: fixed-order sums
     hipLaunchKernelGGL(pcc_sums_kernel, dim3(blocks), dim3(256), 0, st, x, y, n, sums5);
     hipLaunchKernelGGL(pcc_final_kernel, dim3(1), dim3(64), 0, st, sums5, (double)n, out);
     return hipGetLastError() == hipSuccess ? OK : E_LAUNCH;

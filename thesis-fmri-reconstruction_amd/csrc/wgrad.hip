@@ -13,7 +13,8 @@
 // Tiles are DMA'd to LDS as [m][channels] rows (256 B) and the MFMA fragments (8 consecutive m per
 // lane) are produced by ds_read_b64_tr_b16 transposing reads -- no transposed copies in HBM.
 // The LDS image is XOR-swizzled (on the DMA source side) so that every transposing read is
-// bank-conflict free.  Split-K over m with fp32 atomics (or plain stores when splits == 1).
+// bank-conflict free.  Split-K over m with fp32 atomics (atomic == 1), per-split slabs written with plain stores
+// (atomic == 2: the deterministic form, summed by fmri_unpack_grad) or plain stores when splits == 1.
 #include "kernels.h"
 
 namespace fmri {
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
         if (it + 1 < nsteps) stage_load(cur ^ 1, it + 1);
         compute(cur);
     }
-    if (nsteps <= 0 && a.atomic) return;
+    if (nsteps <= 0 && a.atomic == 1) return;
 
     // D[i = a][j = column]: lane owns column (lane&15), rows (lane>>4)*4 .. +3
 #pragma unroll
@@ -163,8 +164,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
             const int arow = a0 + wa * WAVE_A + ta * 16 + (lane >> 4) * 4;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float* o = a.out + (int64_t)(arow + r) * a.ldo + col;
-                if (a.atomic) atomicAdd(o, acc[ta][tb][r]);
+                // atomic == 2: every K split stores its own slab (plain stores; fmri_unpack_grad sums them in order)
+                float* o = a.out + (a.atomic == 2 ? (int64_t)blockIdx.z * a.slab_stride : 0) +
+                           (int64_t)(arow + r) * a.ldo + col;
+                if (a.atomic == 1) atomicAdd(o, acc[ta][tb][r]);
                 else *o = acc[ta][tb][r];
             }
         }

@@ -33,6 +33,9 @@ _SIGS = {
     "fmri_igemm_ep": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _l, _i, _l, _p, _p,
                       _p],
     "fmri_wgrad_slabs": [_i, _i, _i, _i, _i, _i],
+    "fmri_wgrad_narrow_blocks": [_i, _i, _i],
+    "fmri_set_deterministic": [_i],
+    "fmri_get_deterministic": [],
     "fmri_wgrad": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "fmri_nchw_to_nhwc": [_p, _p, _i, _i, _i, _i, _p],
     "fmri_nhwc_to_nchw": [_p, _p, _i, _i, _i, _i, _f, _p],

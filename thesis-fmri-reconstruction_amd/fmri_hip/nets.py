@@ -710,7 +710,9 @@ class WaeDiscriminatorNet:
         dz32 = torch.empty(M, Z, dtype=torch.float32, device=dev) if need_dz else None
         wds = [(self.layers[i].pw_d.get() if (i > 0 or need_dz) else None) for i in range(4)]
         kpd = (ctypes.c_int * 4)(*[self.layers[i].pw_d.kpads[0] for i in range(4)])
-        dbias = self._ptrs([l.bg for l in self.layers]) if train else None
+        from . import ops
+        det = ops.deterministic()        # bias gradients as fixed-order column sums instead of the kernel's atomics
+        dbias = self._ptrs([l.bg for l in self.layers]) if (train and not det) else None
         lib.call("fmri_mlp_bwd", _P(dlogit16), dlogit16.shape[1], M, Zp, Z, 512, self._ptrs(hs[1:5]),
                  _P(self.layers[4].pw_f.get()), self._ptrs(wds), kpd, self._ptrs([dbuf[i] for i in range(4)]), dbias,
                  _P(dz32), 1.0 / scale)
@@ -718,4 +720,6 @@ class WaeDiscriminatorNet:
             deltas = [dbuf[0], dbuf[1], dbuf[2], dbuf[3], dlogit16]
             for j in range(5):
                 self.layers[j].wgrad(hs[j], deltas[j], scale)
+                if det:
+                    self.layers[j].bias_grad(deltas[j], scale)
         return dz32

@@ -285,6 +285,32 @@ _WW_SLABS = int(os.environ.get("FMRI_WW_SLABS", "24"))
 
 
 # ------------------------------------------------------------------------------------------------
+# deterministic-reduction mode
+# ------------------------------------------------------------------------------------------------
+# Default: the weight-gradient kernels with many K splits, the narrow 5x5 weight gradient, the latent discriminator's bias
+# gradients and the scalar loss sums meet in fp32 atomics, so two runs of the same step differ in the last bits of those
+# sums (and RMSprop's normalised first updates can turn a last-bit difference of a near-zero gradient into a different
+# step).  ``set_deterministic(True)`` (or FMRI_DETERMINISTIC=1) selects the fixed-order form of each: per-split slabs
+# summed in slab order for every fmri_wgrad route, one slab per block for the narrow kernel, the bias gradients of the
+# fused MLP backward as column sums of its (bit-reproducible) cotangent tiles, one-block launches of the scalar sums
+# (fmri_set_deterministic) -- two runs of a step are then bit-identical, whatever the launch mode (eager, two streams,
+# HIP graph).  tests/test_zz_selfcheck_gpu.py compares the launch modes under it.
+_DET = {"on": os.environ.get("FMRI_DETERMINISTIC") == "1"}
+
+
+def set_deterministic(on: bool) -> bool:
+    """Switch the deterministic-reduction mode; returns the previous setting."""
+    was = _DET["on"]
+    _DET["on"] = bool(on)
+    lib.load().fmri_set_deterministic(1 if on else 0)
+    return was
+
+
+def deterministic() -> bool:
+    return _DET["on"]
+
+
+# ------------------------------------------------------------------------------------------------
 # side stream for weight gradients
 # ------------------------------------------------------------------------------------------------
 # A layer's weight gradient depends only on (input activation, output cotangent) and nothing downstream of the backward
@@ -356,7 +382,7 @@ def run_wgrad(P, Q, N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad, flip=0, flops=0.0)
         budget = _WW_BLOCKS or 256              # one 8-wave block per CU (csrc/wgrad_win.hip)
         splits = max(4, budget // groups)                               # block budget per group over the 4 planes
         nslabs = lib.load().fmri_wgrad_slabs(N, Yc, Xc, k, pad, splits)
-        slabs = nslabs <= _WW_SLABS                                     # few splits: per-split slabs, else atomics
+        slabs = nslabs <= _WW_SLABS or _DET["on"]                       # few splits: per-split slabs, else atomics
         if slabs:
             out = torch.empty(nslabs, apad, ldo, dtype=torch.float32, device=P.device)
         else:
@@ -371,6 +397,8 @@ def run_wgrad(P, Q, N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad, flip=0, flops=0.0)
         # needs >= ~16 tiles per wave to amortise its block reduction: measured 1.9x on the 3B-image discriminator
         # layer, a loss on the B-image decoder layer
         nslabs = 4                   # blocks add into slab (block index % 4): a quarter of the same-address atomics
+        if _DET["on"]:               # one slab per block: every element is added once, onto zero
+            nslabs = lib.load().fmri_wgrad_narrow_blocks(N, Yc, Xc)
         out = torch.zeros(nslabs, apad, ldo, dtype=torch.float32, device=P.device)
         note("fmri::wgrad_narrow_kernel")
         lib.call("fmri_wgrad", _P(P), _P(Q), _P(out), _P(zero_page(P.device)), N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad,
@@ -383,13 +411,17 @@ def run_wgrad(P, Q, N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad, flip=0, flops=0.0)
     if tiles < 512 and steps >= 16:
         splits = min(steps // 8, (1024 + tiles - 1) // tiles)
         splits = max(splits, 1)
-    if splits > 1:
+    mode = 1 if splits > 1 else 0
+    if splits > 1 and _DET["on"]:
+        mode = 4                     # per-split slabs (plain stores), summed in slab order by unpack_grad
+        out = torch.zeros(splits, apad, ldo, dtype=torch.float32, device=P.device)
+    elif splits > 1:
         out = torch.zeros(apad, ldo, dtype=torch.float32, device=P.device)
     else:
         out = torch.empty(apad, ldo, dtype=torch.float32, device=P.device)
     note("fmri::wgrad_kernel")
     lib.call("fmri_wgrad", _P(P), _P(Q), _P(out), _P(zero_page(P.device)), N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad,
-             flip, apad, ba, ldo, splits, 1 if splits > 1 else 0)
+             flip, apad, ba, ldo, splits, mode)
     return out, ldo
 
 

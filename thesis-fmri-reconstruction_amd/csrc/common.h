@@ -16,6 +16,23 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2, ACT_SIGMOID = 3 };
 
+// gfx950 store-data hazard.  A VMEM store of more than 64 bits reads its data VGPRs AFTER it has issued; a VALU write of
+// one of them in the next two issue slots can land first, and the store then carries the new value.  hipcc (ROCm 7.2) pads
+// such pairs with wait states -- except when the store has an SGPR offset, which is how the loader waves of igemm_c5w /
+// igemm_tc5w address a tile's rows.  Round 3 met the back-to-back packed-fp32 form (wrong second dword, every launch);
+// round 4's deterministic mode exposed the single-register form: `buffer_store_dwordx4 v[24:27], v28, s[20:23], s15 offen`
+// directly followed by `v_cndmask_b32 v24, ...` (the next store's offset computed into the first data register) stored a
+// wrong FIRST dword in about one launch in a few hundred, and only while a kernel on another stream kept the memory system
+// busy (tools/probes/store_hazard_stress.py).  Every such store is therefore followed by two wait states that the
+// scheduler may not move: FMRI_STORE_FENCE().  tools/scan_store_hazard.py (a build step, fmri_hip/build.py) counts the wait
+// states behind every wide VMEM store of the library and fails the build on fewer than two.
+#define FMRI_STORE_FENCE()                        \
+    do {                                          \
+        __builtin_amdgcn_sched_barrier(0);        \
+        asm volatile("s_nop 1" ::: "memory");     \
+        __builtin_amdgcn_sched_barrier(0);        \
+    } while (0)
+
 // error codes of the C ABI (include/fmri_hip.h)
 enum Err { OK = 0, E_BADARG = -1, E_UNSUPPORTED = -2, E_LAUNCH = -3, E_WORKSPACE = -4 };
 

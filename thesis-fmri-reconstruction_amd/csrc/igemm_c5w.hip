@@ -299,6 +299,7 @@ __global__ __launch_bounds__(512, 1) void igemm_c5w_kernel(const C5Args a) {
             }
             if (C5W_ABL == 1 && a.N > 0) return;
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, oreg[r][k]), srd_out, (int)vt, (int)(k * row_b), 0);
+            FMRI_STORE_FENCE();        // SGPR-offset store: the compiler pads no wait states (common.h)
         };
         int stg = 0;                              // ring stage of the current step (wave-uniform)
         // one 32-channel sub-chunk: 13 steps (schedule: w5_allow's comment); `outs`: the previous tile's outputs leave

@@ -245,15 +245,7 @@ __global__ __launch_bounds__(512, 1) void igemm_tc5w_kernel(const Tc5Args a) {
             }
             if (TC5W_ABL == 1 && a.N > 0) return;
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, oreg[r][k]), srd_out, (int)vt, (int)(k * row2_b), 0);
-            if constexpr (STATS == 1 && SOLO) {
-                // gfx950 store-data hazard (tools/scan_store_hazard.py): in this instantiation the compiler
-                // places a v_pk_add_f32 / v_pk_mul_f32 of the statistics that overwrites the first two data registers
-                // DIRECTLY behind the store, and the store then carries the new second dword.  Its hazard recogniser leaves
-                // no wait state because the store has an SGPR offset; two wait states here are measured to be enough.
-                __builtin_amdgcn_sched_barrier(0);
-                asm volatile("s_nop 1" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            FMRI_STORE_FENCE();        // SGPR-offset store: the compiler pads no wait states (common.h)
         };
         auto feed_class = [&](auto CLS_) __attribute__((always_inline)) {
             constexpr int cls = decltype(CLS_)::value;

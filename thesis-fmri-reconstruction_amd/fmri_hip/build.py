@@ -55,7 +55,32 @@ def build(force: bool = False, verbose: bool = True) -> str:
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _stale(LIB, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
+        _scan_store_hazard(verbose)
     return LIB
+
+
+def _scan_store_hazard(verbose: bool):
+    """Build step: the gfx950 store-data hazard scan of the linked library (tools/scan_store_hazard.py; csrc/common.h
+    FMRI_STORE_FENCE).  A hit fails the build -- the library is removed, so that nothing can load it."""
+    import importlib.util
+    tool = os.path.abspath(os.path.join(HERE, "..", "..", "tools", "scan_store_hazard.py"))
+    if not os.path.exists(tool):
+        return
+    spec = importlib.util.spec_from_file_location("scan_store_hazard", tool)
+    scan = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(scan)
+    if not os.path.exists(scan.OBJDUMP):
+        if verbose:
+            print("store-hazard scan skipped: llvm-objdump not found", file=sys.stderr)
+        return
+    hits, nstores, _, _ = scan.scan(LIB)
+    if hits:
+        os.unlink(LIB)
+        raise RuntimeError(f"gfx950 store-data hazard: {len(hits)} wide VMEM stores of the build are followed by a VALU "
+                           "write of their data registers with fewer than two wait states (FMRI_STORE_FENCE):\n"
+                           + "\n".join(f"  {k}: {s}  ->  {v}  ({ws} wait states)" for k, s, v, ws in hits[:12]))
+    if verbose:
+        print(f"store-hazard scan: {nstores} wide VMEM stores, 0 hazards")
 
 
 if __name__ == "__main__":

@@ -1,17 +1,23 @@
 #!/usr/bin/env python3
 """gfx950 store-data hazard scan of the built library (dev container or GPU box; needs only llvm-objdump).
 
-Observed on MI355X (round 3, `igemm_tc5w_kernel<16,1,true>`): a `buffer_store_dwordx4 v[a:a+3], …, sN offen` whose NEXT
-instruction is a packed-fp32 VALU op (`v_pk_add_f32` / `v_pk_mul_f32` …) writing v[a:a+1] stores the NEW value of v[a+1]:
-the second dword of the 16 bytes is the VALU result, not the register's content at issue.  The compiler's hazard recogniser
-(ROCm 7.2 clang) leaves no wait state there when the store carries an SGPR offset.  One `s_nop` between the two cures it
-(tools/probes/tc5w_check.py, variants ss1/ss4 in DESIGN.md §6).
+A VMEM store of more than 64 bits (``*_store_dwordx3/x4``) reads its data VGPRs after it has issued; a VALU write of one
+of them in the next two issue slots can land first.  hipcc pads such pairs with wait states EXCEPT when the store carries
+an SGPR offset.  Observed on MI355X:
+  round 3, `igemm_tc5w_kernel<16,1,true>`: `buffer_store_dwordx4 v[14:17], ..., s20 offen` + `v_pk_add_f32 v[14:15], ...`
+           back to back -> wrong second dword in every launch; one wait state did not cure it, two did;
+  round 4, `igemm_tc5w_kernel<8,0,true>`:  `buffer_store_dwordx4 v[24:27], v28, ..., s15 offen` + `v_cndmask_b32 v24, ...`
+           back to back -> wrong FIRST dword in ~1 launch of a few hundred, only with another stream's kernel running
+           (tools/probes/store_hazard_stress.py); found by the bit-exact self-comparison tests of deterministic mode.
 
-This script disassembles every gfx950 code object of libfmri_hip.so and reports each VMEM store of more than 64 bits that
-is followed, within WINDOW instructions (default 1: the observed case), by a VALU instruction writing any of its data
-registers.  Exit status 1 if any is found.  tests/test_abi.py runs it so that a scheduling change cannot ship the pattern.
+This script disassembles every gfx950 code object of libfmri_hip.so and counts, for each wide VMEM store, the wait states
+(instructions issued, `s_nop N` = N + 1) in front of the first VALU instruction that writes one of its data registers.
+Fewer than NEED (default 2: what hipcc itself leaves behind stores without an SGPR offset, and what cured both observed
+cases) is a hazard.  Exit status 1 if any is found.  fmri_hip/build.py runs it as a build step and tests/test_abi.py on
+every CPU test run, so that a scheduling change cannot ship the pattern.  (VMEM loads into the data registers are not
+hazards: the memory pipeline executes a wave's VMEM instructions in order.)
 
-usage: tools/scan_store_hazard.py [path/to/libfmri_hip.so] [--window N] [--all-valu]
+usage: tools/scan_store_hazard.py [path/to/libfmri_hip.so] [--need N]
 """
 import os
 import re
@@ -57,10 +63,10 @@ def code_objects(lib):
     return tmp, sorted(os.path.join(tmp, f) for f in os.listdir(tmp) if "gfx950" in f)
 
 
-def scan_text(dis, window=1, packed_only=True):
-    """Hits in one llvm-objdump -d listing: ([(kernel, store, valu)], wide stores seen, symbols seen)."""
+def scan_text(dis, need=2):
+    """Hits in one llvm-objdump -d listing: ([(kernel, store, valu, wait states)], wide stores seen, symbols seen)."""
     hits, nstores, nkern = [], 0, 0
-    kern, pend = "?", []          # pend: [(store text, data regs, instructions left)]
+    kern, pend = "?", []          # pend: [(store text, data regs, wait states elapsed since the store)]
     for line in dis.splitlines():
         lm = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
         if lm:
@@ -71,25 +77,27 @@ def scan_text(dis, window=1, packed_only=True):
         if not body.strip() or body.strip().startswith((";", ".")):
             continue
         op, dst = valu_dst(body)
-        if op and dst and (not packed_only or op.startswith("v_pk_") or len(dst) > 1):
-            for st, regs, _ in pend:
+        if op and dst:
+            for st, regs, ws in pend:
                 if regs & dst:
-                    hits.append((kern, st.strip(), body.strip()))
-        pend = [(s, r, n - 1) for s, r, n in pend if n > 1]
+                    hits.append((kern, st.strip(), body.strip(), ws))
+        nm = re.match(r"^\s*s_nop\s+(\d+)", body)
+        inc = int(nm.group(1)) + 1 if nm else 1
+        pend = [(s, r, w + inc) for s, r, w in pend if w + inc < need]
         sm = STORE.match(body)
         if sm:
             nstores += 1
-            pend.append((body, store_data(sm.group(1), sm.group(2)), window))
+            pend.append((body, store_data(sm.group(1), sm.group(2)), 0))
     return hits, nstores, nkern
 
 
-def scan(lib, window=1, packed_only=True):
+def scan(lib, need=2):
     tmp, objs = code_objects(lib)
     hits, nstores, nkern = [], 0, 0
     try:
         for o in objs:
             dis = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", o], check=True, capture_output=True, text=True).stdout
-            h, ns, nk = scan_text(dis, window, packed_only)
+            h, ns, nk = scan_text(dis, need)
             hits += h
             nstores += ns
             nkern += nk
@@ -103,20 +111,18 @@ def scan(lib, window=1, packed_only=True):
 def main(argv):
     here = os.path.dirname(os.path.abspath(__file__))
     lib = os.path.join(here, "..", "thesis-fmri-reconstruction_amd", "fmri_hip", "libfmri_hip.so")
-    window, packed_only = 1, True
+    need = 2
     it = iter(argv)
     for a in it:
-        if a == "--window":
-            window = int(next(it))
-        elif a == "--all-valu":
-            packed_only = False
+        if a == "--need":
+            need = int(next(it))
         else:
             lib = a
-    hits, nstores, nkern, nobj = scan(lib, window, packed_only)
-    print(f"{nobj} code objects, {nkern} symbols, {nstores} wide VMEM stores scanned, window {window}, "
-          f"{'multi-register VALU writers' if packed_only else 'all VALU writers'}: {len(hits)} hazards")
-    for k, s, v in hits:
-        print(f"  {k}\n      {s}\n      {v}")
+    hits, nstores, nkern, nobj = scan(lib, need)
+    print(f"{nobj} code objects, {nkern} symbols, {nstores} wide VMEM stores scanned, {need} wait states required in front "
+          f"of a VALU write of the store data: {len(hits)} hazards")
+    for k, s, v, ws in hits:
+        print(f"  {k}\n      {s}\n      {v}      ({ws} wait states)")
     return 1 if hits else 0
 
 

@@ -247,9 +247,15 @@ int fmri_bn_bwd_reduce2(const void* x, const void* dy2, int M, int C, const floa
 int fmri_bn_bwd_apply2(const void* x, const void* dy2, void* dx2, int M, int C, float count, const float* mean,
                        const float* rstd, const float* gamma, const float* beta, int relu, const float* sums4C,
                        void* stream);
-/* dpre = dy * act'(y) (ReLU / tanh); if colsum2C != NULL its first C floats receive the column sums of dpre */
+/* dpre = dy * act'(y) (ReLU / tanh); if colsum2C != NULL its first C floats receive the column sums of dpre and, with
+ * dbias != NULL, dbias[c] += gscale * colsum[c] for c < dbias_n <= C (the bias gradient of the layer in front of the activation: autograd of
+ * `nn.Conv2d(..., bias=True)` + Tanh, models/vae_gan.py:118-121) */
 int fmri_act_bwd(const void* y, const void* dy, void* dpre, int M, int C, int act, float* colsum2C, float* ws,
-                 int64_t ws_floats, void* stream);
+                 int64_t ws_floats, float* dbias, int dbias_n, float gscale, void* stream);
+/* dst[c] += scale * sum_{m < M} src[m*ld_row + c*ld_col], c < C; src fp16 (is_f16) or fp32.  Bias gradients of the dense
+ * layers (column sums of the cotangent rows, what autograd's Linear backward reduces) in one launch, fixed-order sums. */
+int fmri_colsum_acc(const void* src, int is_f16, int M, int C, int64_t ld_row, int64_t ld_col, float scale, float* dst,
+                    void* stream);
 
 /* ---- latent / losses (models/vae_gan.py:266-269, :302-320; train_vgan_stage1.py:368-404) ----------- */
 int fmri_latent_fwd(const float* head, const float* eps, int B, int Z, int zp, void* z16, float* kl_rows,

@@ -859,10 +859,15 @@ int fmri_bn_bwd_apply(const void* x, const void* dy, void* dx, int M, int C, flo
                                relu, sums2C, S(stream));
 }
 int fmri_act_bwd(const void* y, const void* dy, void* dpre, int M, int C, int act, float* colsum2C, float* ws,
-                 int64_t ws_floats, void* stream) {
-    if (!y || !dy || !dpre || (C & 7)) return FMRI_E_BADARG;
-    return act_bwd_launch((const half_t*)y, (const half_t*)dy, (half_t*)dpre, M, C, act, colsum2C, ws, ws_floats,
-                          S(stream));
+                 int64_t ws_floats, float* dbias, int dbias_n, float gscale, void* stream) {
+    if (!y || !dy || !dpre || (C & 7) || (dbias && (!colsum2C || dbias_n < 1 || dbias_n > C))) return FMRI_E_BADARG;
+    return act_bwd_launch((const half_t*)y, (const half_t*)dy, (half_t*)dpre, M, C, act, colsum2C, ws, ws_floats, dbias,
+                          dbias_n, gscale, S(stream));
+}
+int fmri_colsum_acc(const void* src, int is_f16, int M, int C, int64_t ld_row, int64_t ld_col, float scale, float* dst,
+                    void* stream) {
+    if (!src || !dst || M < 1 || C < 1) return FMRI_E_BADARG;
+    return colsum_acc_launch(src, is_f16, M, C, ld_row, ld_col, scale, dst, S(stream));
 }
 
 int fmri_latent_fwd(const float* head, const float* eps, int B, int Z, int zp, void* z16, float* kl_rows,

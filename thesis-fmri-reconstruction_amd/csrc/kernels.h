@@ -93,7 +93,9 @@ int bn_bwd_apply_launch(const half_t* x, const half_t* dy, half_t* dx, int M, in
                         const float* rstd, const float* gamma, const float* beta, int relu, const float* sums,
                         hipStream_t st);
 int act_bwd_launch(const half_t* y, const half_t* dy, half_t* dpre, int M, int C, int act, float* colsum, float* ws,
-                   int64_t ws_floats, hipStream_t st);
+                   int64_t ws_floats, float* dbias, int dbias_n, float gscale, hipStream_t st);
+int colsum_acc_launch(const void* src, int is_f16, int M, int C, int64_t ld_row, int64_t ld_col, float scale, float* dst,
+                      hipStream_t st);
 
 // loss.hip: process-wide deterministic-reduction switch (fmri_set_deterministic)
 extern int g_deterministic;

@@ -316,6 +316,27 @@ __global__ void permute_chw_kernel(const float* __restrict__ src, float* __restr
     }
 }
 
+// dst[c] += scale * sum_m src[m*ld_row + c*ld_col], c < C (bias gradients: column sums of a cotangent; also the spare
+// column of the narrow weight-gradient kernel's slabs).  One block per 8 columns, 32 row lanes, fixed-order sums.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_acc_kernel(const T* __restrict__ src, int M, int C, int64_t ld_row,
+                                                         int64_t ld_col, float scale, float* __restrict__ dst) {
+    __shared__ float red[32][9];
+    const int cx = threadIdx.x & 7, ry = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + cx;
+    float s = 0.f;
+    if (c < C)
+        for (int m = ry; m < M; m += 32) s += (float)src[(int64_t)m * ld_row + (int64_t)c * ld_col];
+    red[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) t += red[r][cx];
+        dst[c] += scale * t;
+    }
+}
+
 static inline int nblocks(int64_t total, int threads = 256, int cap = 4096) {
     int64_t b = (total + threads - 1) / threads;
     if (b > cap) b = cap;
@@ -397,6 +418,16 @@ int reduce_slabs_launch(const float* slabs, int nslabs, int64_t slab_stride, int
                         int act, float* out32, int ld32, half_t* out16, int ld16, hipStream_t st) {
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(nblocks((int64_t)M * ld)), dim3(256), 0, st, slabs, nslabs,
                        slab_stride, M, C, ld, bias, act, out32, ld32, out16, ld16);
+    return hipGetLastError() == hipSuccess ? OK : E_LAUNCH;
+}
+int colsum_acc_launch(const void* src, int is_f16, int M, int C, int64_t ld_row, int64_t ld_col, float scale, float* dst,
+                      hipStream_t st) {
+    if (is_f16)
+        hipLaunchKernelGGL((colsum_acc_kernel<half_t>), dim3((C + 7) / 8), dim3(256), 0, st, (const half_t*)src, M, C,
+                           ld_row, ld_col, scale, dst);
+    else
+        hipLaunchKernelGGL((colsum_acc_kernel<float>), dim3((C + 7) / 8), dim3(256), 0, st, (const float*)src, M, C,
+                           ld_row, ld_col, scale, dst);
     return hipGetLastError() == hipSuccess ? OK : E_LAUNCH;
 }
 int permute_chw_launch(const float* s, float* d, int C, int HW, int to_engine, float scale, int accumulate,

@@ -534,7 +534,7 @@ template <int MODE>
 static int reduce_launch(const half_t* x, const half_t* dy, half_t* dout, int M, int C, const float* mean,
                          const float* rstd, const float* gamma, const float* beta, int flag, float* sums, float* ws,
                          int64_t ws_floats, hipStream_t st, float* g0 = nullptr, float* g1 = nullptr,
-                         float gscale = 0.f) {
+                         float gscale = 0.f, int g_count = 0) {
     int max_gy = 1 << 30;
     if (sums) {
         if (!ws || ws_floats < 2 * (int64_t)C) return E_WORKSPACE;
@@ -546,7 +546,7 @@ static int reduce_launch(const half_t* x, const half_t* dy, half_t* dout, int M,
     if (sums) {
         const int n = 2 * C;
         hipLaunchKernelGGL(fold_partials_kernel, dim3((n + 31) / 32), dim3(1024), 0, st, ws, g.gy, n, sums, g0, g1,
-                           gscale, 0, 0);
+                           gscale, g_count, 0);
     }
     return LAUNCH_OK();
 }
@@ -619,10 +619,12 @@ int bn_bwd_reduce_launch(const half_t* x, const half_t* dy, int M, int C, const 
     return reduce_launch<1>(x, dy, nullptr, M, C, mean, rstd, gamma, beta, relu, sums, ws, ws_floats, st, dbeta, dgamma,
                             gscale);
 }
-// colsum may be null (then no reduction is performed); colsum gets [2][C] (second half unused)
+// colsum may be null (then no reduction is performed); colsum gets [2][C] (second half unused).  dbias (may be null):
+// dbias[c] += gscale * colsum[c], c < dbias_n <= C, in the fold of the partial sums (one writer per element).
 int act_bwd_launch(const half_t* y, const half_t* dy, half_t* dpre, int M, int C, int act, float* colsum, float* ws,
-                   int64_t ws_floats, hipStream_t st) {
-    return reduce_launch<2>(y, dy, dpre, M, C, nullptr, nullptr, nullptr, nullptr, act, colsum, ws, ws_floats, st);
+                   int64_t ws_floats, float* dbias, int dbias_n, float gscale, hipStream_t st) {
+    return reduce_launch<2>(y, dy, dpre, M, C, nullptr, nullptr, nullptr, nullptr, act, colsum, ws, ws_floats, st, dbias,
+                            nullptr, gscale, dbias_n);
 }
 int bn_bwd_reduce2_launch(const half_t* x, const half_t* dy, int M, int C, const float* mean, const float* rstd,
                           const float* gamma, const float* beta, int relu, float* sums4C, float* ws, int64_t ws_floats,

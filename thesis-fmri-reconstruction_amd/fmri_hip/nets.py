@@ -353,9 +353,9 @@ class DecoderNet:
             colsum = None
             if en["train"]:
                 colsum = torch.empty(2 * pad8(self.c3.cout), dtype=torch.float32, device=cot.device)
-            act_backward(rows(y, en["g"]), rows(cot, e), ACT_TANH, colsum, out=rows(dpre, e))
-            if en["train"]:
-                self.c3.bg.add_(colsum[:self.c3.cout], alpha=1.0 / en["scale"])
+            # the bias gradient of conv.3 rides in the fold of the column sums (its first cout entries)
+            act_backward(rows(y, en["g"]), rows(cot, e), ACT_TANH, colsum, out=rows(dpre, e),
+                         dbias=self.c3.bg if en["train"] else None, dbias_scale=1.0 / en["scale"])
         wgrads(self.c3, ctx["acts"][3], dpre)
         _, hi, wi, _ = ctx["acts"][3].shape
         d = self.c3.dgrad(dpre, hi, wi)
@@ -601,9 +601,9 @@ class DiscriminatorNet:
                 colsum = None
                 if s["train"]:
                     colsum = torch.empty(2 * self.c0.coutp, dtype=torch.float32, device=d.device)
-                dpre = act_backward(a0[need[si]], dacts[si], ACT_RELU, colsum)
+                dpre = act_backward(a0[need[si]], dacts[si], ACT_RELU, colsum,
+                                    dbias=self.c0.bg if s["train"] else None, dbias_scale=1.0 / s["scale"])
                 if s["train"]:
-                    self.c0.bg.add_(colsum[:self.c0.cout], alpha=1.0 / s["scale"])
                     self.c0.wgrad(ctx["x"], dpre, s["scale"])
             if img_rows is not None and s["img"]:
                 _, xh, xw, _ = ctx["x"].shape

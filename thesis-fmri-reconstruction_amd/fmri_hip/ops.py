@@ -595,9 +595,12 @@ class ConvLayer:
         if bias_too:
             # bias.grad += (1/scale) * sum over pixels of dy: the narrow kernel's spare column, else a reduction
             if getattr(packed, "_fmri_colsum", False):
-                self.bg.add_(packed[:, :self.cout, self.k * self.k * self.cinp].sum(0), alpha=1.0 / scale)
+                # slabs [nslabs][apad][ldo]: element (a, column k*k*cinp) of every slab
+                colsum_acc(packed[0, 0, self.k * self.k * self.cinp:], packed.shape[0], self.cout,
+                           packed.shape[1] * packed.shape[2], packed.shape[2], 1.0 / scale, self.bg)
             else:
-                self.bg.add_(dy.reshape(-1, self.coutp)[:, :self.cout].float().sum(0), alpha=1.0 / scale)
+                d2 = dy.reshape(-1, self.coutp)
+                colsum_acc(d2, d2.shape[0], self.cout, self.coutp, 1, 1.0 / scale, self.bg)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -687,7 +690,7 @@ class DenseLayer:
 
     def bias_grad(self, dy: torch.Tensor, scale: float):
         if self.bg is not None:
-            self.bg.add_(dy[:, :self.n_out].float().sum(0), alpha=1.0 / scale)
+            colsum_acc(dy, dy.shape[0], self.n_out, dy.shape[1], 1, 1.0 / scale, self.bg)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -988,8 +991,10 @@ def _reduce_ws(M: int, C: int, device) -> torch.Tensor:
 
 
 def act_backward(y: torch.Tensor, dy: torch.Tensor, act: int, colsum: Optional[torch.Tensor] = None,
-                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """dpre = dy * act'(y).  ``colsum`` (fp32, >= 2*C floats): its first C entries receive sum_rows(dpre)."""
+                 out: Optional[torch.Tensor] = None, dbias: Optional[torch.Tensor] = None,
+                 dbias_scale: float = 1.0) -> torch.Tensor:
+    """dpre = dy * act'(y).  ``colsum`` (fp32, >= 2*C floats): its first C entries receive sum_rows(dpre); ``dbias``
+    (fp32, needs ``colsum``): dbias[:n] += dbias_scale * sum_rows(dpre)[:n], n = min(C, len(dbias)), in the same launches."""
     C = y.shape[-1]
     M = y.numel() // C
     if out is None:
@@ -998,10 +1003,17 @@ def act_backward(y: torch.Tensor, dy: torch.Tensor, act: int, colsum: Optional[t
     if colsum is not None:
         assert colsum.numel() >= 2 * C
         ws = _reduce_ws(M, C, y.device)
-        lib.call("fmri_act_bwd", _P(y), _P(dy), _P(out), M, C, act, _P(colsum), _P(ws), ws.numel())
+        lib.call("fmri_act_bwd", _P(y), _P(dy), _P(out), M, C, act, _P(colsum), _P(ws), ws.numel(), _P(dbias),
+                 min(C, dbias.numel()) if dbias is not None else 0, float(dbias_scale))
     else:
-        lib.call("fmri_act_bwd", _P(y), _P(dy), _P(out), M, C, act, None, None, 0)
+        lib.call("fmri_act_bwd", _P(y), _P(dy), _P(out), M, C, act, None, None, 0, None, 0, 0.0)
     return out
+
+
+def colsum_acc(src: torch.Tensor, M: int, C: int, ld_row: int, ld_col: int, scale: float, dst: torch.Tensor):
+    """dst[c] += scale * sum_{m < M} src[m*ld_row + c*ld_col] (csrc/layout.hip; bias gradients)."""
+    lib.call("fmri_colsum_acc", _P(src), 1 if src.dtype == torch.float16 else 0, M, C, ld_row, ld_col, float(scale),
+             _P(dst))
 
 
 def axpby(x: torch.Tensor, y: Optional[torch.Tensor], a: float, b: float, out: Optional[torch.Tensor] = None,

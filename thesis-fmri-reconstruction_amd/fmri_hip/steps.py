@@ -298,7 +298,7 @@ class _GanStepBase:
         """fp32 cotangent -> unit-RMS fp16 (times ``scale``); S_NE <- (*factor_in) / rms.  The sum of squares is
         all-reduced so that every data-parallel rank applies the same factor."""
         n = x32.numel()
-        self._slot(S_ESQ).zero_()
+        # (slot S_ESQ is zero here: the gate kernel, which every step runs between forward and backward, clears it)
         lib.call("fmri_sumsq", _P(x32), n, _P(self._slot(S_ESQ)))
         self.dd.all_reduce(self._slot(S_ESQ))
         out = torch.empty(x32.shape, dtype=torch.float16, device=x32.device)

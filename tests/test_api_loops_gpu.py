@@ -466,3 +466,73 @@ def test_literal_dual_stage1_loop_body_runs_on_engine():
     for k, v in P.items():
         if "num_batches" in k:
             assert int(sd[k]) == int(v), (k, int(sd[k]), int(v))
+
+
+@pytest.mark.parametrize("level", [1, 2])
+def test_discriminator_recon_level_matches_oracle(level):
+    """``Discriminator(recon_level=1 | 2)`` (models/vae_gan.py:139-173): the 'REC' call returns the RAW convolution output
+    of block ``recon_level`` and stops there -- the blocks above it see no forward, no running-statistics update and no
+    gradient -- while a 'GAN' call runs the whole stack.  Features, their gradients w.r.t. the predicted images and the
+    parameters, the class probabilities and the BatchNorm counters against the CPU oracle."""
+    from oracle import vaegan_oracle as O
+    _cfg64()
+    import models.vae_gan as M
+    cfg_o = O.ArchCfg.px64()
+    B = 4
+    rs = np.random.RandomState(77 + level)
+    xs = [torch.from_numpy(rs.uniform(-1, 1, (B, 3, 64, 64)).astype(np.float32)) for _ in range(3)]
+    P = O.fill_state(O.discriminator_spec(cfg_o, ""), 21, True)
+    dis = M.Discriminator(channel_in=3, recon_level=level).to(DEV)
+    dis.load_state_dict({k: v.clone() for k, v in P.items()})
+    dis.train()
+    xo, xp, xq = (t.to(DEV) for t in xs)
+    xp.requires_grad_(True)
+    feat = dis(xo, xp, xq, "REC")
+    w = torch.from_numpy(rs.standard_normal(tuple(feat.shape)).astype(np.float32))
+    (feat * w.to(DEV)).sum().backward()
+    # oracle: same call under autograd
+    Po = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and "running" not in k else v.clone())
+          for k, v in P.items()}
+    xpo = xs[1].clone().requires_grad_(True)
+    ref = O.discriminator_fwd(Po, "", xs[0], xpo, xs[2], "REC", cfg_o, True, recon_level=level)
+    (ref * w).sum().backward()
+    assert tuple(feat.shape) == tuple(ref.shape)
+    err = ((feat.detach().cpu() - ref.detach()).norm() / ref.detach().norm()).item()
+    assert err < 5e-3, err
+    gx = ((xp.grad.cpu() - xpo.grad).norm() / xpo.grad.norm()).item()
+    assert gx < 3e-2, gx
+    got = dict(dis.named_parameters())
+    for k, v in Po.items():
+        if not (torch.is_tensor(v) and v.requires_grad):
+            continue
+        blk = int(k.split(".")[1]) if k.startswith("conv.") else 99
+        if blk > level or v.grad is None:
+            # never reached by a REC call (blocks above the level; the level block's own BatchNorm, whose output the
+            # call throws away)
+            assert v.grad is None or float(v.grad.abs().max()) == 0.0
+            assert got[k].grad is None or float(got[k].grad.abs().max()) == 0.0, k
+            continue
+        g, r = got[k].grad.cpu().double().reshape(-1), v.grad.double().reshape(-1)
+        cos = float(g @ r / (g.norm() * r.norm() + 1e-30))
+        assert cos > 0.98 and abs(float(g.norm() / r.norm()) - 1) < 0.05, (k, cos, float(g.norm() / r.norm()))
+    sd = dis.state_dict()
+    for i in (1, 2, 3):
+        assert int(sd[f"conv.{i}.bn.num_batches_tracked"]) == (1 if i <= level else 0), i
+        assert int(Po[f"conv.{i}.bn.num_batches_tracked"]) == (1 if i <= level else 0), i
+    # a GAN call on the same tensors runs every block (and is not served from the REC call's conv stack)
+    prob = dis(xo, xp.detach(), xq, "GAN")
+    refp = O.discriminator_fwd(Po, "", xs[0], xs[1], xs[2], "GAN", cfg_o, True)
+    assert float((prob.detach().cpu() - refp.detach()).abs().max()) < 3e-3
+    sd = dis.state_dict()
+    for i in (1, 2, 3):
+        assert int(sd[f"conv.{i}.bn.num_batches_tracked"]) == (2 if i <= level else 1), i
+
+
+def test_discriminator_recon_level_outside_the_reference_range_is_refused():
+    """Level 0 raises a TypeError in the reference (its block 0 is an nn.Sequential called with two arguments), levels
+    above 3 make its forward return None: the engine refuses both at construction."""
+    _cfg64()
+    import models.vae_gan as M
+    for level in (0, 4):
+        with pytest.raises(ValueError):
+            M.Discriminator(channel_in=3, recon_level=level).to(DEV)._engine()

@@ -420,8 +420,13 @@ class DecoderNet:
 # ------------------------------------------------------------------------------------------------
 class DiscriminatorNet:
     def __init__(self, cfg: ArchConfig, device, recon_level: int = 3):
-        if recon_level != 3:
-            raise NotImplementedError("the HIP engine implements recon_level=3 (the reference default)")
+        # models/vae_gan.py:139-173: the 'REC' output is the RAW convolution output of block ``recon_level``.  Block 0 is
+        # an nn.Sequential, which does not take the reference's ``lay(ten, True)`` call (TypeError), and a level past
+        # the last block makes its forward return None: levels 1..3 are the ones the reference can run.
+        if recon_level not in (1, 2, 3):
+            raise ValueError(f"recon_level={recon_level}: the reference Discriminator works for levels 1, 2, 3 only "
+                             "(level 0 raises a TypeError there, levels > 3 return None; models/vae_gan.py:164-173)")
+        self.level = recon_level
         self.cfg = cfg
         self.group = FlatGroup(discriminator_spec(cfg), device)
         g = self.group
@@ -451,8 +456,11 @@ class DiscriminatorNet:
         a0 = self.c0.forward(x16, ACT_RELU)
         acts, raws, svs = [a0], [], []
         h = a0
+        lv = self.level
         for li, (conv, bn) in enumerate(zip(self.convs, self.bns)):
-            if bn.eval_mode and not bn.perm and li < 2:       # (the third block's RAW output is the 'REC' feature tensor)
+            if not head and li >= lv:
+                break                     # a 'REC' call ends at block ``recon_level`` (models/vae_gan.py:166-173)
+            if bn.eval_mode and not bn.perm and li != lv - 1:   # (block ``recon_level``'s RAW output is the 'REC' tensor)
                 out_e = conv.forward(h, affine=bn.eval_affine())
                 if conv.aff_applied:
                     raws.append(None); svs.append(None); acts.append(out_e)
@@ -461,14 +469,17 @@ class DiscriminatorNet:
                 raw = out_e
             else:
                 raw = conv.forward(h, bn_groups=0 if bn.eval_mode else 1)
-            h, sv = bn.forward(raw, relu=True, updates=conv_updates if train_stats else 0, stat_acc=conv.take_stats())
+            # one pass standing for the reference's REC + GAN passes (conv_updates = 2): the REC pass never reaches the
+            # blocks above ``recon_level``, they take the GAN pass's update only
+            upd = conv_updates if li < lv else min(conv_updates, 1)
+            h, sv = bn.forward(raw, relu=True, updates=upd if train_stats else 0, stat_acc=conv.take_stats())
             raws.append(raw)
             svs.append(sv)
             acts.append(h)
         ctx = dict(x=x16, acts=acts, raws=raws, svs=svs)
         if not head:
-            return raws[2], None, ctx
-        return raws[2], self.forward_head(ctx, train_stats, fc_updates), ctx
+            return raws[lv - 1], None, ctx
+        return raws[lv - 1], self.forward_head(ctx, train_stats, fc_updates), ctx
 
     def forward_head(self, ctx, train_stats: bool = True, fc_updates: int = 1):
         """The 'GAN' head (flatten -> fc.0 -> BN1d -> ReLU -> fc.3, models/vae_gan.py:176-183) on the conv activations of
@@ -505,6 +516,12 @@ class DiscriminatorNet:
            Returns (dimg_A, dimg_B): cotangents w.r.t. input images ``img_rows`` (None if not requested)."""
         n3 = ctx["x"].shape[0]
         streams = []
+        top = 2                             # block whose raw output the cotangents enter at (index into convs / raws)
+        if dlogit16 is None and dfeat16 is not None:
+            top = self.level - 1             # a 'REC' call alone: the feature cotangent enters at block ``recon_level``
+        elif dfeat16 is not None and self.level != 3:
+            raise NotImplementedError("two cotangent streams through one discriminator pass (the fused steps) are "
+                                      "implemented for recon_level=3; other levels run through the module API")
         if dlogit16 is not None:
             if train:
                 self.fc3.wgrad(ctx["hfc"], dlogit16, scale_a)
@@ -526,7 +543,7 @@ class DiscriminatorNet:
         else:
             stack = None
         if dfeat16 is not None:
-            streams.append(dict(d=dfeat16.reshape(ctx["raws"][2].shape), scale=scale_b, train=train_b,
+            streams.append(dict(d=dfeat16.reshape(ctx["raws"][top].shape), scale=scale_b, train=train_b,
                                 img=img_streams[1]))
         S = len(streams)
         if S > 1 and stack is not None:
@@ -534,10 +551,8 @@ class DiscriminatorNet:
         else:
             d = torch.cat([s["d"] for s in streams], 0) if S > 1 else streams[0]["d"]
         rows = lambda t, i: t[i * n3:(i + 1) * n3]
-        # conv3 .. conv1
-        for li in (2, 1, 0):
-            if li < 2:   # BN+ReLU backward of block li+1 happened already for li == 2
-                pass
+        # conv3 .. conv1 (from block ``top`` down)
+        for li in range(top, -1, -1):
             for si, s in enumerate(streams):
                 if s["train"]:
                     self.convs[li].wgrad(ctx["acts"][li], rows(d, si), s["scale"])

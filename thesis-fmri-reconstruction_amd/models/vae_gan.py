@@ -220,8 +220,8 @@ class _DiscriminatorFn(Function):
         # re-used for other data in between; any in-place write changes ``_version`` and invalidates it.
         memo = mod.__dict__.get("_memo")
         key = (id(xo), xo._version, id(xp), xp._version, id(xs), xs._version, net.group.version, mod.training)
-        if (_REUSE and mode == "GAN" and memo is not None and memo["key"] == key and memo["xs"][0] is xo and memo["xs"][1] is xp
-                and memo["xs"][2] is xs):
+        if (_REUSE and mode == "GAN" and net.level == 3 and memo is not None and memo["key"] == key
+                and memo["xs"][0] is xo and memo["xs"][1] is xp and memo["xs"][2] is xs):
             sctx = dict(memo["sctx"])                 # own dict: the head's entries belong to this call
             mod.__dict__["_memo"] = None
             if mod.training:
@@ -234,7 +234,8 @@ class _DiscriminatorFn(Function):
             if mode == "REC":
                 feat, _, sctx = net.forward(d, conv_updates=1, head=False)
                 ctx.sctx = sctx
-                mod.__dict__["_memo"] = dict(key=key, xs=(xo, xp, xs), sctx=sctx)
+                # (recon_level < 3: the REC pass stopped below the last block, a GAN call starts over)
+                mod.__dict__["_memo"] = dict(key=key, xs=(xo, xp, xs), sctx=sctx) if net.level == 3 else None
                 return _ops.nhwc_to_images(feat, feat.shape[-1]).reshape(3 * B, -1)
             mod.__dict__["_memo"] = None
             _, logit32, sctx = net.forward(d, conv_updates=1, fc_updates=1)
@@ -269,7 +270,7 @@ class _DiscriminatorFn(Function):
         rows = slice(0, 3 * B) if want_img else None
         net.group.zero_grad()
         if ctx.mode == "REC":
-            feat = ctx.sctx["raws"][2]
+            feat = ctx.sctx["raws"][net.level - 1]
             n3, h, w, c_ = feat.shape
             f = _unit_scale(dout)
             dfeat16 = _ops.images_to_nhwc((dout * f).reshape(n3, c_, h, w).contiguous())

@@ -120,6 +120,16 @@ int fmri_igemm_ep(const void* in, const void* w, void* out, const float* bias, c
                   int Wi, int Ci, int Ho, int Wo, int CoStore, int Co, int k, int stride, int pad, int mode, int act,
                   int out_f32, int splits, int64_t slab_stride, int bn_tile, int64_t w_elems, const fmri_epilogue* ep,
                   int* ep_done, void* stream);
+/* Name of the kernel instantiation fmri_igemm_ep routes a call with these arguments to, e.g.
+ * "fmri::igemm_c5w_kernel<16,1>" ("none": nothing to launch).  The device pointers of fmri_igemm_ep are replaced by
+ * flags (has_bias; stat_rows_cap > 0: statistics epilogue asked with that row capacity / stat_group_n; want_bn_bwd,
+ * want_act_y, want_affine: the other fmri_epilogue fields set).  Pure host code -- no GPU is touched, it runs on a machine
+ * without one -- and the ONLY statement of the routing: profilers, benches and tests ask it instead of mirroring the
+ * rules.  name_out receives at most cap - 1 characters. */
+int fmri_igemm_route(int N, int Hi, int Wi, int Ci, int Ho, int Wo, int CoStore, int Co, int k, int stride, int pad,
+                     int mode, int act, int out_f32, int splits, int bn_tile, int64_t w_elems, int has_bias,
+                     int stat_rows_cap, int stat_group_n, int want_bn_bwd, int want_act_y, int want_affine, char* name_out,
+                     int cap);
 /* dW[a][tap*Bc+b] (+)= sum_m P[m][a] * Q[gather(m,tap)][b]; see csrc/wgrad.hip.  Replaces the weight
  * gradients autograd computes for the same modules (train/train_vgan_stage1.py:412,422,430). */
 int fmri_wgrad(const void* P, const void* Q, float* out, const void* zero16, int N, int Yc, int Xc, int A, int Hq,

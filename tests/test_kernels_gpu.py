@@ -124,14 +124,15 @@ C5_CASES = [
 def test_conv_stride2_window_kernel(cin, cout, H, W, N):
     """csrc/igemm_c5.hip (window-resident stride-2 convolution) against the fp32 convolution, and against the tap-list
     kernel it replaces (FMRI_C5 is read once per process, so that comparison goes through the label only)."""
-    from fmri_hip.ops import ConvLayer, ACT_NONE, igemm_kernel_label, MODE_CONV
+    from fmri_hip.ops import ConvLayer, ACT_NONE, igemm_route, MODE_CONV
     torch.manual_seed(cin * 7 + cout + H * 3 + W + N)
     w = _h(torch.randn(cout, cin, 5, 5) * 0.05)
     x = _h(torch.randn(N, cin, H, W))
     g = _G({"w": w})
     layer = ConvLayer(g, "w", None, "conv", cin, cout, 5, 2, 2)
     Ho, Wo = layer.out_hw(H, W)
-    assert "igemm_c5" in igemm_kernel_label(N, H, W, cin, Ho, Wo, cout, cout, 5, 2, 2, MODE_CONV, False, 1, 128)
+    assert "igemm_c5" in igemm_route(N, H, W, cin, Ho, Wo, cout, cout, 5, 2, 2, MODE_CONV, ACT_NONE, False, 1, 128,
+                                     layer.pw_f.buf.numel())
     y16 = layer.forward(_nhwc16(x), ACT_NONE)
     ref = F.conv2d(x, w, None, 2, 2)
     _close(_from_nhwc(y16, cout), ref, "conv s2 (window kernel)")
@@ -712,18 +713,27 @@ def test_optimizers_match_torch():
     assert torch.allclose(pd.cpu(), pt.detach(), rtol=2e-6, atol=1e-7)
 
 
-@pytest.mark.parametrize("route", ["all", "off"])
+ROUTE_VARIANTS = {
+    # the round-2 kernels behind the 8-wave loader / compute forms (they still own the 64-channel tiles, the
+    # BatchNorm-backward epilogue and the statistics groups the wide forms decline)
+    "narrower": dict(FMRI_C5W="off", FMRI_TC5W="off"),
+    # every specialised kernel off: the tap-list kernel (csrc/igemm.hip) takes all geometries
+    "generic": dict(FMRI_C5="off", FMRI_TC5="off", FMRI_TC32="off", FMRI_NARROW="off"),
+}
+
+
+@pytest.mark.parametrize("route", sorted(ROUTE_VARIANTS))
 def test_igemm_routing_variants(route):
-    """The patch-resident kernel is routed by default only to the stride-1 convolutions; FMRI_PATCH=all sends every
-    eligible geometry (transposed-conv parity classes too) through it and FMRI_PATCH=off none.  The routing is read
-    once per process, so the conv / deconv parity cases are re-run in a child process for both settings."""
+    """Every geometry has a second kernel behind the one the default routing picks (fmri_igemm_ep falls through to it when
+    the first declines): the conv / deconv parity cases are re-run with the first choice switched off.  The switches are
+    read once per process, hence the child process."""
     import os
     import subprocess
     import sys
-    env = dict(os.environ, FMRI_PATCH=route)
+    env = dict(os.environ, **ROUTE_VARIANTS[route])
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k",
                         "conv_forward or deconv_forward or epilogues", "-p", "no:cacheprovider"],
-                       env=env, capture_output=True, text=True, timeout=600,
+                       env=env, capture_output=True, text=True, timeout=900,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 

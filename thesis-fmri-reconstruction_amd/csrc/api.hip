@@ -2,6 +2,8 @@
 // Host-side geometry derivation + argument validation; all device work is enqueued on the caller's stream.
 #include "../../include/fmri_hip.h"
 #include "kernels.h"
+#include <stdarg.h>
+#include <stdio.h>
 #include <string.h>
 #include <cstdlib>
 
@@ -31,6 +33,22 @@ void tconv_classes(int k, int pad, int ci, int rows_pad, TClass out[4]) {
         }
 }
 }  // namespace
+
+// ---- routing probe (kernels.h): thread-local, so that fmri_igemm_route is re-entrant like every other entry point
+namespace {
+thread_local bool t_probe_on = false;
+thread_local char t_probe_name[128];
+}  // namespace
+namespace fmri {
+bool route_probe(const char* fmt, ...) {
+    if (!t_probe_on) return false;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(t_probe_name, sizeof(t_probe_name), fmt, ap);
+    va_end(ap);
+    return true;
+}
+}  // namespace fmri
 
 extern "C" {
 
@@ -158,6 +176,37 @@ int fmri_igemm(const void* in, const void* w, void* out, const float* bias, cons
                int out_f32, int splits, int64_t slab_stride, int bn_tile, void* stream) {
     return fmri_igemm_ep(in, w, out, bias, zero16, N, Hi, Wi, Ci, Ho, Wo, CoStore, Co, k, stride, pad, mode, act, out_f32,
                          splits, slab_stride, bn_tile, 0, nullptr, nullptr, stream);
+}
+
+int fmri_igemm_route(int N, int Hi, int Wi, int Ci, int Ho, int Wo, int CoStore, int Co, int k, int stride, int pad,
+                     int mode, int act, int out_f32, int splits, int bn_tile, int64_t w_elems, int has_bias,
+                     int stat_rows_cap, int stat_group_n, int want_bn_bwd, int want_act_y, int want_affine, char* name_out,
+                     int cap) {
+    if (!name_out || cap < 2) return FMRI_E_BADARG;
+    name_out[0] = 0;
+    // the routing decisions read sizes, flags and NULL-ness only: every pointer is a non-NULL dummy that is never
+    // dereferenced, every launcher stops at route_probe()
+    void* const dummy = (void*)(uintptr_t)64;
+    fmri_epilogue e;
+    memset(&e, 0, sizeof(e));
+    if (stat_rows_cap > 0) { e.stat_part = (float*)dummy; e.stat_rows_cap = stat_rows_cap; e.stat_group_n = stat_group_n; }
+    if (want_bn_bwd) {
+        e.bn_x = dummy; e.bn_gamma = (const float*)dummy; e.bn_beta = (const float*)dummy; e.bn_relu = 1;
+        for (int i = 0; i < 4; ++i) { e.bn_mean[i] = (const float*)dummy; e.bn_rstd[i] = (const float*)dummy; }
+    }
+    if (want_act_y) e.act_y = dummy;
+    if (want_affine) { e.aff_scale = (const float*)dummy; e.aff_shift = (const float*)dummy; }
+    const bool any_ep = stat_rows_cap > 0 || want_bn_bwd || want_act_y || want_affine;
+    int done = 0;
+    t_probe_name[0] = 0;
+    t_probe_on = true;
+    const int r = fmri_igemm_ep(dummy, dummy, dummy, has_bias ? (const float*)dummy : nullptr, dummy, N, Hi, Wi, Ci, Ho, Wo,
+                                CoStore, Co, k, stride, pad, mode, act, out_f32, splits, 0, bn_tile, w_elems,
+                                any_ep ? &e : nullptr, &done, nullptr);
+    t_probe_on = false;
+    if (r != FMRI_OK) return r;
+    snprintf(name_out, (size_t)cap, "%s", t_probe_name[0] ? t_probe_name : "none");
+    return FMRI_OK;
 }
 
 int fmri_igemm_ep(const void* in, const void* w, void* out, const float* bias, const void* zero16, int N, int Hi,
@@ -295,11 +344,9 @@ int fmri_igemm_ep(const void* in, const void* w, void* out, const float* bias, c
         q.fdTPI = make_fastdiv((uint32_t)(q.tiles_y * q.tiles_x));
         q.fdTX = make_fastdiv((uint32_t)q.tiles_x);
         q.st = se;
-        // persistent blocks: tpb consecutive tiles each when that makes whole rounds of 2 blocks per CU (FMRI_C5_TPB overrides)
-        static const char* tpb_env = getenv("FMRI_C5_TPB");
-        static const int tpb_force = tpb_env ? atoi(tpb_env) : 0;
+        // persistent blocks: tpb consecutive tiles each when that makes whole rounds of 2 blocks per CU
         const int ncol = copad / 128;
-        q.tpb = tpb_force > 0 ? tpb_force : (q.ntiles * ncol) / 512;      // whole rounds only: fewer, longer blocks leave CUs idle
+        q.tpb = (q.ntiles * ncol) / 512;      // whole rounds only: fewer, longer blocks leave CUs idle
         if (q.tpb < 1) q.tpb = 1;
         // statistics: one row per block; statistics groups must not share a tile, nor a block
         const int tpg5 = se.group_n > 0 ? (se.group_n / ipb) * q.tiles_y * q.tiles_x : q.ntiles;
@@ -318,12 +365,11 @@ int fmri_igemm_ep(const void* in, const void* w, void* out, const float* bias, c
         // CU, loader / compute waves; FMRI_C5W=off disables
         static const char* c5w_env = getenv("FMRI_C5W");
         static const bool no_c5w = c5w_env && !strcmp(c5w_env, "off");
-        static const bool no_c5w8 = c5w_env && !strcmp(c5w_env, "16");          // FMRI_C5W=16: the 16-wide form only
         const int ipbw = q.pw16 ? 1 : 4;
         // (gated on the caller's REQUEST for the BatchNorm-backward epilogue, bb.x: the wide kernel has none, and q.bb.x is
         // also cleared when the narrow form's rows did not fit -- the wide form, needing fewer rows, would then emit
         // FORWARD statistics rows that the caller reads as (sum g, sum g*xhat))
-        if (!no_c5w && !(no_c5w8 && !q.pw16) && !bb.x && (q.pw16 ? Ho > 8 : true) &&
+        if (!no_c5w && !bb.x && (q.pw16 ? Ho > 8 : true) &&
             !(se.part && se.group_n > 0 && (se.group_n % ipbw))) {
             C5Args w = q;
             const int ph = q.pw16 ? 16 : 8;
@@ -336,7 +382,6 @@ int fmri_igemm_ep(const void* in, const void* w, void* out, const float* bias, c
             w.tpb = 1;
             for (int t = (w.ntiles * ncol) / 256; t > 1; --t)
                 if (tpgw % t == 0 && w.ntiles % t == 0 && ((w.ntiles / t) * ncol) % 256 == 0) { w.tpb = t; break; }
-            if (tpb_force > 0 && tpgw % tpb_force == 0) w.tpb = tpb_force;
             if (se.part) {
                 w.st.tpg[0] = (tpgw + w.tpb - 1) / w.tpb;
                 if (w.st.tpg[0] > se.rows_cap) w.st.part = nullptr;
@@ -386,9 +431,7 @@ int fmri_igemm_ep(const void* in, const void* w, void* out, const float* bias, c
         q.ntiles = Yc0 > 0 && Xc0 > 0 ? ((N + q.IPB - 1) / q.IPB) * q.tiles_y * q.tiles_x : 0;
         q.nslice = (q.IPB * q.IH * q.IW * 8 + 255) / 256;
         // whole class grid (and input) inside one 8 x 8 tile per image: the window's halo is all padding -> dense form
-        static const char* dense_env = getenv("FMRI_TC5_DENSE");
-        static const bool no_dense = dense_env && !strcmp(dense_env, "off");
-        if (!no_dense && q.IPB == 2 && q.tiles_x == 1 && q.tiles_y == 1 && Hi <= 8 && Wi <= 8) q.nslice = 4;
+        if (q.IPB == 2 && q.tiles_x == 1 && q.tiles_y == 1 && Hi <= 8 && Wi <= 8) q.nslice = 4;
         q.in_bytes = (uint32_t)((int64_t)N * Hi * Wi * Ci * 2);
         q.w_bytes = (uint32_t)(w_elems * 2);
         q.fdTPI = make_fastdiv((uint32_t)(q.tiles_y * q.tiles_x));
@@ -428,10 +471,8 @@ int fmri_igemm_ep(const void* in, const void* w, void* out, const float* bias, c
             w.fdTPI = make_fastdiv((uint32_t)(w.tiles_y * w.tiles_x));
             w.fdTX = make_fastdiv((uint32_t)w.tiles_x);
             w.st = se;
-            // few tiles: one parity class per block (FMRI_TC5W_SOLO=<max tiles x column blocks>, default 128)
-            static const char* solo_env = getenv("FMRI_TC5W_SOLO");
-            static const int solo_max = solo_env ? atoi(solo_env) : 128;
-            w.solo = w.ntiles * (copad / 128) <= solo_max ? 1 : 0;
+            // few tiles (at most 128 tile x column-block pairs): one parity class per block, grid.z = 4
+            w.solo = w.ntiles * (copad / 128) <= 128 ? 1 : 0;
             w.pad_solo = 0;
             if (se.part) {
                 w.st.tpg[0] = (se.group_n > 0 ? (se.group_n / w.IPB) * w.tiles_y * w.tiles_x : w.ntiles) * (w.solo ? 4 : 1);
@@ -483,108 +524,6 @@ int fmri_igemm_ep(const void* in, const void* w, void* out, const float* bias, c
             if (r != E_UNSUPPORTED) return r;
         }
     }
-    // unit-stride sampling, Ci % 64 == 0 -> window-resident kernel (csrc/igemm_win.hip); FMRI_WIN=off disables
-    static const char* win_env = getenv("FMRI_WIN");
-    static const bool no_win = win_env && !strcmp(win_env, "off");
-    const bool unit_any = mode == FMRI_TCONV2 || mode == FMRI_CONV_FLIP || (mode == FMRI_CONV && stride == 1);
-    if (!no_win && unit_any && bn_tile >= 64 && !out_f32 && splits == 1 && k >= 2 && k <= 5 && Hi * Wi > 1 && (Ci & 63) == 0 &&
-        (int64_t)N * Hi * Wi * Ci < 0x7fffffffLL) {
-        WinArgs p;
-        p.in = a.in; p.w = a.w; p.out = (half_t*)out; p.bias = bias; p.zero = a.zero;
-        p.N = N; p.Hi = Hi; p.Wi = Wi; p.Ci = Ci; p.Ho = Ho; p.Wo = Wo; p.CoStore = CoStore; p.Co = Co;
-        p.os = a.os; p.act = act; p.ncls = a.ncls;
-        p.nchunks = Ci / 64;
-        p.pbufs = 1;
-        int max_tiles = 0, max_slices = 0;
-        bool ok = true;
-        for (int i = 0; i < a.ncls; ++i) {
-            const IgemmClass& s = a.cls[i];
-            WinClass& d = p.cls[i];
-            d.Yc = s.Yc; d.Xc = s.Xc; d.oy0 = s.oy0; d.ox0 = s.ox0; d.T = s.T; d.TW = s.TW;
-            d.dy0 = s.dy0; d.dx0 = s.dx0; d.dstep = s.dstep; d.Kpad = s.Kpad; d.w_off = s.w_off; d.pad0 = 0;
-            const int TH = s.T / s.TW;
-            const int ey = (TH - 1) * s.dstep, ex = (s.TW - 1) * s.dstep;
-            d.dymin = s.dy0 + (ey < 0 ? ey : 0);
-            d.dxmin = s.dx0 + (ex < 0 ? ex : 0);
-            d.pw_log2 = s.Xc > 8 ? 4 : 3;
-            d.ph_log2 = (d.pw_log2 == 3 && s.Yc > 8) ? 4 : 3;
-            d.PH = 1 << d.ph_log2;
-            d.IPB = 128 >> (d.pw_log2 + d.ph_log2);
-            d.IH = d.PH + (TH - 1);
-            d.IW = (1 << d.pw_log2) + (s.TW - 1);
-            d.tiles_x = (s.Xc + (1 << d.pw_log2) - 1) >> d.pw_log2;
-            d.tiles_y = (s.Yc + d.PH - 1) >> d.ph_log2;
-            d.ntiles = s.M > 0 ? ((N + d.IPB - 1) / d.IPB) * d.tiles_y * d.tiles_x : 0;
-            d.nslice = (d.IPB * d.IH * d.IW * 8 + 255) / 256;
-            d.spt = (d.nslice + s.T - 1) / s.T;
-            d.fdTPI = make_fastdiv((uint32_t)(d.tiles_y * d.tiles_x));
-            d.fdTX = make_fastdiv((uint32_t)d.tiles_x);
-            d.fdIHW = make_fastdiv((uint32_t)(d.IH * d.IW));
-            d.fdIW = make_fastdiv((uint32_t)d.IW);
-            if (d.nslice > 8 || d.spt > 2) ok = false;
-            if (d.nslice > max_slices) max_slices = d.nslice;
-            if (d.ntiles > max_tiles) max_tiles = d.ntiles;
-        }
-        for (int i = a.ncls; i < 4; ++i) p.cls[i] = p.cls[0];
-        p.win_bytes = max_slices * 4096;
-        if (ok && max_tiles > 0) {
-            const int r = igemm_win_launch(p, max_tiles, bn_tile, copad, S(stream));
-            if (r != E_UNSUPPORTED) return r;
-        }
-    }
-    // unit-stride sampling with a spatial extent -> patch-resident kernel (csrc/igemm_patch.hip)
-    // Measured at the B=256 Stage-I shapes (tools/microbench_igemm.py): the patch kernel wins on the stride-1
-    // (single class, 25 tap) convolutions and loses on the short-K parity classes of the transposed convolutions,
-    // so only the former are routed to it by default.  FMRI_PATCH=all routes every eligible geometry (tests),
-    // FMRI_PATCH=off none.
-    static const char* patch_env = getenv("FMRI_PATCH");
-    static const bool no_patch = patch_env && !strcmp(patch_env, "off");
-    static const bool all_patch = patch_env && !strcmp(patch_env, "all");
-    const bool unit = all_patch ? (mode == FMRI_TCONV2 || mode == FMRI_CONV_FLIP || (mode == FMRI_CONV && stride == 1))
-                                : ((mode == FMRI_CONV_FLIP || mode == FMRI_CONV) && stride == 1);
-    if (!no_patch && unit && !out_f32 && splits == 1 && k >= 2 && k <= 5 && Hi * Wi > 1 &&
-        (Ci == 8 || Ci == 32 || (Ci & 63) == 0) && (int64_t)N * Hi * Wi * Ci < 0x7fffffffLL) {
-        PatchArgs p;
-        p.in = a.in; p.w = a.w; p.out = (half_t*)out; p.bias = bias; p.zero = a.zero;
-        p.N = N; p.Hi = Hi; p.Wi = Wi; p.Ci = Ci; p.Ho = Ho; p.Wo = Wo; p.CoStore = CoStore; p.Co = Co;
-        p.os = a.os; p.act = act; p.ncls = a.ncls;
-        const int CK = Ci >= 64 ? 64 : Ci;
-        p.cpp_log2 = CK == 64 ? 3 : (CK == 32 ? 2 : 0);
-        p.nchunks = Ci / CK;
-        p.pbufs = p.nchunks > 1 ? 2 : 1;
-        int max_tiles = 0, max_ent = 0;
-        bool ok = true;
-        for (int i = 0; i < a.ncls; ++i) {
-            const IgemmClass& s = a.cls[i];
-            PatchClass& d = p.cls[i];
-            d.Yc = s.Yc; d.Xc = s.Xc; d.oy0 = s.oy0; d.ox0 = s.ox0; d.T = s.T; d.TW = s.TW;
-            d.dy0 = s.dy0; d.dx0 = s.dx0; d.dstep = s.dstep; d.Kpad = s.Kpad; d.w_off = s.w_off;
-            const int TH = s.T / s.TW;
-            const int ey = (TH - 1) * s.dstep, ex = (s.TW - 1) * s.dstep;
-            d.dymin = s.dy0 + (ey < 0 ? ey : 0);
-            d.dxmin = s.dx0 + (ex < 0 ? ex : 0);
-            d.pw_log2 = s.Xc > 8 ? 4 : 3;
-            d.PH = s.Yc > 8 ? 16 : 8;
-            d.IPB = 256 / (d.PH << d.pw_log2);
-            d.IH = d.PH + (TH - 1);
-            d.IW = (1 << d.pw_log2) + (s.TW - 1);
-            d.tiles_x = (s.Xc + (1 << d.pw_log2) - 1) >> d.pw_log2;
-            d.tiles_y = (s.Yc + d.PH - 1) / d.PH;
-            d.ntiles = s.M > 0 ? ((N + d.IPB - 1) / d.IPB) * d.tiles_y * d.tiles_x : 0;
-            const int chunks = (d.IPB * d.IH * d.IW) << p.cpp_log2;
-            const int nent = (chunks + 511) / 512;
-            if (nent > 7 || s.T > 31) ok = false;
-            if (chunks > max_ent) max_ent = chunks;
-            if (d.ntiles > max_tiles) max_tiles = d.ntiles;
-        }
-        for (int i = a.ncls; i < 4; ++i) p.cls[i] = p.cls[0];
-        p.patch_bytes = pad_to(max_ent * 16, 1024);
-        p.wstages = 0; p.pad0 = 0;
-        if (ok && max_tiles > 0) {
-            const int r = igemm_patch_launch(p, max_tiles, bn_tile, copad, S(stream));
-            if (r != E_UNSUPPORTED) return r;
-        }
-    }
     // generic kernel: statistics epilogue (one row per row tile) when no tile straddles two statistics groups
     a.st = se;
     int prows = 0;
@@ -609,18 +548,15 @@ int fmri_igemm_ep(const void* in, const void* w, void* out, const float* bias, c
 // K pieces (8 x 8 pixel tiles per block) of the four parity planes of fmri_wgrad's window kernel for a budget of `splits`
 // blocks per (row block, column block) over the planes.  A K-step costs ~128 cycles per shift of the plane (8 MFMAs of one
 // wave) + ~550 of barrier, fragment reads and waits (csrc/wgrad_win.hip, measured 1 825 / 1 430 / 1 033 cycles at 9 / 6 / 4
-// shifts), so the planes get pieces in inverse proportion: all blocks of a launch finish together.  FMRI_WW_EQUAL=1: the
-// same pieces for every plane (round 2).  Returns the number of pieces of the plane with the most (= slabs written).
+// shifts), so the planes get pieces in inverse proportion: all blocks of a launch finish together.  Returns the number of pieces of the plane with the most (= slabs written).
 static int wgrad_plane_pieces(int N, int Yc, int Xc, int k, int pad, int splits, int tps_out[4]) {
     const int ntiles = N * ((Yc + 7) / 8) * ((Xc + 7) / 8);
     int nsh[2] = {0, 0};
     for (int t = 0; t < k; ++t) ++nsh[(t - pad) & 1];
     int total = splits < 4 ? 4 : splits;
     total -= total & 3;
-    static const char* eq_env = getenv("FMRI_WW_EQUAL");
-    static const bool equal = eq_env && !strcmp(eq_env, "1");
     double cost[4], csum = 0;
-    for (int pl = 0; pl < 4; ++pl) { cost[pl] = equal ? 1.0 : 128.0 * nsh[pl >> 1] * nsh[pl & 1] + 550.0; csum += cost[pl]; }
+    for (int pl = 0; pl < 4; ++pl) { cost[pl] = 128.0 * nsh[pl >> 1] * nsh[pl & 1] + 550.0; csum += cost[pl]; }
     int smax = 1;
     for (int pl = 0; pl < 4; ++pl) {
         int sp = (int)(total * cost[pl] / csum + 0.5);

@@ -144,60 +144,6 @@ struct IgemmArgs {
     IgemmClass cls[4];
 };
 
-// patch-resident implicit GEMM (igemm_patch.hip): unit-stride sampling only
-struct PatchClass {
-    int32_t Yc, Xc, oy0, ox0;
-    int32_t T, TW, dy0, dx0, dstep;
-    int32_t pw_log2, PH, IPB;           // tile: PW = 1 << pw_log2, PW * PH * IPB == 256 output pixels
-    int32_t tiles_x, tiles_y, ntiles;   // tiles per image (x, y); ntiles = ceil(N/IPB) * tiles_y * tiles_x
-    int32_t IH, IW, dymin, dxmin;       // input patch rows / cols and origin offset
-    int32_t Kpad;
-    int64_t w_off;
-};
-
-struct PatchArgs {
-    const half_t* in;
-    const half_t* w;
-    half_t* out;
-    const float* bias;
-    const half_t* zero;
-    int32_t N, Hi, Wi, Ci;
-    int32_t Ho, Wo, CoStore, Co;
-    int32_t os, act, ncls;
-    int32_t cpp_log2, nchunks;   // log2(channels per chunk / 8) in {0, 2, 3}; Ci / 64 (1 if Ci <= 64)
-    int32_t patch_bytes, pbufs;  // bytes of one LDS patch buffer (multiple of 1024); 1 or 2 buffers
-    int32_t wstages, pad0;       // weight ring depth (3 or 4), set by igemm_patch_launch
-    PatchClass cls[4];
-};
-
-// window-resident implicit GEMM (igemm_win.hip): unit-stride sampling, Ci % 64 == 0, 128 output pixels per block
-struct WinClass {
-    int32_t Yc, Xc, oy0, ox0;
-    int32_t T, TW, dy0, dx0, dstep;
-    int32_t pw_log2, ph_log2, PH, IPB;  // window: PW = 1 << pw_log2, PH = 1 << ph_log2, PW * PH * IPB == 128
-    int32_t tiles_x, tiles_y, ntiles;   // windows per image (x, y); ntiles = ceil(N/IPB) * tiles_y * tiles_x
-    int32_t IH, IW, dymin, dxmin;       // input window rows / cols and origin offset
-    int32_t Kpad;
-    int32_t nslice, spt;                // 4 KB DMA slices per window; slices issued per tap (<= 2)
-    int32_t pad0;
-    int64_t w_off;
-    FastDiv fdTPI, fdTX, fdIHW, fdIW;
-};
-
-struct WinArgs {
-    const half_t* in;
-    const half_t* w;
-    half_t* out;
-    const float* bias;
-    const half_t* zero;
-    int32_t N, Hi, Wi, Ci;
-    int32_t Ho, Wo, CoStore, Co;
-    int32_t os, act, ncls;
-    int32_t nchunks;             // Ci / 64
-    int32_t win_bytes, pbufs;    // bytes of one LDS window buffer (multiple of 4096); 1 or 2 buffers (set at launch)
-    WinClass cls[4];
-};
-
 // all four parity classes of a k5 s2 p2 transposed convolution per block (igemm_tc5.hip)
 struct Tc5Class {
     int32_t Yc, Xc;        // class output grid: class (cy, cx) writes output pixel (2y + cy, 2x + cx)

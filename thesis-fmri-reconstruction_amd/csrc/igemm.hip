@@ -333,6 +333,8 @@ static int launch_bn(const IgemmArgs& a, int maxM, int copad, bool out_f32, hipS
     const int lds = 2 * (BM * 128 + BN * 128);
     // fp32-slab output is used for split-K / fp32 consumers; UNI = K-steps never straddle taps
     const bool uni = (a.Ci & 63) == 0;
+    if (route_probe("fmri::igemm_kernel<%d,%d,%d,%d,%s,%s>", BM, BN, WM, WN, out_f32 ? "true" : "false", uni ? "true" : "false"))
+        return OK;
     auto go = [&](auto kern) {
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipLaunchKernelGGL(kern, grid, dim3(NT), lds, st, a);

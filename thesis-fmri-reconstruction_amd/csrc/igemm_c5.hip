@@ -26,20 +26,6 @@
 
 namespace fmri {
 
-#ifdef FMRI_STAMP
-// Diagnostic build only (tools/probes/c5_stamps.py; never shipped): where a wave's cycles go inside a K-step.
-// [0] sync (counted vmcnt + lgkmcnt(0) + s_barrier), [1] DMA issue (weights + window slices), [2] fragment reads + MFMA
-// issue, [3] epilogue, [4] steps, [5] waves
-__device__ unsigned long long c5_stamp_acc[8];
-#define FMRI_STAMP_AT(v)                                                                     \
-    do {                                                                                     \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory");            \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-    } while (0)
-#else
-#define FMRI_STAMP_AT(v) do { } while (0)
-#endif
 
 namespace {
 
@@ -199,9 +185,6 @@ __global__ __launch_bounds__(256, 2) void igemm_c5_kernel(const C5Args a) {
 
     const int wm = wave >> 1, wn = wave & 1;
     const int frow = lane & 15, fq = lane >> 4;
-#ifdef FMRI_STAMP
-    unsigned long long st_sync = 0, st_dma = 0, st_comp = 0, st_epi = 0, st_steps = 0;
-#endif
 
     // ---- A fragment addresses: abase[kx][tm] for window row shift 0; row shift sy adds the immediate sy * ROW * 64
     uint32_t abase[5][TM];
@@ -281,10 +264,6 @@ __global__ __launch_bounds__(256, 2) void igemm_c5_kernel(const C5Args a) {
             // window slices issued behind the weight tiles of the PREVIOUS step
             constexpr int prev_n = (t >= 1 && t <= 6) ? 1 : ((t == 9 || t == 10) ? 2 : ((t == 11 || t == 12) ? 1 : 0));
             constexpr bool prev_cond = t >= 9;             // ... only when another (tile, sub-chunk) follows
-#ifdef FMRI_STAMP
-            unsigned long long ta, tb, tc, td;
-            FMRI_STAMP_AT(ta);
-#endif
             if constexpr (t == 0) { if (!landed) wait_vmc<0>(); }
             else if constexpr (prev_n == 0) wait_vmc<0>();
             else if constexpr (prev_cond) { if (more) wait_vmc<prev_n>(); else wait_vmc<0>(); }
@@ -292,9 +271,6 @@ __global__ __launch_bounds__(256, 2) void igemm_c5_kernel(const C5Args a) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-#ifdef FMRI_STAMP
-            FMRI_STAMP_AT(tb);
-#endif
             // next step's weight tiles
             if constexpr (t < 12) load_w(std::integral_constant<int, stg ^ 1>{}, std::integral_constant<int, 2 * t + 2>{}, sub);
             else if (more) load_w(std::integral_constant<int, stg ^ 1>{}, std::integral_constant<int, 0>{}, nsubi);
@@ -313,14 +289,7 @@ __global__ __launch_bounds__(256, 2) void igemm_c5_kernel(const C5Args a) {
                     load_slices(std::integral_constant<int, 0>{}, nsubi, std::integral_constant<int, t - 6>{},
                                 std::integral_constant<int, t - 5>{});
             }
-#ifdef FMRI_STAMP
-            FMRI_STAMP_AT(tc);
-#endif
             compute(std::integral_constant<int, 2 * t>{}, std::integral_constant<int, stg>{});
-#ifdef FMRI_STAMP
-            FMRI_STAMP_AT(td);
-            st_sync += tb - ta; st_dma += tc - tb; st_comp += td - tc; st_steps += 1;
-#endif
         });
     };
 
@@ -407,15 +376,7 @@ __global__ __launch_bounds__(256, 2) void igemm_c5_kernel(const C5Args a) {
         landed = false;
         if (last_sub) {
             if (next_tile) { wait_vmc<0>(); landed = true; }     // the next tile's first window and weights
-#ifdef FMRI_STAMP
-            unsigned long long te0, te1;
-            FMRI_STAMP_AT(te0);
-#endif
             epilogue();
-#ifdef FMRI_STAMP
-            FMRI_STAMP_AT(te1);
-            st_epi += te1 - te0;
-#endif
 #pragma unroll
             for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -430,12 +391,6 @@ __global__ __launch_bounds__(256, 2) void igemm_c5_kernel(const C5Args a) {
         one(std::integral_constant<int, 0>{});
         if (tile < tile1) one(std::integral_constant<int, 1>{});
     }
-#ifdef FMRI_STAMP
-    if (lane == 0) {
-        atomicAdd(&c5_stamp_acc[0], st_sync); atomicAdd(&c5_stamp_acc[1], st_dma); atomicAdd(&c5_stamp_acc[2], st_comp);
-        atomicAdd(&c5_stamp_acc[3], st_epi); atomicAdd(&c5_stamp_acc[4], st_steps); atomicAdd(&c5_stamp_acc[5], 1ull);
-    }
-#endif
     if constexpr (STATS != 0) {
         // one row per block; the blocks of one statistics group are contiguous (tpg[0] = blocks per group)
         const int prow = bx - sgrp * a.st.tpg[0];
@@ -449,6 +404,7 @@ static int launch_c5(const C5Args& a, int copad, hipStream_t st) {
     auto kern = igemm_c5_kernel<PW, STATS>;
     constexpr int lds = 2 * 6 * 4096 + 2 * 16384;
     static_assert(lds <= 80 * 1024, "two blocks per CU");
+    if (route_probe("fmri::igemm_c5_kernel<%d,%d>", PW, STATS)) return OK;
     // raising the dynamic-LDS limit is idempotent; every call sets it (no library-global state)
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return E_LAUNCH;
@@ -467,15 +423,5 @@ int igemm_c5_launch(const C5Args& a, int copad, hipStream_t st) {
     return a.bb.x ? launch_c5<8, 2>(a, copad, st) : launch_c5<8, 1>(a, copad, st);
 }
 
-#ifdef FMRI_STAMP
-extern "C" int fmri_debug_c5_stamps(unsigned long long* out8, int reset) {
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(c5_stamp_acc), 64) != hipSuccess) return -1;
-    if (reset) {
-        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(c5_stamp_acc), z, 64) != hipSuccess) return -1;
-    }
-    return 0;
-}
-#endif
 
 }  // namespace fmri

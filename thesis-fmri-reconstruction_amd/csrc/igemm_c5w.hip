@@ -1,54 +1,36 @@
-// Stride-2 convolution (k5 p2) with >= 128 input channels on MFMA (gfx950), WIDE form of igemm_c5.hip: one 4-wave block
-// per CU owns 16 x 16 output pixels x 128 channels (wave tile 128 pixels x 64 channels) and its K-step is pipelined by hand.
+// Stride-2 convolution (k5 p2), Ci % 32 == 0, on MFMA (gfx950): WIDE form of igemm_c5.hip.  One 8-WAVE block owns a CU:
+// waves 4-7 LOAD (window slices and weight tiles by buffer_load ... lds with counted vmcnt, the tile arithmetic, the
+// output stores and the BatchNorm statistics of the stored values), waves 0-3 COMPUTE (fragment reads and MFMAs only);
+// one s_barrier per K-step joins the two roles.  A block's tile is 16 x 16 output pixels of one image (PW = 16) or
+// 8 x 8 pixels of four images (PW = 8) x 128 output channels; blocks are persistent over whole rounds of tiles.
 //
-// Replaces (reference models/vae_gan.py): the forward of discriminator.conv.2 (:149-153) and the data gradient of
-// decoder.conv.1 (:112-116 -- a stride-2 convolution of the 128-channel cotangent), i.e. the Ci >= 128, Wo >= 16
-// launches of igemm_c5.hip.
+// Replaces (reference models/vae_gan.py): every Conv2d(k5, s2, p2) forward with >= 32 input channels -- encoder.conv.1/2
+// (:73-78), discriminator.conv.1/2/3 (:149-153) -- and every ConvTranspose2d(k5, s2, p2) data gradient (a stride-2
+// convolution of the cotangent): decoder.conv.0/1/2 (:112-116).  Declines what needs igemm_c5.hip: the
+// BatchNorm-backward epilogue, statistics groups that would share a four-image tile, Wo > 8 with Ho <= 8.
 //
-// Why (round 3): igemm_c5 with ONE of its two blocks per CU resident still delivers 76 % of its
-// throughput -- a lone wave per SIMD runs the K-step in ~1 500 cycles of which 512 are its MFMAs, the rest is the
-// step's fixed chain (barrier, operand DMA round trip, fragment-read latency), and the second resident block only adds
-// 30 %.  Here the fixed chain is paid per 64 MFMAs instead of 32: the wave tile is 8 x 4 MFMA tiles (0.375 LDS fragment
-// reads per MFMA instead of 0.5; 22 KB of operand DMA per 256 MFMAs of the block instead of 20 KB per 128), and the
-// wave's own instruction stream keeps the matrix pipe fed across the chain:
-//   * the second tap slot of step t - 1 stays PENDING (fragments in registers); its 32 MFMAs run right behind the
-//     barrier of step t with the step's six DMA instructions issued one by one between them and the first slot's 12
-//     fragment reads in front (they land under those MFMAs); then the first slot's 32 MFMAs with the second slot's
-//     reads between them;
-//   * one block per CU: 512 registers per lane (no pressure from the 128 accumulators), 112 KB of LDS (two 40 KB phase
-//     windows of (16 + 2) x 35 pixels x 32 channels, 2 x 16 KB weight ring).
+// Why (round 3): one wave per SIMD is ISSUE-bound -- ~60 cycles of a wave's instruction stream per
+// LDS-DMA instruction, and nothing else on the SIMD to fill them; a finished tile's 64 KB of stores stalled the wave
+// that multiplies.  With the roles split
+//   * the compute wave's tile is 8 x 4 MFMA tiles (128 pixels x 64 channels: 0.375 ds_read_b128 per MFMA, 64 MFMAs per
+//     K-step = two taps x 32 channels); the second tap slot of step t - 1 stays PENDING in registers and its 32 MFMAs
+//     run right behind the barrier of step t, covering the first slot's 12 fragment reads; reads are interleaved one
+//     per two MFMAs in both halves (sched_group_barrier);
+//   * a finished tile goes to the loader waves as fp16 through a 32 KB LDS staging area in two rounds; they store it
+//     (256 contiguous bytes per pixel, one or two buffer_store_dwordx4 per K-step of the NEXT tile, each followed by
+//     FMRI_STORE_FENCE: common.h) and sum the statistics on the way;
+//   * LDS 144-160 KB: two phase windows (10 / 12 slices of 4 KB), the 2 x 16 KB weight ring, the staging area.
 // Everything else is igemm_c5.hip's: phase windows with the columns split into their parities (unit-stride conflict-free
 // ds_read_b128 with the chunk swizzle 2*bit2(column)), weights straight out of the [co][tap * Ci + ci] matrix, buffer
-// descriptor DMA with hardware zero fill, counted vmcnt, compile-time tap loops, persistent blocks over consecutive
-// tiles, BatchNorm forward statistics of the stored values (StatEpi).
+// descriptor DMA with hardware zero fill, compile-time tap loops, eval-mode BatchNorm folded in (AffEpi).
 #include "kernels.h"
 #include <type_traits>
 
 #ifndef C5W_NSTG
 #define C5W_NSTG 2      // weight ring stages (16 KB each); deeper rings measured no faster
 #endif
-#ifndef C5W_HALFA
-#define C5W_HALFA 1
-#endif
-#ifndef C5W_ABL
-#define C5W_ABL 0       // diagnostic builds only: 1 no output stores, 2 no fragment reads, 3 no operand DMA, 5 stores into image 0,
-                        // 6 no barrier at the odd K-steps (timing only: -4.7 % wave cycles, i.e. the barriers are not the overhead)
-#endif
 
 namespace fmri {
-
-#ifdef FMRI_STAMP
-// Diagnostic build only (tools/probes/c5w_stamps.py; never shipped): [0] sync (vmcnt + barrier), [1] pending-slot phase
-// (12 fragment reads, 32 MFMAs, 6 DMA pieces), [2] first-slot phase, [3] epilogue, [4] steps, [5] waves, [6] kernel
-// cycles (s_memtime), [7] kernel 100 MHz ticks (s_memrealtime)
-__device__ unsigned long long c5w_stamp_acc[8];
-#define FMRI_STAMP_AT(v)                                                                     \
-    do {                                                                                     \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory");            \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-    } while (0)
-#endif
 
 namespace {
 
@@ -70,7 +52,6 @@ __device__ __forceinline__ void wdma(v4i srd, uint32_t voff, uint32_t soff, uint
     srd.w = __builtin_amdgcn_readfirstlane(srd.w);
     soff = __builtin_amdgcn_readfirstlane(soff);
     lds = __builtin_amdgcn_readfirstlane(lds);
-    if (C5W_ABL == 3 && srd.z != 0x7fffffff) return;
     asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
                  ::"v"(voff), "s"(srd), "s"(soff), "s"(lds)
                  : "memory");
@@ -165,11 +146,6 @@ __global__ __launch_bounds__(512, 1) void igemm_c5w_kernel(const C5Args a) {
     int grp0, ty0, tx0;
     tile_geom(tile0, grp0, ty0, tx0);
     const int sgrp = (STATS != 0 && a.st.group_n > 0) ? (grp0 * IPB) / a.st.group_n : 0;   // statistics group of the block's tiles
-#ifdef FMRI_STAMP
-    unsigned long long st_sync = 0, st_pend = 0, st_first = 0, st_epi = 0, st_steps = 0, k0, k1, r0, r1;
-    FMRI_STAMP_AT(k0);
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r0)::"memory");
-#endif
 
     if (loader) {
         // =====================================================================================================
@@ -277,7 +253,7 @@ __global__ __launch_bounds__(512, 1) void igemm_c5w_kernel(const C5Args a) {
                 const int n = PW == 16 ? g : g * IPB + r * 2 + (opx >> 3);
                 const int yb = PW == 16 ? yy + r * 8 : yy, x = xx + ox;
                 const bool ok = n < a.N && x < a.Wo && co0 + slot * 8 < a.CoStore;
-                ovo[r] = ok ? (uint32_t)(((((C5W_ABL == 5 ? 0 : n) * a.Ho + yb) * a.Wo + x) * a.CoStore + co0 + slot * 8) * 2) : 0x80000000u;
+                ovo[r] = ok ? (uint32_t)((((n * a.Ho + yb) * a.Wo + x) * a.CoStore + co0 + slot * 8) * 2) : 0x80000000u;
                 onrow[r] = a.Ho - yb;                              // tile rows k < onrow exist
             }
         };
@@ -297,7 +273,6 @@ __global__ __launch_bounds__(512, 1) void igemm_c5w_kernel(const C5Args a) {
                     lsq[j] += f * f;
                 }
             }
-            if (C5W_ABL == 1 && a.N > 0) return;
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, oreg[r][k]), srd_out, (int)vt, (int)(k * row_b), 0);
             FMRI_STORE_FENCE();        // SGPR-offset store: the compiler pads no wait states (common.h)
         };
@@ -316,7 +291,7 @@ __global__ __launch_bounds__(512, 1) void igemm_c5w_kernel(const C5Args a) {
                 } else {
                     if (more) wait_vmw<n_more>(); else wait_vmw<n_last>();
                 }
-                if constexpr (!(C5W_ABL == 6 && (t & 1))) __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
                 int sd = stg + D;
                 if (sd >= NSTG) sd -= NSTG;
@@ -412,13 +387,6 @@ __global__ __launch_bounds__(512, 1) void igemm_c5w_kernel(const C5Args a) {
                     acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pbf[tn], paf[tm], acc[tn][tm], 0, 0, 0);
         };
         auto clear_pending = [&]() __attribute__((always_inline)) {
-            if constexpr (C5W_ABL == 2) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) paf[i] = (h8)(half_t)(0.37f * (float)((lane * 7 + i) & 15) - 2.f);
-#pragma unroll
-                for (int i = 0; i < TN; ++i) pbf[i] = (h8)(half_t)(0.011f * (float)((lane * 5 + i) & 15) - 0.08f);
-                return;
-            }
 #pragma unroll
             for (int i = 0; i < TM; ++i) paf[i] = (h8)(half_t)0.f;
 #pragma unroll
@@ -431,12 +399,7 @@ __global__ __launch_bounds__(512, 1) void igemm_c5w_kernel(const C5Args a) {
             constexpr int t0 = decltype(T0_)::value;
             constexpr int NS = t0 + 1 < 25 ? 2 : 1;
             h8 af0[TM], bf0[TN];
-            if constexpr (C5W_ABL == 2) {
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm) af0[tm] = paf[tm];
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn) bf0[tn] = pbf[tn];
-            } else {
+            {
                 constexpr int ky = w5_ky(t0), kx = w5_kx(t0);
                 const char* Ps = smem + (ky & 1) * WINB + (ky >> 1) * (ROW * 64);
 #pragma unroll
@@ -444,18 +407,10 @@ __global__ __launch_bounds__(512, 1) void igemm_c5w_kernel(const C5Args a) {
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) bf0[tn] = *(const h8*)(smem + (wb + tn * 1024));
             }
-#if !C5W_HALFA
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-#if defined(FMRI_STAMP) && FMRI_STAMP >= 2
-            unsigned long long tb, tc, td;
-            FMRI_STAMP_AT(tb);
-#endif
             // (t0 == 0: the previous step was the lone 25th tap or the start of the kernel -- nothing is pending, and 32 MFMAs
             // on zeros would only cover the first slot's read latency at twice its price)
             if constexpr (t0 != 0) pending_mfmas();
-#if C5W_HALFA
-            if constexpr (C5W_ABL != 2 && t0 != 0) {
+            if constexpr (t0 != 0) {
                 // the reads one by one between the first MFMAs, not as a burst in front of them
 #pragma unroll
                 for (int i = 0; i < TM + TN; ++i) {
@@ -464,13 +419,8 @@ __global__ __launch_bounds__(512, 1) void igemm_c5w_kernel(const C5Args a) {
                 }
                 __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - 2 * (TM + TN), 0);
             }
-#endif
             __builtin_amdgcn_sched_barrier(0);
-#if defined(FMRI_STAMP) && FMRI_STAMP >= 2
-            FMRI_STAMP_AT(tc);
-#endif
-            if constexpr (C5W_ABL == 2) {
-            } else if constexpr (NS == 2) {
+            if constexpr (NS == 2) {
                 constexpr int ky = w5_ky(t0 + 1), kx = w5_kx(t0 + 1);
                 const char* Ps = smem + (ky & 1) * WINB + (ky >> 1) * (ROW * 64);
 #pragma unroll
@@ -494,26 +444,14 @@ __global__ __launch_bounds__(512, 1) void igemm_c5w_kernel(const C5Args a) {
                 __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - 2 * (TM + TN), 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-#if defined(FMRI_STAMP) && FMRI_STAMP >= 2
-            FMRI_STAMP_AT(td);
-            st_pend += tc - tb; st_first += td - tc; st_steps += 1;
-#endif
         };
         int stg = 0;                              // ring stage of the current step (wave-uniform)
         auto run_sub = [&]() __attribute__((always_inline)) {
             static_for_w<0, 13>([&](auto T_) __attribute__((always_inline)) {
                 constexpr int t = decltype(T_)::value;
-#if defined(FMRI_STAMP) && FMRI_STAMP >= 2
-                unsigned long long ta, tb0;
-                FMRI_STAMP_AT(ta);
-#endif
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if constexpr (!(C5W_ABL == 6 && (t & 1))) __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
-#if defined(FMRI_STAMP) && FMRI_STAMP >= 2
-                FMRI_STAMP_AT(tb0);
-                st_sync += tb0 - ta;
-#endif
                 step(std::integral_constant<int, 2 * t>{}, boff + (uint32_t)(stg * W_BYTES));
                 stg = stg + 1 == NSTG ? 0 : stg + 1;
             });
@@ -579,16 +517,8 @@ __global__ __launch_bounds__(512, 1) void igemm_c5w_kernel(const C5Args a) {
             run_sub();
             ++sub;
             if (last_sub) {
-#if defined(FMRI_STAMP) && FMRI_STAMP >= 2
-                unsigned long long te0, te1;
-                FMRI_STAMP_AT(te0);
-#endif
                 epilogue();
                 clear_pending();
-#if defined(FMRI_STAMP) && FMRI_STAMP >= 2
-                FMRI_STAMP_AT(te1);
-                st_epi += te1 - te0;
-#endif
 #pragma unroll
                 for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -600,15 +530,6 @@ __global__ __launch_bounds__(512, 1) void igemm_c5w_kernel(const C5Args a) {
             }
         }
     }
-#ifdef FMRI_STAMP
-    FMRI_STAMP_AT(k1);
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r1)::"memory");
-    if (lane == 0 && !loader) {
-        atomicAdd(&c5w_stamp_acc[0], st_sync); atomicAdd(&c5w_stamp_acc[1], st_pend); atomicAdd(&c5w_stamp_acc[2], st_first);
-        atomicAdd(&c5w_stamp_acc[3], st_epi); atomicAdd(&c5w_stamp_acc[4], st_steps); atomicAdd(&c5w_stamp_acc[5], 1ull);
-        atomicAdd(&c5w_stamp_acc[6], k1 - k0); atomicAdd(&c5w_stamp_acc[7], r1 - r0);
-    }
-#endif
     if constexpr (STATS != 0) {
         // one row per block; the blocks of one statistics group are contiguous (tpg[0] = blocks per group).  The 16 loader
         // threads that hold the same 8 channels (one per pixel column of an item) meet in LDS
@@ -643,6 +564,7 @@ template <int PW, int STATS>
 static int launch_c5w(const C5Args& a, int copad, hipStream_t st) {
     auto kern = igemm_c5w_kernel<PW, STATS>;
     constexpr int lds = 2 * (PW == 16 ? 10 : 12) * 4096 + C5W_NSTG * 16384 + 32768;
+    if (route_probe("fmri::igemm_c5w_kernel<%d,%d>", PW, STATS)) return OK;
     // raising the dynamic-LDS limit is idempotent; every call sets it (no library-global state)
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return E_LAUNCH;
@@ -659,15 +581,5 @@ int igemm_c5w_launch(const C5Args& a, int copad, hipStream_t st) {
     return a.st.part ? launch_c5w<8, 1>(a, copad, st) : launch_c5w<8, 0>(a, copad, st);
 }
 
-#ifdef FMRI_STAMP
-extern "C" int fmri_debug_c5w_stamps(unsigned long long* out8, int reset) {
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(c5w_stamp_acc), 64) != hipSuccess) return -1;
-    if (reset) {
-        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(c5w_stamp_acc), z, 64) != hipSuccess) return -1;
-    }
-    return 0;
-}
-#endif
 
 }  // namespace fmri

@@ -218,6 +218,7 @@ template <int CI, int TN>
 static int launch_narrow(const NarrowArgs& a, bool flip, hipStream_t st) {
     constexpr int WB = 20 * 20 * (CI == 32 ? 80 : 16);
     int blocks = a.ntiles < 512 ? a.ntiles : 512;
+    if (route_probe("fmri::igemm_narrow_kernel<%d,%d,%s>", CI, TN, flip ? "true" : "false")) return OK;
     if (flip) hipLaunchKernelGGL((igemm_narrow_kernel<CI, TN, true>), dim3(blocks), dim3(256), 2 * WB, st, a);
     else hipLaunchKernelGGL((igemm_narrow_kernel<CI, TN, false>), dim3(blocks), dim3(256), 2 * WB, st, a);
     return hipGetLastError() == hipSuccess ? OK : E_LAUNCH;

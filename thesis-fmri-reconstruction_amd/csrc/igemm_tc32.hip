@@ -258,6 +258,7 @@ int igemm_tc32_launch(const Tc32Args& a, int nblocks, hipStream_t st) {
     if ((int64_t)a.N * a.Ho * a.Wo * a.CoStore * 2 >= 0x80000000LL || (int64_t)a.N * a.Hi * a.Wi * 256 >= 0x80000000LL ||
         (a.CoStore & 3))
         return E_UNSUPPORTED;
+    if (route_probe("fmri::igemm_tc32_kernel<%s>", a.relu_y ? "true" : "false")) return OK;
     auto kern = a.relu_y ? igemm_tc32_kernel<true> : igemm_tc32_kernel<false>;
     // raising the dynamic-LDS limit is idempotent; every call sets it (no library-global state)
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, TC32_LDS) != hipSuccess) return E_LAUNCH;

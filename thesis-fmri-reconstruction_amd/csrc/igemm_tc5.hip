@@ -419,6 +419,7 @@ static int launch_tc5(const Tc5Args& a, int copad, hipStream_t st) {
     constexpr int PBUFS = NSL <= 6 ? 2 : 1;
     constexpr int lds = PBUFS * (NSL == 4 ? 4 * 4096 + 128 : NSL * 4096) + 2 * BN * 128;
     static_assert(lds <= 80 * 1024, "two blocks per CU");
+    if (route_probe("fmri::igemm_tc5_kernel<%d,%d,%d>", BN, NSL, STATS)) return OK;
     // raising the dynamic-LDS limit is idempotent; every call sets it (no library-global state)
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return E_LAUNCH;

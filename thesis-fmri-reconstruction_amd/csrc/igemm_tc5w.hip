@@ -23,17 +23,8 @@
 #include "kernels.h"
 #include <type_traits>
 
-#ifndef TC5W_ABL
-#define TC5W_ABL 0      // diagnostic builds only: 1 no output stores, 2 no fragment reads, 3 no operand DMA, 4 no window DMA, 5 no weight DMA
-#endif
-
 namespace fmri {
 
-#ifdef FMRI_STAMP
-// Diagnostic build only (tools/probes/c5w_stamps.py; never shipped): [5] compute waves, [6] their cycles in the kernel
-// (s_memtime), [7] 100 MHz ticks (s_memrealtime)
-__device__ unsigned long long tc5w_stamp_acc[8];
-#endif
 
 namespace {
 
@@ -59,7 +50,6 @@ __device__ __forceinline__ void tdma(v4i srd, uint32_t voff, uint32_t soff, uint
     srd.w = __builtin_amdgcn_readfirstlane(srd.w);
     soff = __builtin_amdgcn_readfirstlane(soff);
     lds = __builtin_amdgcn_readfirstlane(lds);
-    if (TC5W_ABL == 3 && srd.z != 0x7fffffff) return;
     asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
                  ::"v"(voff), "s"(srd), "s"(soff), "s"(lds)
                  : "memory");
@@ -121,10 +111,6 @@ __global__ __launch_bounds__(512, 1) void igemm_tc5w_kernel(const Tc5Args a) {
     const int frow = lane & 15, fq = lane >> 4;
     const int sgrp = (STATS != 0 && a.st.group_n > 0) ? (grp * IPB) / a.st.group_n : 0;     // statistics group of the tile
 
-#ifdef FMRI_STAMP
-    unsigned long long k0, k1, r0, r1;
-    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(k0), "=s"(r0)::"memory");
-#endif
     if (loader) {
         // =====================================================================================================
         // loader waves: per K-step, wait for the operands of this step, meet the compute waves at the barrier (they are
@@ -167,7 +153,6 @@ __global__ __launch_bounds__(512, 1) void igemm_tc5w_kernel(const Tc5Args a) {
             const uint32_t so = (uint32_t)chunk * 128u;
             static_for_t<lo, (hi < NSL ? hi : NSL)>([&](auto E_) __attribute__((always_inline)) {
                 constexpr int e = decltype(E_)::value;
-                if (TC5W_ABL == 4 && a.N > 0) return;
                 tdma(srd_in, soff[e], so, lds_wave + buf * WINB + e * 4096);
             });
         };
@@ -185,7 +170,6 @@ __global__ __launch_bounds__(512, 1) void igemm_tc5w_kernel(const Tc5Args a) {
             constexpr int stg = decltype(STG_)::value;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                if (TC5W_ABL == 5 && a.N > 0) continue;
                 tdma(srd_w, vw, so + i * rs, lds_wave + WBUF0 + stg * W_BYTES + i * 4096);
             }
         };
@@ -243,7 +227,6 @@ __global__ __launch_bounds__(512, 1) void igemm_tc5w_kernel(const Tc5Args a) {
                     lsq[j] += f * f;
                 }
             }
-            if (TC5W_ABL == 1 && a.N > 0) return;
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, oreg[r][k]), srd_out, (int)vt, (int)(k * row2_b), 0);
             FMRI_STORE_FENCE();        // SGPR-offset store: the compiler pads no wait states (common.h)
         };
@@ -348,13 +331,6 @@ __global__ __launch_bounds__(512, 1) void igemm_tc5w_kernel(const Tc5Args a) {
         // ---- the pending second half of the previous K-step (all zeros: nothing pending)
         h8 paf[TM], pbf[TN];
         auto clear_pending = [&]() __attribute__((always_inline)) {
-            if constexpr (TC5W_ABL == 2) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) paf[i] = (h8)(half_t)(0.37f * (float)((lane * 7 + i) & 15) - 2.f);
-#pragma unroll
-                for (int i = 0; i < TN; ++i) pbf[i] = (h8)(half_t)(0.011f * (float)((lane * 5 + i) & 15) - 0.08f);
-                return;
-            }
 #pragma unroll
             for (int i = 0; i < TM; ++i) paf[i] = (h8)(half_t)0.f;
 #pragma unroll
@@ -384,21 +360,14 @@ __global__ __launch_bounds__(512, 1) void igemm_tc5w_kernel(const Tc5Args a) {
             const char* Ps = smem + sy * ROWB;
             const char* Ws = smem + stg * W_BYTES;
             h8 af0[TM], bf0[TN];
-            if constexpr (TC5W_ABL == 2) {
 #pragma unroll
-                for (int tm = 0; tm < TM; ++tm) af0[tm] = paf[tm];
+            for (int tm = 0; tm < TM; ++tm) af0[tm] = *(const h8*)(Ps + abase[pb][sx] + tm * ROWB);
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn) bf0[tn] = pbf[tn];
-            } else {
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm) af0[tm] = *(const h8*)(Ps + abase[pb][sx] + tm * ROWB);
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn) bf0[tn] = *(const h8*)(Ws + (boff + tn * 2048));
-            }
+            for (int tn = 0; tn < TN; ++tn) bf0[tn] = *(const h8*)(Ws + (boff + tn * 2048));
             pending_mfmas();
             interleave();
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (TC5W_ABL != 2) {
+            {
                 // the second half: one XOR each (volatile: the compiler would otherwise keep both address sets live)
                 uint32_t ax, bxo;
                 asm volatile("v_xor_b32 %0, 64, %1" : "=v"(ax) : "v"(abase[pb][sx]));
@@ -511,12 +480,6 @@ __global__ __launch_bounds__(512, 1) void igemm_tc5w_kernel(const Tc5Args a) {
         }
     }
 
-#ifdef FMRI_STAMP
-    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(k1), "=s"(r1)::"memory");
-    if (lane == 0 && !loader) {
-        atomicAdd(&tc5w_stamp_acc[5], 1ull); atomicAdd(&tc5w_stamp_acc[6], k1 - k0); atomicAdd(&tc5w_stamp_acc[7], r1 - r0);
-    }
-#endif
     // ---- BatchNorm statistics of the block (all four classes): its own row of the partial buffer.  The 16 loader threads
     // that hold the same 8 channels (one per position column of an item) meet in LDS
     if constexpr (STATS != 0) {
@@ -553,6 +516,7 @@ template <int PW, int STATS, bool SOLO>
 static int launch_tc5w_(const Tc5Args& a, int copad, hipStream_t st) {
     auto kern = igemm_tc5w_kernel<PW, STATS, SOLO>;
     constexpr int lds = PW == 16 ? 2 * 11 * 4096 + 2 * 128 * 128 + 32768 : 2 * 13 * 4096 + 2 * 128 * 128;
+    if (route_probe("fmri::igemm_tc5w_kernel<%d,%d,%s>", PW, STATS, SOLO ? "true" : "false")) return OK;
     // raising the dynamic-LDS limit is idempotent; every call sets it (no library-global state)
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return E_LAUNCH;
@@ -581,15 +545,5 @@ int igemm_tc5w_launch(const Tc5Args& a, int copad, hipStream_t st) {
     return a.st.part ? launch_tc5w<16, 1>(a, copad, st) : launch_tc5w<16, 0>(a, copad, st);
 }
 
-#ifdef FMRI_STAMP
-extern "C" int fmri_debug_tc5w_stamps(unsigned long long* out8, int reset) {
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(tc5w_stamp_acc), 64) != hipSuccess) return -1;
-    if (reset) {
-        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(tc5w_stamp_acc), z, 64) != hipSuccess) return -1;
-    }
-    return 0;
-}
-#endif
 
 }  // namespace fmri

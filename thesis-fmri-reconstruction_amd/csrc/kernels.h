@@ -34,8 +34,6 @@ struct UnpackArgs {
 
 int igemm_launch(const IgemmArgs& a, int maxM, int bn_tile, int copad, bool out_f32, hipStream_t st);
 int igemm_bm(const IgemmArgs& a, int maxM, int bn_tile, int copad, bool out_f32);   // row tile igemm_launch will use
-int igemm_patch_launch(PatchArgs& a, int max_tiles, int bn_tile, int copad, hipStream_t st);
-int igemm_win_launch(WinArgs& a, int max_tiles, int bn_tile, int copad, hipStream_t st);
 int igemm_tc32_launch(const Tc32Args& a, int nblocks, hipStream_t st);
 int igemm_tc5_launch(const Tc5Args& a, int bn_tile, int copad, hipStream_t st);
 int igemm_c5_launch(const C5Args& a, int copad, hipStream_t st);
@@ -96,6 +94,11 @@ int act_bwd_launch(const half_t* y, const half_t* dy, half_t* dpre, int M, int C
                    int64_t ws_floats, float* dbias, int dbias_n, float gscale, hipStream_t st);
 int colsum_acc_launch(const void* src, int is_f16, int M, int C, int64_t ld_row, int64_t ld_col, float scale, float* dst,
                       hipStream_t st);
+
+// api.hip: routing probe (fmri_igemm_route).  Every igemm launch function calls route_probe() with the name of the kernel
+// instantiation it is about to launch, after its own support checks and before any HIP call; while a probe is active on
+// the calling thread the name is recorded and `true` returned: the launcher then returns OK without touching the GPU.
+bool route_probe(const char* fmt, ...);
 
 // loss.hip: process-wide deterministic-reduction switch (fmri_set_deterministic)
 extern int g_deterministic;

@@ -14,17 +14,9 @@
 #include "kernels.h"
 #include <type_traits>
 
-#ifndef WGW_ABL
-#define WGW_ABL 0       // diagnostic builds only: 1 no output, 2 no fragment reads, 3 no operand DMA
-#endif
 
 namespace fmri {
 
-#ifdef FMRI_STAMP
-// Diagnostic build only (tools/probes/wgw_stamps.py; never shipped): [5] waves, [6] their cycles in the kernel (s_memtime),
-// [7] 100 MHz ticks (s_memrealtime)
-__device__ unsigned long long wgw_stamp_acc[8];
-#endif
 
 namespace {
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -44,7 +36,6 @@ __device__ __forceinline__ void wdma16(v4i srd, uint32_t voff, uint32_t lds) {
     srd.z = __builtin_amdgcn_readfirstlane(srd.z);
     srd.w = __builtin_amdgcn_readfirstlane(srd.w);
     lds = __builtin_amdgcn_readfirstlane(lds);
-    if (WGW_ABL == 3 && srd.z != 0x7fffffff) return;
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(srd), "s"(lds)
                  : "memory");
 }
@@ -181,7 +172,6 @@ __device__ __forceinline__ void wgrad_win_body(const WgradWinArgs& a, char* smem
         const char* Ws = Ps + P_BYTES + woff;
         constexpr int NI = 2 * NS;
         auto read_a = [&](int ks, int ta) __attribute__((always_inline)) -> h8 {
-            if constexpr (WGW_ABL == 2) return (h8)(half_t)(0.01f * (float)((lane + ta) & 15) - 0.07f);
             const int blk = wa * 4 + ta;
             const int ch = (2 * blk + (p >> 1)) ^ fr;
             const char* ad = Ps + ks * (32 * 256) + rowoff + ch * 16;
@@ -192,7 +182,6 @@ __device__ __forceinline__ void wgrad_win_body(const WgradWinArgs& a, char* smem
         };
         auto read_w = [&](int i) __attribute__((always_inline)) -> h8 {
             const int ks = i / NS, sh = i % NS, sy = sh / NSX, sx = sh % NSX;
-            if constexpr (WGW_ABL == 2) return (h8)(half_t)(0.3f * (float)((lane * 3 + sy + sx) & 15) - 2.f);
             const char* ad = Ws + ((ks * 4 + sy) * WW + sx) * 64;
             union { s4v s[2]; h8 h; } u;
             u.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(ad));
@@ -216,10 +205,8 @@ __device__ __forceinline__ void wgrad_win_body(const WgradWinArgs& a, char* smem
             for (int ta = 0; ta < TA; ++ta)
                 acc[sh][ta] = SLABS ? __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i % 3], af[ks][ta], acc[sh][ta], 0, 0, 0)
                                     : __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ks][ta], wf[i % 3], acc[sh][ta], 0, 0, 0);
-            if constexpr (WGW_ABL != 2) {
-                if constexpr (rd_w || rd_a) __builtin_amdgcn_sched_group_barrier(0x100, (rd_w ? 2 : 0) + (rd_a ? 2 : 0), 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, TA, 0);
-            }
+            if constexpr (rd_w || rd_a) __builtin_amdgcn_sched_group_barrier(0x100, (rd_w ? 2 : 0) + (rd_a ? 2 : 0), 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TA, 0);
         });
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -271,16 +258,6 @@ __device__ __forceinline__ void wgrad_win_body(const WgradWinArgs& a, char* smem
     const int bcol = b0 + wb * 16 + (SLABS ? (lane >> 4) * 4 : (lane & 15));
     if (bcol >= kBc) return;
     const int nfill = (SLABS && split + 1 == a.plane_pieces[py * 2 + px]) ? a.splits - split : 1;
-    if (WGW_ABL == 1 && a.N > 0) {
-        // keep the accumulators alive without the stores
-        float keep = 0.f;
-#pragma unroll
-        for (int s = 0; s < NS; ++s)
-#pragma unroll
-            for (int i = 0; i < TA; ++i) keep += acc[s][i][0] + acc[s][i][1] + acc[s][i][2] + acc[s][i][3];
-        if (keep == 12345.678f) slab[0] = keep;
-        return;
-    }
 #pragma unroll
     for (int sy = 0; sy < NSY; ++sy)
 #pragma unroll
@@ -328,21 +305,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_win_kernel(const WgradWinArgs a)
     const int split = piece;
     const int py = plane >> 1, px = plane & 1;
     const int nsy = a.nsy[py], nsx = a.nsx[px];
-#ifdef FMRI_STAMP
-    unsigned long long k0, k1, r0, r1;
-    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(k0), "=s"(r0)::"memory");
-#endif
     if (nsy == 3 && nsx == 3) wgrad_win_body<3, 3, SLABS>(a, smem, py, px, a_tile, b_tile, split);
     else if (nsy == 3 && nsx == 2) wgrad_win_body<3, 2, SLABS>(a, smem, py, px, a_tile, b_tile, split);
     else if (nsy == 2 && nsx == 3) wgrad_win_body<2, 3, SLABS>(a, smem, py, px, a_tile, b_tile, split);
     else wgrad_win_body<2, 2, SLABS>(a, smem, py, px, a_tile, b_tile, split);
-#ifdef FMRI_STAMP
-    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(k1), "=s"(r1)::"memory");
-    if ((threadIdx.x & 63) == 0 && threadIdx.x < 256) {
-        atomicAdd(&wgw_stamp_acc[(nsy * nsx == 9) ? 0 : (nsy * nsx == 6 ? 1 : 2)], k1 - k0);
-        atomicAdd(&wgw_stamp_acc[5], 1ull); atomicAdd(&wgw_stamp_acc[6], k1 - k0); atomicAdd(&wgw_stamp_acc[7], r1 - r0);
-    }
-#endif
 }
 
 int wgrad_win_launch(const WgradWinArgs& a, int apad, hipStream_t st) {
@@ -359,15 +325,5 @@ int wgrad_win_launch(const WgradWinArgs& a, int apad, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? OK : E_LAUNCH;
 }
 
-#ifdef FMRI_STAMP
-extern "C" int fmri_debug_wgw_stamps(unsigned long long* out8, int reset) {
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(wgw_stamp_acc), 64) != hipSuccess) return -1;
-    if (reset) {
-        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(wgw_stamp_acc), z, 64) != hipSuccess) return -1;
-    }
-    return 0;
-}
-#endif
 
 }  // namespace fmri

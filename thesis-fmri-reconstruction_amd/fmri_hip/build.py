@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.abspath(os.path.join(HERE, "..", "csrc"))
 LIB = os.path.join(HERE, "libfmri_hip.so")
-SOURCES = ["igemm.hip", "igemm_patch.hip", "igemm_win.hip", "igemm_narrow.hip", "igemm_tc32.hip", "igemm_tc5.hip", "igemm_tc5w.hip", "igemm_c5.hip", "igemm_c5w.hip", "wgrad.hip", "wgrad_win.hip", "wgrad_narrow.hip", "layout.hip", "norm.hip", "loss.hip", "mlp.hip", "metrics.hip", "ingest.hip", "api.hip"]
+SOURCES = ["igemm.hip", "igemm_narrow.hip", "igemm_tc32.hip", "igemm_tc5.hip", "igemm_tc5w.hip", "igemm_c5.hip", "igemm_c5w.hip", "wgrad.hip", "wgrad_win.hip", "wgrad_narrow.hip", "layout.hip", "norm.hip", "loss.hip", "mlp.hip", "metrics.hip", "ingest.hip", "api.hip"]
 HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "fmri_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wno-unused-result"]
 

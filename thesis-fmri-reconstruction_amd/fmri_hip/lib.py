@@ -32,6 +32,8 @@ _SIGS = {
     "fmri_igemm": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _l, _i, _p],
     "fmri_igemm_ep": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _l, _i, _l, _p, _p,
                       _p],
+    "fmri_igemm_route": [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _l, _i, _i, _i, _i, _i, _i,
+                         C.c_char_p, _i],
     "fmri_wgrad_slabs": [_i, _i, _i, _i, _i, _i],
     "fmri_wgrad_narrow_blocks": [_i, _i, _i],
     "fmri_set_deterministic": [_i],

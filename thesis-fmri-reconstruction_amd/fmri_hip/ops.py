@@ -178,49 +178,18 @@ def _choose_splits(blocks: int, ksteps: int) -> int:
     return (ksteps + per - 1) // per
 
 
-def igemm_kernel_label(N, Hi, Wi, Ci, Ho, Wo, CoStore, Co, k, stride, pad, mode, out_f32, splits, tile,
-                       bias_none=True, act=0) -> str:
-    """Name of the kernel instantiation csrc/api.hip::fmri_igemm routes this geometry to (mirrors its rules)."""
-    spatial = Hi * Wi > 1
-    if (mode in (MODE_CONV, MODE_CONV_FLIP) and stride == 1 and k == 5 and pad == 2 and Ci in (8, 32) and Co <= 32
-            and not out_f32 and splits == 1 and (Ci == 8 or Co <= 16)):
-        return f"fmri::igemm_narrow_kernel<{Ci},{1 if Co <= 16 else 2},{'true' if mode == MODE_CONV_FLIP else 'false'}>"
-    if mode == MODE_TCONV2 and Ci == 128 and CoStore <= 32 and not out_f32 and splits == 1:
-        return "fmri::igemm_tc32_kernel"
-    if (mode == MODE_TCONV2 and k == 5 and pad == 2 and Ci % 128 == 0 and tile >= 64 and not out_f32 and splits == 1
-            and bias_none and act == ACT_NONE and os.environ.get("FMRI_TC5") != "off"):
-        yc, xc = (Ho + 1) // 2, (Wo + 1) // 2
-        pw = 16 if xc > 8 else 8
-        ph = 16 if (pw == 8 and yc > 8) else 8
-        ipb = 128 // (pw * ph)
-        nsl = (ipb * (ph + 2) * (pw + 2) * 8 + 255) // 256
-        if ipb == 2 and yc <= 8 and xc <= 8 and Hi <= 8 and Wi <= 8 and os.environ.get("FMRI_TC5_DENSE") != "off":
-            nsl = 4
-        if (tile == 128 and (Ci // 64) % 2 == 0 and os.environ.get("FMRI_TC5W") != "off"
-                and ((xc > 8 and yc > 8) or (xc <= 8 and yc <= 8 and Hi <= 8 and Wi <= 8))):
-            return "fmri::igemm_tc5w_kernel"
-        if nsl in (4, 6, 7):
-            return f"fmri::igemm_tc5_kernel<{tile},{nsl},0>"
-    if (mode == MODE_CONV and stride == 2 and k == 5 and pad == 2 and Ci % 32 == 0 and tile == 128 and not out_f32
-            and splits == 1 and bias_none and act == ACT_NONE and Ho == (Hi - 1) // 2 + 1 and Wo == (Wi - 1) // 2 + 1
-            and os.environ.get("FMRI_C5") != "off"):
-        if (Wo <= 8 or Ho > 8) and os.environ.get("FMRI_C5W") != "off":
-            return "fmri::igemm_c5w_kernel"
-        return f"fmri::igemm_c5_kernel<{16 if Wo > 8 else 8}>"
-    unit = (mode == MODE_TCONV2 or stride == 1) and spatial and 2 <= k <= 5 and not out_f32 and splits == 1
-    if unit and Ci % 64 == 0 and tile >= 64:
-        return f"fmri::igemm_win_kernel<{tile},2,2>"
-    if unit and mode != MODE_TCONV2 and Ci in (8, 32):
-        return f"fmri::igemm_patch_kernel<{tile}>"
-    uni = "true" if Ci % 64 == 0 else "false"
-    copad = ceil_to(Co, tile)
-    M = N * Ho * Wo if mode != MODE_TCONV2 else N * ((Ho + 1) // 2) * ((Wo + 1) // 2)
-    ncls = 4 if mode == MODE_TCONV2 else 1
-    if (tile == 128 and not out_f32 and splits == 1 and copad % 256 == 0
-            and ((M + 255) // 256) * (copad // 256) * ncls >= 192):
-        return f"fmri::igemm_kernel<256,256,2,4,false,{uni}>"
-    wm, wn = (4, 1) if tile == 32 else (2, 2)
-    return f"fmri::igemm_kernel<128,{tile},{wm},{wn},{'true' if out_f32 else 'false'},{uni}>"
+def igemm_route(N, Hi, Wi, Ci, Ho, Wo, CoStore, Co, k, stride, pad, mode, act, out_f32, splits, tile, w_elems=0,
+                has_bias=False, stat_rows_cap=0, stat_group_n=0, want_bn_bwd=False, want_act_y=False,
+                want_affine=False) -> str:
+    """Name of the kernel instantiation csrc/api.hip::fmri_igemm_ep routes these arguments to -- asked of the library
+    itself (fmri_igemm_route: host code only, works without a GPU), the single statement of the routing rules."""
+    buf = ctypes.create_string_buffer(160)
+    code = lib.load().fmri_igemm_route(N, Hi, Wi, Ci, Ho, Wo, CoStore, Co, k, stride, pad, mode, act, 1 if out_f32 else 0,
+                                       splits, tile, int(w_elems), 1 if has_bias else 0, int(stat_rows_cap),
+                                       int(stat_group_n), 1 if want_bn_bwd else 0, 1 if want_act_y else 0,
+                                       1 if want_affine else 0, buf, len(buf))
+    lib.check(code, "fmri_igemm_route")
+    return buf.value.decode()
 
 
 def run_igemm(x, pw: PackedWeight, out, bias, N, Hi, Wi, Ci, Ho, Wo, CoStore, Co, k, stride, pad, mode, act, out_f32,
@@ -233,8 +202,11 @@ def run_igemm(x, pw: PackedWeight, out, bias, N, Hi, Wi, Ci, Ho, Wo, CoStore, Co
     w = pw.get()
     if lib.PROFILE is not None:
         # algorithmic bytes: the input once, the output once, the weights once
-        lib.note(kernel=igemm_kernel_label(N, Hi, Wi, Ci, Ho, Wo, CoStore, Co, k, stride, pad, mode, out_f32, splits, tile,
-                                           bias is None, act),
+        lib.note(kernel=igemm_route(N, Hi, Wi, Ci, Ho, Wo, CoStore, Co, k, stride, pad, mode, act, out_f32, splits, tile,
+                                    w.numel(), bias is not None, stats[1] if stats is not None else 0,
+                                    stats[2] if stats is not None else 0, bn_bwd is not None,
+                                    act_y is not None and stats is None and affine is None,
+                                    affine is not None and stats is None),
                  flops=flops, bytes=2.0 * N * Hi * Wi * Ci + (4.0 if out_f32 else 2.0) * N * Ho * Wo * CoStore * splits
                  + 2.0 * w.numel())
     ep, done = None, ctypes.c_int(0)
@@ -626,7 +598,10 @@ class DenseLayer:
             self.b, self.bg = bkey if bkey else (None, None)
         self.k_in, self.n_out = k_in, n_out
         self.kp, self.np_ = pad8(k_in), pad8(n_out)
-        self.t_out, self.t_in = tile_for(n_out), tile_for(k_in)
+        # 64-wide output tiles for the dense layers: they run on a few hundred rows, so the launch is filled by split-K
+        # slabs -- twice the tiles halve the slabs (and their fp32 write + re-read): -15...-20 % on the two
+        # 16384-wide layers, nothing lost on the others (tools/probes/dense_tiles.py, profiles/r04_dense_tiles.log)
+        self.t_out, self.t_in = min(64, tile_for(n_out)), min(64, tile_for(k_in))
         K, Nn = k_in, n_out
         if in_perm:
             C, HW = in_perm

@@ -19,7 +19,7 @@ torch.cuda.synchronize()
 ref = F.conv2d(x.cuda(), w.cuda(), None, 2, 2).permute(0, 2, 3, 1)
 err = (y.float() - ref).abs()
 bad = ~(err < 2e-2 * (1 + ref.abs()))
-print("label", ops.igemm_kernel_label(N, H, W, cin, y.shape[1], y.shape[2], cout, cout, 5, 2, 2, ops.MODE_CONV, False, 1, 128))
+print("label", ops.igemm_route(N, H, W, cin, y.shape[1], y.shape[2], cout, cout, 5, 2, 2, ops.MODE_CONV, ops.ACT_NONE, False, 1, 128, L.pw_f.buf.numel()))
 print("bad elements", int(bad.sum()), "of", bad.numel(), "nan", int(torch.isnan(y).sum()))
 for n in range(N):
     rows = bad[n].any(dim=2).cpu()

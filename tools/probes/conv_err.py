@@ -19,7 +19,7 @@ def run(cin, cout, H, N, what):
         x = torch.randn(N, H, H, cin).half().cuda()
         y = L.forward(x)
         ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double().cuda(), None, 2, 2).permute(0, 2, 3, 1)
-        lab = ops.igemm_kernel_label(N, H, H, cin, H // 2, H // 2, cout, cout, 5, 2, 2, ops.MODE_CONV, False, 1, 128)
+        lab = ops.igemm_route(N, H, H, cin, H // 2, H // 2, cout, cout, 5, 2, 2, ops.MODE_CONV, ops.ACT_NONE, False, 1, 128, cout * 25 * cin)
     else:
         dy = torch.randn(N, H // 2, H // 2, cout).half().cuda()
         y = L.dgrad(dy, H, H)

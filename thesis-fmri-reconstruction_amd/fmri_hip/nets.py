@@ -191,15 +191,18 @@ class EncoderNet:
             join_side()
         return out
 
-    def _backward(self, ctx, dhead16: torch.Tensor, scale: float, after_fc=None):
+    def _backward(self, ctx, dhead16: torch.Tensor, scale: float, after_fc=None, after_fc_join: bool = True):
         """Accumulate encoder parameter gradients of (1/scale)*<dhead16, head>.  ``after_fc`` is called once the
         gradients of fc.0 / fc.1 / l_mu / l_var -- the tail of the flat buffer from ``fc.0.weight`` on, 93 % of its
-        bytes -- are final, so a data-parallel run can start reducing them under the conv backward."""
+        bytes -- are issued, so a data-parallel run can start reducing them under the conv backward;
+        ``after_fc_join`` first joins the side stream they were issued on (a hook that itself runs on the side stream
+        does not need that)."""
         dh = self.heads.backward(ctx["hfc"], dhead16, scale)
         draw_fc, _ = self.fc_bn.backward(ctx["raw_fc"], dh, ctx["svfc"], True, scale)
         self.fc.wgrad(ctx["flat"], draw_fc, scale)
         if after_fc is not None:
-            join_side()                                 # fc.0 weight gradient (side stream) is final
+            if after_fc_join:
+                join_side()                             # fc.0 weight gradient (side stream) is final
             after_fc()
         dflat, _ = self.fc.dgrad(draw_fc)
         d = dflat.reshape(ctx["acts"][3].shape)

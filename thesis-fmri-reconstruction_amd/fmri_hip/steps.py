@@ -166,16 +166,26 @@ class _Dist:
         self.world = dist.get_world_size() if self.on else 1
         self.sync_bn = sync_bn
         self.pending = []
+        # A communicator of its own for the SMALL collectives of the main stream (loss scalars, the stream-norm scalar,
+        # SyncBN sums).  Collectives of one communicator run in issue order on its stream: behind a 44 MB gradient
+        # all-reduce that is itself waiting for the side stream's weight gradients, a 40-byte all-reduce of the main
+        # stream would stall the whole backward pass (head-of-line blocking); on a second communicator it does not.
+        self.small = dist.new_group() if self.on else None
 
     recorder: Optional[_SegmentRecorder] = None
 
+    SMALL = 1 << 16          # elements: at most this many go through the small-message communicator
+
     def all_reduce(self, t: torch.Tensor):
+        """Blocking SUM all-reduce on the CURRENT stream (the host does not wait): scalars / statistics on the
+        small-message communicator, gradient buffers on the default one."""
         if not self.on:
             return
+        grp = self.small if t.numel() <= self.SMALL else None
         if self.recorder is not None:
-            self.recorder.collective(lambda: self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM))
+            self.recorder.collective(lambda: self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=grp))
         else:
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=grp)
 
     def all_reduce_async(self, t: torch.Tensor):
         """Start a SUM all-reduce (same communicator, so it queues behind / ahead of the blocking ones in program
@@ -477,12 +487,18 @@ class Stage1Step(_GanStepBase):
         # joined per sub-network, because its gradient reduction starts as soon as its buffer is final and runs under
         # the backward of the next one (discriminator 43.8 MB -> decoder 18.8 MB -> encoder fc tail 67 MB -> rest)
         dp = self.dd.on
-        early = early_apply and not dp and ops._SIDE["on"]
+        # ``early``: a sub-network's gradient reduction (data parallel), optimizer update and weight repack are queued on the
+        # SIDE stream right behind its last weight gradient -- the main stream neither joins the side stream nor waits for
+        # the collective before it goes on with the next sub-network's backward pass.  (Recording into graph segments
+        # keeps everything on one stream: the round-3 order with asynchronous collectives joined at the end.)
+        early = early_apply and ops._SIDE["on"] and self.dd.recorder is None
         self._applied_early = early
-        dimg_a, dimg_b = self.dis.backward(fw["sctx"], dlogit16, sc.a, dfeat16, sc.b, True, slice(B, 3 * B), join=dp)
-        self.dd.all_reduce_async(self.dis.group.grad)
+        dimg_a, dimg_b = self.dis.backward(fw["sctx"], dlogit16, sc.a, dfeat16, sc.b, True, slice(B, 3 * B),
+                                           join=dp and not early)
         if early:
-            ops.side_run(dev, lambda: self._apply_one(self.opt_dis, self.dis, self.flags[0:1], S_NA))
+            ops.side_run(dev, lambda: self._reduce_apply(self.opt_dis, self.dis, self.flags[0:1], S_NA))
+        else:
+            self.dd.all_reduce_async(self.dis.group.grad)
         # decoder cotangent, stored = dec * nA * (lambda*B_true - (1-lambda)*A_true); the weights lambda*nA/nB and
         # 1-lambda are device scalars written by the gate kernel (a recorded step follows the lambda schedule)
         cot = torch.empty(3 * B, H, W, 8, dtype=torch.float16, device=dev)
@@ -495,10 +511,11 @@ class Stage1Step(_GanStepBase):
               b_dev=self._slot(S_C2))
         entries = [dict(g=0, scale=sc.b, train=False, need_dz=True), dict(g=0, scale=sc.dec, train=True),
                    dict(g=1, scale=sc.dec, train=True)]
-        dz = self.dec.backward(fw["dctx"], cot, entries, join=dp)[0]  # = nB * dz_true
-        self.dd.all_reduce_async(self.dec.group.grad)
+        dz = self.dec.backward(fw["dctx"], cot, entries, join=dp and not early)[0]  # = nB * dz_true
         if early:
-            ops.side_run(dev, lambda: self._apply_one(self.opt_dec, self.dec, self.flags[1:2], S_GDEC))
+            ops.side_run(dev, lambda: self._reduce_apply(self.opt_dec, self.dec, self.flags[1:2], S_GDEC))
+        else:
+            self.dd.all_reduce_async(self.dec.group.grad)
         dhead32 = torch.empty(B, 2 * Z, dtype=torch.float32, device=dev)
         # KL weight: 1, or beta / batch for 'beta-vae' (train_vgan_stage1.py:360-362).  The gate kernel writes it to
         # the device slot S_KLW from the device-resident hyper-parameters, so that a recorded (HIP-graph) step follows
@@ -513,6 +530,14 @@ class Stage1Step(_GanStepBase):
         dhead16 = self._renorm(dhead32, sc.enc, self._slot(S_NB), B * self.dd.world)   # S_NE = nB * nE
         eg = self.enc.group
         tail = eg.offsets["fc.0.weight"]
+        if early and dp:
+            # the fc.0 ... l_var tail (93 % of the buffer) is reduced on the side stream as soon as the fc weight gradient
+            # is final there, under the conv backward; the conv head right behind the last weight gradient
+            self.enc.backward(fw["ectx"], dhead16, sc.enc, join=False, after_fc_join=False,
+                              after_fc=lambda: ops.side_run(dev, lambda: self.dd.all_reduce(eg.grad[tail:])))
+            ops.side_run(dev, lambda: self.dd.all_reduce(eg.grad[:tail]))
+            ops.join_side()
+            return
         self.enc.backward(fw["ectx"], dhead16, sc.enc,                  # grads = S_NE * true
                           after_fc=(lambda: self.dd.all_reduce_async(eg.grad[tail:])) if dp else None)
         self.dd.all_reduce(eg.grad[:tail])
@@ -570,6 +595,12 @@ class Stage1Step(_GanStepBase):
                           after_fc=(lambda: self.dd.all_reduce_async(eg.grad[tail:])) if dp else None)
         self.dd.all_reduce(eg.grad[:tail])
         self.dd.wait_all()
+
+    def _reduce_apply(self, opt, net, flag, slot):
+        """(current stream = the side stream) SUM all-reduce of the sub-network's gradient buffer over the ranks -- nothing
+        on one GPU --, then its optimizer update and the refresh of everything derived from its weights."""
+        self.dd.all_reduce(net.group.grad)
+        self._apply_one(opt, net, flag, slot)
 
     def _apply_one(self, opt, net, flag, slot):
         """Optimizer update of one sub-network + refresh of everything derived from its weights (current stream)."""

@@ -268,12 +268,15 @@ def test_stage1_full_batch_two_steps_match_oracle():
     decides where its weight goes, and fp16 activations flip the ReLU mask of the ~1e-3 of elements whose
     pre-activation lies within rounding of zero (each flip changes that element's gradient by 100 %).  Bounds:
       step 0, engine vs plain oracle:           1e-3 (the north-star bar; measured <= 5e-5)
-      step 1, engine vs mask-pinned oracle:     1e-3 on every loss (measured <= 4.3e-4): the engine follows its
-                                                arithmetic model, what is left against fp32 is that model's distance
-      step 1, engine vs plain fp32 oracle:      1e-3 on every loss (measured <= 5e-4) except the feature term ``mse``
-                                                and ``loss_encoder`` = kl + mse: 3e-3 (measured 1.98e-3, where the
-                                                mask-pinned 16-bit ORACLE itself reads 2.4e-3 against the fp32 one;
-                                                profiles/r04_fullbatch_two_steps.log)"""
+      step 1, engine vs mask-pinned oracle:     1e-3 on every loss (measured <= 4.3e-4, 4.3e-5 after the dense layers'
+                                                tile change of round 4): the engine follows its arithmetic model
+      step 1, engine vs plain fp32 oracle:      the MODEL's own distance from fp32 + 1e-3, per loss.  That distance is
+                                                <= 5e-4 for every loss except the feature term ``mse`` (and
+                                                ``loss_encoder`` = kl + mse), where it read 2.4e-3 and, after nothing but
+                                                the dense layers' split-K tile width had changed, 3.1e-3
+                                                (profiles/r04_fullbatch_two_steps.log): it moves with rounding-level
+                                                details of an EXACT 16-bit-storage implementation, so a constant next
+                                                to the last measurement would test the weather, not the engine."""
     from oracle import vaegan_oracle as O
     from fmri_hip.params import ArchConfig
     B, seed = 256, 0
@@ -321,6 +324,6 @@ def test_stage1_full_batch_two_steps_match_oracle():
                 if rm >= LOSS_RTOL:
                     bad.append((s, k, "vs mask-pinned oracle", e, m, rm))
             say(line)
-            if r >= (3e-3 if (s == 1 and k in ("mse", "loss_encoder")) else LOSS_RTOL):
+            if r >= LOSS_RTOL + (_rel(model1["logs"][k], p) if s == 1 else 0.0):
                 bad.append((s, k, "vs plain oracle", e, p, r))
     assert not bad, bad

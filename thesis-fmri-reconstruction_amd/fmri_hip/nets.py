@@ -285,10 +285,9 @@ class DecoderNet:
         order = list(range(groups)) if stat_order is None else list(stat_order)
         raw_fc, _ = self.fc.forward(z16)
         act_fc = torch.empty_like(raw_fc)
-        sv_fc = [None] * groups
-        for gi in order:
-            _, sv = self.fc_bn.forward(raw_fc[gi * B:(gi + 1) * B], True, upd, out=act_fc[gi * B:(gi + 1) * B])
-            sv_fc[gi] = sv
+        grows = lambda t: [t[gi * B:(gi + 1) * B] for gi in range(groups)]
+        # the call groups of one layer are ready together: with SyncBN their statistics travel in ONE all-reduce
+        sv_fc = self.fc_bn.forward_groups(grows(raw_fc), True, upd, grows(act_fc), [None] * groups, order)
         h = act_fc.reshape(GB, f, f, self.size0)
         acts, raws, svs = [h], [], []
         for dc, bn in zip(self.deconvs, self.bns):
@@ -303,11 +302,7 @@ class DecoderNet:
             else:
                 raw = dc.forward(h, bn_groups=0 if bn.eval_mode else groups)
             act = torch.empty_like(raw)
-            sl = [None] * groups
-            for gi in order:
-                _, sv = bn.forward(raw[gi * B:(gi + 1) * B], True, upd, out=act[gi * B:(gi + 1) * B],
-                                   stat_acc=dc.take_stats(gi))
-                sl[gi] = sv
+            sl = bn.forward_groups(grows(raw), True, upd, grows(act), [dc.take_stats(gi) for gi in range(groups)], order)
             raws.append(raw)
             svs.append(sl)
             acts.append(act)
@@ -363,26 +358,37 @@ class DecoderNet:
         _, hi, wi, _ = ctx["acts"][3].shape
         d = self.c3.dgrad(dpre, hi, wi)
         stat = None
+        def bn_backward(bn, raw_all, sv_all, d_all, draw_all, stat):
+            """BatchNorm backward of every cotangent block of one layer.  With SyncBN the reductions of all blocks run
+            first (phase 1) into one [2E][C] buffer that is exchanged ONCE, then the apply passes (phase 2)."""
+            sync = bn.reducer is not None
+            sums_all = torch.empty(2 * E, bn.C, dtype=torch.float32, device=d_all.device) if sync else None
+            for phase in ((1, 2) if sync else (3,)):
+                if phase == 2:
+                    bn.reducer(sums_all)
+                e = 0
+                while e < E:
+                    en = entries[e]
+                    nx = entries[e + 1] if e + 1 < E else None
+                    sm = sums_all[2 * e:] if sync else None
+                    if nx is not None and nx["g"] == en["g"] and not (nx["train"] and en["train"]):
+                        # two adjacent blocks through the same forward activations: one pass over them for both; the
+                        # gamma / beta gradients come from whichever of the two trains
+                        ps = 1 if nx["train"] else 0
+                        tr = nx if nx["train"] else en
+                        bn.backward2(rows(raw_all, en["g"]), d_all[e * B:(e + 2) * B], sv_all[en["g"]], True,
+                                     tr["scale"] if tr["train"] else None, out=draw_all[e * B:(e + 2) * B],
+                                     param_stream=ps, stat=stat, stat_group=e, sums=sm[:4] if sync else None, phase=phase)
+                        e += 2
+                    else:
+                        bn.backward(rows(raw_all, en["g"]), rows(d_all, e), sv_all[en["g"]], True,
+                                    en["scale"] if en["train"] else None, out=rows(draw_all, e), stat=stat,
+                                    stat_group=e, sums=sm[:2] if sync else None, phase=phase)
+                        e += 1
+
         for i in (2, 1, 0):
             draw = torch.empty_like(d)
-            e = 0
-            while e < E:
-                en = entries[e]
-                nx = entries[e + 1] if e + 1 < E else None
-                if nx is not None and nx["g"] == en["g"] and not (nx["train"] and en["train"]):
-                    # two adjacent blocks through the same forward activations: one pass over them for both; the
-                    # gamma / beta gradients come from whichever of the two trains
-                    ps = 1 if nx["train"] else 0
-                    tr = nx if nx["train"] else en
-                    self.bns[i].backward2(rows(ctx["raws"][i], en["g"]), d[e * B:(e + 2) * B], ctx["svs"][i][en["g"]],
-                                          True, tr["scale"] if tr["train"] else None, out=draw[e * B:(e + 2) * B],
-                                          param_stream=ps, stat=stat, stat_group=e)
-                    e += 2
-                else:
-                    self.bns[i].backward(rows(ctx["raws"][i], en["g"]), rows(d, e), ctx["svs"][i][en["g"]], True,
-                                         en["scale"] if en["train"] else None, out=rows(draw, e), stat=stat,
-                                         stat_group=e)
-                    e += 1
+            bn_backward(self.bns[i], ctx["raws"][i], ctx["svs"][i], d, draw, stat)
             wgrads(self.deconvs[i], ctx["acts"][i], draw)
             _, hi, wi, _ = ctx["acts"][i].shape
             if i > 0:
@@ -397,21 +403,7 @@ class DecoderNet:
         dflat = d.reshape(E * B, -1)
         draw_fc = torch.empty_like(dflat)
         out = {}
-        e = 0
-        while e < E:
-            en = entries[e]
-            nx = entries[e + 1] if e + 1 < E else None
-            if nx is not None and nx["g"] == en["g"] and not (nx["train"] and en["train"]):
-                ps = 1 if nx["train"] else 0
-                tr = nx if nx["train"] else en
-                self.fc_bn.backward2(rows(ctx["raw_fc"], en["g"]), dflat[e * B:(e + 2) * B], ctx["sv_fc"][en["g"]], True,
-                                     tr["scale"] if tr["train"] else None, out=draw_fc[e * B:(e + 2) * B],
-                                     param_stream=ps)
-                e += 2
-            else:
-                self.fc_bn.backward(rows(ctx["raw_fc"], en["g"]), rows(dflat, e), ctx["sv_fc"][en["g"]], True,
-                                    en["scale"] if en["train"] else None, out=rows(draw_fc, e))
-                e += 1
+        bn_backward(self.fc_bn, ctx["raw_fc"], ctx["sv_fc"], dflat, draw_fc, None)
         wgrads(self.fc, ctx["z"], draw_fc)
         for e, en in enumerate(entries):
             if en.get("need_dz"):

@@ -749,10 +749,43 @@ class BatchNorm:
             lib.call("fmri_permute_chw", _P(self.rv_e), _P(self.rv), c0, hw, 0, 1.0, 0)
             self._run_dirty = False
 
+    def forward_groups(self, raws, relu: bool, updates: int, outs, stat_accs, order):
+        """Train-mode forward of several calls of this BatchNorm whose inputs are ready together (the decoder's call groups
+        of one layer), running-statistics updates in ``order``.  Data parallel with SyncBN: the statistics of all calls are
+        exchanged in ONE all-reduce ([G][2][C]) instead of one per call.  Returns the BNSaved of each call."""
+        G = len(raws)
+        svs = [None] * G
+        if self.reducer is None or self.eval_mode:
+            for gi in order:
+                _, svs[gi] = self.forward(raws[gi], relu, updates, out=outs[gi], stat_acc=stat_accs[gi])
+            return svs
+        C = self.C
+        sums_all = torch.empty(G, 2, C, dtype=torch.float32, device=raws[0].device)
+        for gi in range(G):
+            self._forward_sums(raws[gi], stat_accs[gi], sums_all[gi])
+        world = self.reducer(sums_all)
+        for gi in order:
+            _, svs[gi] = self.forward(raws[gi], relu, updates, out=outs[gi], exchanged=(sums_all[gi], world))
+        return svs
+
+    def _forward_sums(self, raw: torch.Tensor, stat_acc, sums: torch.Tensor):
+        """sums [2][C] <- (sum x, sum x^2) of ``raw`` (from the producer's statistics rows where given)."""
+        C = self.C
+        x2 = raw.reshape(-1, C)
+        M = x2.shape[0]
+        if stat_acc is not None:
+            scratch = torch.empty(lib.load().fmri_bn_fold_scratch_floats(C), dtype=torch.float32, device=raw.device)
+            lib.call("fmri_bn_fold", _P(stat_acc), stat_acc.shape[0], C, _P(scratch), _P(sums))
+        else:
+            ws = _reduce_ws(M, C, raw.device)
+            lib.note(bytes=2.0 * M * C)
+            lib.call("fmri_bn_stats", _P(x2), M, C, _P(sums), _P(ws), ws.numel())
+
     def forward(self, raw: torch.Tensor, relu: bool = True, updates: int = 1, out: Optional[torch.Tensor] = None,
-                stat_acc: Optional[torch.Tensor] = None):
+                stat_acc: Optional[torch.Tensor] = None, exchanged=None):
         """``stat_acc``: the batch statistics of ``raw`` as rows [P][2][C] written by the producing kernel's epilogue
-        (``ConvLayer.take_stats``): the statistics pass over ``raw`` is skipped."""
+        (``ConvLayer.take_stats``): the statistics pass over ``raw`` is skipped.  ``exchanged`` = (sums [2][C] already
+        summed over the ranks, world size): ``forward_groups``' second phase."""
         if self.eval_mode:
             return self.forward_eval(raw, relu, out), None
         C = self.C
@@ -760,8 +793,8 @@ class BatchNorm:
         M = x2.shape[0]
         dev = raw.device
         gamma, beta, rm, rv = self._params()
-        sums = torch.empty(2, C, dtype=torch.float32, device=dev)
-        ws = _reduce_ws(M, C, dev) if stat_acc is None else None
+        sums = torch.empty(2, C, dtype=torch.float32, device=dev) if exchanged is None else exchanged[0]
+        ws = _reduce_ws(M, C, dev) if (stat_acc is None and exchanged is None) else None
         count = float(M)
         sv = BNSaved()
         buf = torch.empty(4, C, dtype=torch.float32, device=dev)
@@ -771,7 +804,10 @@ class BatchNorm:
         fin = (_P(gamma), _P(beta), 1e-5, 0.9, updates, _P(rm) if updates > 0 else None,
                _P(rv) if updates > 0 else None, _P(sv.mean), _P(sv.rstd), _P(sv.scale), _P(sv.shift),
                _P(self.nbt) if updates > 0 else None)
-        if stat_acc is not None:
+        if exchanged is not None:
+            count *= exchanged[1]
+            lib.call("fmri_bn_finalize", _P(sums), C, count, *fin)
+        elif stat_acc is not None:
             assert stat_acc.shape[-1] == C and stat_acc.is_contiguous()
             rows = stat_acc.shape[0]
             scratch = torch.empty(lib.load().fmri_bn_fold_scratch_floats(C), dtype=torch.float32, device=dev)
@@ -850,32 +886,39 @@ class BatchNorm:
 
     def backward(self, raw: torch.Tensor, dy: torch.Tensor, sv: BNSaved, relu: bool = True,
                  param_scale: Optional[float] = None, out: Optional[torch.Tensor] = None, stat=None,
-                 stat_group: int = 0):
+                 stat_group: int = 0, sums: Optional[torch.Tensor] = None, phase: int = 3):
         """dx through (ReLU o BN) with batch statistics; if ``param_scale`` is given, gamma/beta grads are
         accumulated as (1/param_scale) * sums.  ``stat``: the reduction already done by the epilogue of the data
-        gradient that produced ``dy`` (group ``stat_group`` of ``ConvLayer.take_bwd_stats()``; dy is then ReLU-masked)."""
+        gradient that produced ``dy`` (group ``stat_group`` of ``ConvLayer.take_bwd_stats()``; dy is then ReLU-masked).
+        ``phase`` 1 = the reduction only (into ``sums``, a caller-owned [2][C] view), 2 = the apply pass only (``sums``
+        already exchanged), 3 = both with this call's own SyncBN exchange in between: a caller with several calls that are
+        ready together (the decoder's call groups of one layer) runs all phase-1 calls, ONE exchange, all phase-2 calls."""
         C = self.C
         x2 = raw.reshape(-1, C)
         g2 = dy.reshape(-1, C)
         M = x2.shape[0]
         gamma, beta, _, _ = self._params()
-        sums = torch.empty(2, C, dtype=torch.float32, device=raw.device)
+        if sums is None:
+            sums = torch.empty(2, C, dtype=torch.float32, device=raw.device)
         # gamma/beta gradients come from the LOCAL sums (the SUM all-reduce of the gradients adds the other ranks); the
         # fold kernel of the reduction accumulates them, the permuted (C,H,W)-ordered BN1d needs the scatter kernel
         direct = param_scale is not None and not self.perm
-        if stat is not None:
-            assert not self.perm
-            self._fold_bwd(stat, stat_group, 1, sums, param_scale, 0)
-        else:
-            ws = _reduce_ws(M, C, raw.device)
-            lib.note(bytes=4.0 * M * C)
-            lib.call("fmri_bn_bwd_reduce", _P(x2), _P(g2), M, C, _P(sv.mean), _P(sv.rstd), _P(gamma), _P(beta),
-                     1 if relu else 0, _P(sums), _P(ws), ws.numel(), _P(self.gbeta) if direct else None,
-                     _P(self.ggamma) if direct else None, (1.0 / param_scale) if direct else 0.0)
-        if param_scale is not None and self.perm:
-            self.accumulate_param_grads(sums, param_scale)
-        if self.reducer is not None:
+        if phase & 1:
+            if stat is not None:
+                assert not self.perm
+                self._fold_bwd(stat, stat_group, 1, sums, param_scale, 0)
+            else:
+                ws = _reduce_ws(M, C, raw.device)
+                lib.note(bytes=4.0 * M * C)
+                lib.call("fmri_bn_bwd_reduce", _P(x2), _P(g2), M, C, _P(sv.mean), _P(sv.rstd), _P(gamma), _P(beta),
+                         1 if relu else 0, _P(sums), _P(ws), ws.numel(), _P(self.gbeta) if direct else None,
+                         _P(self.ggamma) if direct else None, (1.0 / param_scale) if direct else 0.0)
+            if param_scale is not None and self.perm:
+                self.accumulate_param_grads(sums, param_scale)
+        if phase == 3 and self.reducer is not None:
             self.reducer(sums)
+        if not phase & 2:
+            return None, sums
         if out is None:
             out = torch.empty_like(dy)
         lib.note(bytes=6.0 * M * C)
@@ -885,32 +928,37 @@ class BatchNorm:
 
     def backward2(self, raw: torch.Tensor, dy2: torch.Tensor, sv: BNSaved, relu: bool = True,
                   param_scale: Optional[float] = None, out: Optional[torch.Tensor] = None, param_stream: int = 0,
-                  stat=None, stat_group: int = 0):
+                  stat=None, stat_group: int = 0, sums: Optional[torch.Tensor] = None, phase: int = 3):
         """``backward`` for TWO cotangent streams stacked along the rows, ``dy2 = [A rows | B rows]`` (each as many rows
         as ``raw``): the forward tensor, xhat and the ReLU mask are read / computed once for both.  gamma / beta
-        gradients (``param_scale``) are taken from ONE stream (``param_stream``: 0 = A, 1 = B)."""
+        gradients (``param_scale``) are taken from ONE stream (``param_stream``: 0 = A, 1 = B).  ``sums`` ([4][C]) /
+        ``phase``: as in ``backward``."""
         C = self.C
         x2 = raw.reshape(-1, C)
         g2 = dy2.reshape(-1, C)
         M = x2.shape[0]
         assert g2.shape[0] == 2 * M
         gamma, beta, _, _ = self._params()
-        sums = torch.empty(4, C, dtype=torch.float32, device=raw.device)
+        if sums is None:
+            sums = torch.empty(4, C, dtype=torch.float32, device=raw.device)
         pg = param_scale is not None and not self.perm     # (C,H,W)-permuted BN1d: scattered below
-        if stat is not None:
-            # groups stat_group, stat_group + 1 of the producing data gradient's epilogue rows (dy2 is ReLU-masked)
-            assert not self.perm
-            self._fold_bwd(stat, stat_group, 2, sums, param_scale, int(param_stream))
-        else:
-            ws = torch.empty(2 * lib.load().fmri_bn_ws_floats(M, C), dtype=torch.float32, device=raw.device)
-            lib.note(bytes=6.0 * M * C)
-            lib.call("fmri_bn_bwd_reduce2", _P(x2), _P(g2), M, C, _P(sv.mean), _P(sv.rstd), _P(gamma), _P(beta),
-                     1 if relu else 0, _P(sums), _P(ws), ws.numel(), _P(self.gbeta) if pg else None,
-                     _P(self.ggamma) if pg else None, (1.0 / param_scale) if pg else 0.0, int(param_stream))
-        if param_scale is not None and self.perm:
-            self.accumulate_param_grads(sums[2 * int(param_stream):2 * int(param_stream) + 2], param_scale)
-        if self.reducer is not None:
+        if phase & 1:
+            if stat is not None:
+                # groups stat_group, stat_group + 1 of the producing data gradient's epilogue rows (dy2 is ReLU-masked)
+                assert not self.perm
+                self._fold_bwd(stat, stat_group, 2, sums, param_scale, int(param_stream))
+            else:
+                ws = torch.empty(2 * lib.load().fmri_bn_ws_floats(M, C), dtype=torch.float32, device=raw.device)
+                lib.note(bytes=6.0 * M * C)
+                lib.call("fmri_bn_bwd_reduce2", _P(x2), _P(g2), M, C, _P(sv.mean), _P(sv.rstd), _P(gamma), _P(beta),
+                         1 if relu else 0, _P(sums), _P(ws), ws.numel(), _P(self.gbeta) if pg else None,
+                         _P(self.ggamma) if pg else None, (1.0 / param_scale) if pg else 0.0, int(param_stream))
+            if param_scale is not None and self.perm:
+                self.accumulate_param_grads(sums[2 * int(param_stream):2 * int(param_stream) + 2], param_scale)
+        if phase == 3 and self.reducer is not None:
             self.reducer(sums)
+        if not phase & 2:
+            return None, sums
         if out is None:
             out = torch.empty_like(dy2)
         lib.note(bytes=10.0 * M * C)

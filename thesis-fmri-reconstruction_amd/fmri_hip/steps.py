@@ -171,8 +171,7 @@ class _Dist:
         # all-reduce that is itself waiting for the side stream's weight gradients, a 40-byte all-reduce of the main
         # stream would stall the whole backward pass (head-of-line blocking); on a second communicator it does not.
         self.small = dist.new_group() if self.on else None
-
-    recorder: Optional[_SegmentRecorder] = None
+        self.recorder: Optional[_SegmentRecorder] = None     # set while a step is recorded into graph segments
 
     SMALL = 1 << 16          # elements: at most this many go through the small-message communicator
 

@@ -856,6 +856,10 @@ class BatchNorm:
         self._running_in()
         scale = (gamma * torch.rsqrt(rv + 1e-5)).contiguous()
         shift = (beta - rm * scale).contiguous()
+        if self.C % 8:                  # the kernels read these vectors in 16-byte groups up to the PADDED channel count
+            pad = 8 - self.C % 8
+            scale = torch.nn.functional.pad(scale, (0, pad))
+            shift = torch.nn.functional.pad(shift, (0, pad))
         return scale, shift, relu
 
     def forward_eval(self, raw: torch.Tensor, relu: bool = True, out: Optional[torch.Tensor] = None):
@@ -1137,6 +1141,8 @@ class HostStager:
         self.pinned = [torch.empty(capacity, dtype=torch.uint8).pin_memory() for _ in range(depth)]
         self.dev = [torch.empty(capacity, dtype=torch.uint8, device=self.device) for _ in range(depth)]
         self.free_evt = [None] * depth            # recorded when the side stream is done with slot i
+        # pinned per-slot metadata (byte offsets, (H, W, C) per image), grown on demand: no pin_memory() per submit
+        self.meta = [None] * depth
         self.slot = 0
         self.tickets = {}
         self.next_ticket = 0
@@ -1162,8 +1168,14 @@ class HostStager:
             dims.append(a.shape)
             pos += (nb + 15) // 16 * 16
         N = len(offs)
-        meta = torch.tensor(offs, dtype=torch.int64).pin_memory()
-        dm = torch.tensor(dims, dtype=torch.int32).pin_memory()
+        slot_meta = self.meta[i]
+        if slot_meta is None or slot_meta[0].numel() < N:
+            cap = max(N, 256)
+            slot_meta = self.meta[i] = (torch.empty(cap, dtype=torch.int64).pin_memory(),
+                                        torch.empty(cap, 3, dtype=torch.int32).pin_memory())
+        meta, dm = slot_meta[0][:N], slot_meta[1][:N]
+        meta.copy_(torch.tensor(offs, dtype=torch.int64))
+        dm.copy_(torch.tensor(dims, dtype=torch.int32))
         cur = torch.cuda.current_stream(self.device)
         self.stream.wait_stream(cur)              # allocations made below are ordered after the caller's frees
         with torch.cuda.stream(self.stream):
@@ -1172,6 +1184,11 @@ class HostStager:
             dims_d = dm.to(self.device, non_blocking=True)
             u8 = crop_resize_u8(self.dev[i], offs_d, dims_d, self.crop, self.size)
             x16, x32 = ingest_u8(u8, self.mean, self.std, flip, shift, want16, want32)
+            # caller-allocated per-image draws: read here on the staging stream -- tell the allocator, or their storage
+            # could be handed to later work of the caller's stream while these kernels still read it
+            for t in (flip, shift):
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(self.stream)
             done = torch.cuda.Event()
             done.record(self.stream)
         self.free_evt[i] = done

@@ -184,6 +184,7 @@ class _DecoderFn(Function):
 
 # FMRI_API_REUSE=off: every call recomputes (A/B timing of the two reuse paths below; results are identical)
 import os as _os
+import weakref
 _REUSE = _os.environ.get("FMRI_API_REUSE") != "off"
 
 
@@ -220,8 +221,11 @@ class _DiscriminatorFn(Function):
         # re-used for other data in between; any in-place write changes ``_version`` and invalidates it.
         memo = mod.__dict__.get("_memo")
         key = (id(xo), xo._version, id(xp), xp._version, id(xs), xs._version, net.group.version, mod.training)
+        # the memo holds WEAK references to the three inputs (a strong one to ``xp`` would keep the whole autograd graph
+        # behind it -- encoder, decoder and their saved activations -- alive until the next discriminator call): a dead
+        # reference, i.e. an ``id`` that may have been re-used, never matches
         if (_REUSE and mode == "GAN" and net.level == 3 and memo is not None and memo["key"] == key
-                and memo["xs"][0] is xo and memo["xs"][1] is xp and memo["xs"][2] is xs):
+                and memo["xs"][0]() is xo and memo["xs"][1]() is xp and memo["xs"][2]() is xs):
             sctx = dict(memo["sctx"])                 # own dict: the head's entries belong to this call
             mod.__dict__["_memo"] = None
             if mod.training:
@@ -235,7 +239,8 @@ class _DiscriminatorFn(Function):
                 feat, _, sctx = net.forward(d, conv_updates=1, head=False)
                 ctx.sctx = sctx
                 # (recon_level < 3: the REC pass stopped below the last block, a GAN call starts over)
-                mod.__dict__["_memo"] = dict(key=key, xs=(xo, xp, xs), sctx=sctx) if net.level == 3 else None
+                mod.__dict__["_memo"] = (dict(key=key, xs=tuple(weakref.ref(t) for t in (xo, xp, xs)), sctx=sctx)
+                                         if net.level == 3 else None)
                 return _ops.nhwc_to_images(feat, feat.shape[-1]).reshape(3 * B, -1)
             mod.__dict__["_memo"] = None
             _, logit32, sctx = net.forward(d, conv_updates=1, fc_updates=1)
@@ -255,7 +260,10 @@ class _DiscriminatorFn(Function):
             return none
         # a second traversal with a scalar multiple of the cotangent of the first one (same weights, same
         # requires_grad pattern): its results times that scalar
-        sig = (train, ctx.needs, tuple(p.requires_grad for p in ctx.params), net.group.version)
+        # (the live ``_version`` sum of the parameters: an optimizer step BETWEEN two backward calls on the same forward
+        # changes the weights without passing through ``_engine()``, which is where ``group.version`` is refreshed)
+        sig = (train, ctx.needs, tuple(p.requires_grad for p in ctx.params), net.group.version,
+               sum(p._version for p in ctx.params))
         c = ctx.cache
         if _REUSE and c is not None and c["sig"] == sig:
             r, ok = _same_direction(dout, c["dout"])

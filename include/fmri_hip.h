@@ -266,6 +266,11 @@ int fmri_act_bwd(const void* y, const void* dy, void* dpre, int M, int C, int ac
  * layers (column sums of the cotangent rows, what autograd's Linear backward reduces) in one launch, fixed-order sums. */
 int fmri_colsum_acc(const void* src, int is_f16, int M, int C, int64_t ld_row, int64_t ld_col, float scale, float* dst,
                     void* stream);
+/* The many-row form for contiguous fp16 rows [M][C], C % 8 == 0 (the bias gradient of discriminator.conv.0 over
+ * 3B x 64 x 64 pixels): per-block partial sums in `ws` (fmri_bn_ws_floats(M, C) floats) + fold; sums2C receives
+ * [sum x | sum x^2], dbias[c] += gscale * sum x[c] for c < dbias_n (dbias may be NULL). */
+int fmri_colsum_rows(const void* x16, int M, int C, float* sums2C, float* ws, int64_t ws_floats, float* dbias,
+                     int dbias_n, float gscale, void* stream);
 
 /* ---- latent / losses (models/vae_gan.py:266-269, :302-320; train_vgan_stage1.py:368-404) ----------- */
 int fmri_latent_fwd(const float* head, const float* eps, int B, int Z, int zp, void* z16, float* kl_rows,

@@ -800,6 +800,11 @@ int fmri_act_bwd(const void* y, const void* dy, void* dpre, int M, int C, int ac
     return act_bwd_launch((const half_t*)y, (const half_t*)dy, (half_t*)dpre, M, C, act, colsum2C, ws, ws_floats, dbias,
                           dbias_n, gscale, S(stream));
 }
+int fmri_colsum_rows(const void* x16, int M, int C, float* sums2C, float* ws, int64_t ws_floats, float* dbias,
+                     int dbias_n, float gscale, void* stream) {
+    if (!x16 || !sums2C || !ws || M < 1 || C < 8 || (C & 7) || (dbias && (dbias_n < 1 || dbias_n > C))) return FMRI_E_BADARG;
+    return colsum_rows_launch((const half_t*)x16, M, C, sums2C, ws, ws_floats, dbias, dbias_n, gscale, S(stream));
+}
 int fmri_colsum_acc(const void* src, int is_f16, int M, int C, int64_t ld_row, int64_t ld_col, float scale, float* dst,
                     void* stream) {
     if (!src || !dst || M < 1 || C < 1) return FMRI_E_BADARG;

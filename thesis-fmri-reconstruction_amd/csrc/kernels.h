@@ -92,6 +92,8 @@ int bn_bwd_apply_launch(const half_t* x, const half_t* dy, half_t* dx, int M, in
                         hipStream_t st);
 int act_bwd_launch(const half_t* y, const half_t* dy, half_t* dpre, int M, int C, int act, float* colsum, float* ws,
                    int64_t ws_floats, float* dbias, int dbias_n, float gscale, hipStream_t st);
+int colsum_rows_launch(const half_t* x, int M, int C, float* sums2C, float* ws, int64_t ws_floats, float* dbias,
+                       int dbias_n, float gscale, hipStream_t st);
 int colsum_acc_launch(const void* src, int is_f16, int M, int C, int64_t ld_row, int64_t ld_col, float scale, float* dst,
                       hipStream_t st);
 

@@ -613,6 +613,13 @@ int bn_stats_launch(const half_t* x, int M, int C, float* sums, float* ws, int64
     return reduce_launch<0>(x, nullptr, nullptr, M, C, nullptr, nullptr, nullptr, nullptr, 0, sums, ws, ws_floats,
                             st);
 }
+// column sums of fp16 rows [M][C] (C % 8 == 0) through the statistics reduction: sums2C = [sum x | sum x^2]; dbias (may be
+// null): dbias[c] += gscale * sum x[c], c < dbias_n.  The many-row form of colsum_acc_launch (layout.hip).
+int colsum_rows_launch(const half_t* x, int M, int C, float* sums2C, float* ws, int64_t ws_floats, float* dbias,
+                       int dbias_n, float gscale, hipStream_t st) {
+    return reduce_launch<0>(x, nullptr, nullptr, M, C, nullptr, nullptr, nullptr, nullptr, 0, sums2C, ws, ws_floats, st, dbias,
+                            nullptr, gscale, dbias_n);
+}
 int bn_bwd_reduce_launch(const half_t* x, const half_t* dy, int M, int C, const float* mean, const float* rstd,
                          const float* gamma, const float* beta, int relu, float* sums, float* ws, int64_t ws_floats,
                          float* dbeta, float* dgamma, float gscale, hipStream_t st) {

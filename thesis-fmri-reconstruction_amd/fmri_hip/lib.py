@@ -58,6 +58,7 @@ _SIGS = {
     "fmri_bn_bwd_apply2": [_p, _p, _p, _i, _i, _f, _p, _p, _p, _p, _i, _p, _p],
     "fmri_act_bwd": [_p, _p, _p, _i, _i, _i, _p, _p, _l, _p, _i, _f, _p],
     "fmri_colsum_acc": [_p, _i, _i, _i, _l, _l, _f, _p, _p],
+    "fmri_colsum_rows": [_p, _i, _i, _p, _p, _l, _p, _i, _f, _p],
     "fmri_latent_fwd": [_p, _p, _i, _i, _i, _p, _p, _p, _i, _p],
     "fmri_latent_bwd": [_p, _p, _p, _i, _f, _f, _p, _i, _i, _f, _p, _p, _i, _p],
     "fmri_feat_mse": [_p, _i, _i, _p, _p, _p],

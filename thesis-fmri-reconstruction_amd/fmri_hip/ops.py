@@ -1038,7 +1038,15 @@ def act_backward(y: torch.Tensor, dy: torch.Tensor, act: int, colsum: Optional[t
 
 
 def colsum_acc(src: torch.Tensor, M: int, C: int, ld_row: int, ld_col: int, scale: float, dst: torch.Tensor):
-    """dst[c] += scale * sum_{m < M} src[m*ld_row + c*ld_col] (csrc/layout.hip; bias gradients)."""
+    """dst[c] += scale * sum_{m < M} src[m*ld_row + c*ld_col] (bias gradients).  A few hundred rows (dense layers, the
+    narrow weight-gradient kernel's slabs): one small launch (csrc/layout.hip); many contiguous fp16 rows (a conv
+    cotangent): the BatchNorm statistics reduction with the accumulation in its fold (csrc/norm.hip)."""
+    if M >= 2048 and src.dtype == torch.float16 and ld_col == 1 and ld_row % 8 == 0 and src.is_contiguous():
+        ws = _reduce_ws(M, ld_row, src.device)
+        sums = torch.empty(2, ld_row, dtype=torch.float32, device=src.device)
+        lib.note(bytes=2.0 * M * ld_row)
+        lib.call("fmri_colsum_rows", _P(src), M, ld_row, _P(sums), _P(ws), ws.numel(), _P(dst), C, float(scale))
+        return
     lib.call("fmri_colsum_acc", _P(src), 1 if src.dtype == torch.float16 else 0, M, C, ld_row, ld_col, float(scale),
              _P(dst))
 

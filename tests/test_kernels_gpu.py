@@ -840,3 +840,48 @@ def test_conv_epilogue_eval_batchnorm(kind, cin, cout, H, op, N, expect):
     lim = 2e-3 * ref.float().abs() + 2e-3 * float(ref.float().pow(2).mean().sqrt())
     assert (err <= lim).all(), float(err.max())
     assert (fused >= 0).all()
+
+
+def test_output_stores_survive_memory_contention():
+    """gfx950 store-data hazard, timing-dependent form (csrc/common.h FMRI_STORE_FENCE): the loader
+    waves' `buffer_store_dwordx4 ..., sN offen` followed by a VALU write of the first data register stored a wrong first
+    dword in 268 of 400 launches of igemm_tc5w<8,0,solo> -- but only while a kernel on another stream kept the memory
+    system busy, so no single-stream parity test could see it.  Here the data gradient of discriminator.conv.3 at the
+    size that showed it (and the statistics forward of decoder.conv.0, the other solo instantiation) runs 120 times
+    beside a weight-gradient kernel on a second stream; every output must equal the idle-GPU result bit for bit."""
+    from fmri_hip.ops import ConvLayer
+    from fmri_hip import ops
+    torch.manual_seed(3)
+    side = torch.cuda.Stream()
+    wl = ConvLayer(_G({"w": _h(torch.randn(256, 256, 5, 5) * 0.05)}), "w", None, "conv", 256, 256, 5, 2, 2)
+    wx = torch.randn(96, 16, 16, 256, device=DEV).half()
+    wdy = torch.randn(96, 8, 8, 256, device=DEV).half()
+    side_was, ops._SIDE["on"] = ops._SIDE["on"], False
+    try:
+        for kind, cin, cout, H, N, what in (("conv", 256, 256, 16, 40, "dgrad"), ("deconv", 256, 256, 8, 24, "fwd")):
+            shape = (cout, cin, 5, 5) if kind == "conv" else (cin, cout, 5, 5)
+            L = ConvLayer(_G({"w": _h(torch.randn(*shape) * 0.05)}), "w", None, kind, cin, cout, 5, 2, 2,
+                          1 if kind == "deconv" else 0)
+            Ho, Wo = L.out_hw(H, H)
+            if what == "dgrad":
+                inp = (torch.randn(N, Ho, Wo, L.coutp, device=DEV) * 0.5).half()
+                run = lambda out: L.dgrad(inp, H, H, out=out)
+                ref = torch.empty(N, H, H, L.cinp, dtype=torch.float16, device=DEV)
+            else:
+                inp = torch.randn(N, H, H, L.cinp, device=DEV).half()
+                run = lambda out: L.forward(inp, out=out, bn_groups=1)
+                ref = torch.empty(N, Ho, Wo, L.coutp, dtype=torch.float16, device=DEV)
+            run(ref)
+            torch.cuda.synchronize()
+            ring = [torch.empty_like(ref) for _ in range(4)]
+            bad = 0
+            for it in range(120):
+                with torch.cuda.stream(side):
+                    wl._wgrad(wx, wdy, 1.0)
+                run(ring[it % 4])
+                if it % 4 == 3:
+                    torch.cuda.synchronize()
+                    bad += sum(int(not torch.equal(o, ref)) for o in ring)
+            assert bad == 0, (kind, what, bad)
+    finally:
+        ops._SIDE["on"] = side_was

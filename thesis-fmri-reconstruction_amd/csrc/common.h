@@ -26,12 +26,17 @@ enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2, ACT_SIGMOID = 3 };
 // busy (tools/probes/store_hazard_stress.py).  Every such store is therefore followed by two wait states that the
 // scheduler may not move: FMRI_STORE_FENCE().  tools/scan_store_hazard.py (a build step, fmri_hip/build.py) counts the wait
 // states behind every wide VMEM store of the library and fails the build on fewer than two.
+// (-DFMRI_NO_STORE_FENCE builds the library without it: tools/probes/build_variant.sh, to show that the tests catch it.)
+#ifndef FMRI_NO_STORE_FENCE
 #define FMRI_STORE_FENCE()                        \
     do {                                          \
         __builtin_amdgcn_sched_barrier(0);        \
         asm volatile("s_nop 1" ::: "memory");     \
         __builtin_amdgcn_sched_barrier(0);        \
     } while (0)
+#else
+#define FMRI_STORE_FENCE() do { } while (0)
+#endif
 
 // error codes of the C ABI (include/fmri_hip.h)
 enum Err { OK = 0, E_BADARG = -1, E_UNSUPPORTED = -2, E_LAUNCH = -3, E_WORKSPACE = -4 };

@@ -92,6 +92,68 @@ def cpu_baseline(batch: int, steps: int):
                           dict(variant="literal", batch=256, steps=n_big, value=round(v_big, 3))])
 
 
+def _family_traffic(kernels, family):
+    """Launch-weighted bytes per launch of the kernel family ``family`` in a tools/pmc_traffic.py-style table."""
+    want = family.replace(" ", "")
+    tot = cnt = 0
+    for kname, v in kernels.items():
+        n = kname.replace(" ", "")
+        n = n[4:] if n.startswith("void") else n
+        n = n.split("(")[0].split("<")[0]
+        if n == want:
+            tot += v["bytes_per_launch"] * v["launches"]
+            cnt += v["launches"]
+    return int(tot / cnt) if cnt else None
+
+
+def live_pmc_traffic(family, timeout_s=120):
+    """The traffic counters of THIS box: two rocprofv3 child runs of this script (``--pmc FETCH_SIZE`` and ``--pmc
+    WRITE_SIZE``, each its own run with ``--kernel-trace`` only, five eagerly issued one-stream steps) summarised like
+    tools/pmc_traffic.py: (2 * FETCH_SIZE + WRITE_SIZE) * 1024 per launch of the family (KiB units, the gfx950 read
+    correction: MI355X_MICROARCH.md).  Children, never an exec; None when rocprofv3 is missing, a pass fails or times out
+    (the committed passes of the same command are the fallback)."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None
+    tmp = tempfile.mkdtemp(prefix="fmri_pmc_", dir="/tmp")
+    per = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [rocprof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "x", "--",
+                   sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "2", "--eager", "--serial",
+                   "--no-cpu-baseline", "--no-hbm-rows", "--no-pmc"]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=timeout_s,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            files = [os.path.join(d, f) for d, _, fs in os.walk(out) for f in fs if f.endswith("counter_collection.csv")]
+            if r.returncode != 0 or not files:
+                log(f"pmc pass {counter}: rc {r.returncode}, {len(files)} counter files")
+                return None
+            acc = {}
+            for row in csv.DictReader(open(files[0])):
+                if row["Counter_Name"] == counter:
+                    a = acc.setdefault(row["Kernel_Name"], [0, 0.0])
+                    a[0] += 1
+                    a[1] += float(row["Counter_Value"])
+            per[counter] = acc
+        kernels = {}
+        for name in set(per["FETCH_SIZE"]) | set(per["WRITE_SIZE"]):
+            nf, kf = per["FETCH_SIZE"].get(name, (0, 0.0))
+            nw, kw = per["WRITE_SIZE"].get(name, (0, 0.0))
+            kernels[name] = {"launches": max(nf, nw),
+                             "bytes_per_launch": 2.0 * 1024.0 * kf / max(nf, 1) + 1024.0 * kw / max(nw, 1)}
+        return _family_traffic(kernels, family)
+    except (subprocess.TimeoutExpired, OSError, KeyError, ValueError) as e:
+        log(f"live pmc passes failed: {type(e).__name__}: {e}")
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def pmc_traffic(family):
     """(2*FETCH_SIZE + WRITE_SIZE) * 1024 per launch of the kernel family ``family`` (kernel name without template
     arguments), launch-weighted over its instantiations, from the committed rocprofv3 PMC passes of this same command
@@ -337,6 +399,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="samples per GPU (weak scaling); 0 = the workload's own")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-rows", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="do not run the two rocprofv3 counter passes for roofline.traffic (then the committed passes of "
+                         "the same command under profiles/ are quoted)")
     ap.add_argument("--sync-bn", action="store_true",
                     help="data-parallel runs: all-reduce the BatchNorm partial sums (statistics of the GLOBAL batch, one "
                          "small collective per BatchNorm call).  Default: per-rank statistics over the rank's own batch, "
@@ -519,7 +584,12 @@ def main():
             achieved = tf["bytes"] / (tf["ms_b"] * 1e-3) / 1e9 if tf["ms_b"] > 0 else 0.0
             peak, runit = HBM_PEAK_GBS, "GB/s"
         # the committed PMC passes are of the Stage-I workload: no traffic figure for the other workloads
-        traffic, traffic_src = pmc_traffic(label) if a.workload == "stage1" else (None, None)
+        traffic, traffic_src = None, None
+        if a.workload == "stage1" and world == 1 and not a.no_pmc:
+            traffic = live_pmc_traffic(label)
+            traffic_src = "live" if traffic else None
+        if traffic is None and a.workload == "stage1":
+            traffic, traffic_src = pmc_traffic(label)
         alg_bytes = int(tf["bytes"] / nl) if tf["bytes"] > 0 else None
         lib_ms = sum(f["ms"] for _, f in fams) / ps
         finite = all(np.isfinite(v) for v in logs.values() if isinstance(v, float))
@@ -534,10 +604,12 @@ def main():
                          "unit": runit, "frac": round(achieved / peak, 4), "traffic": traffic,
                          "algorithmic_bytes": alg_bytes,
                          "traffic_over_algorithmic": round(traffic / alg_bytes, 2) if traffic and alg_bytes else None,
-                         "traffic_unit": "bytes per launch leaving L2, (2*FETCH_SIZE + WRITE_SIZE)*1024 of the rocprofv3 "
-                                         f"PMC passes of this workload committed as profiles/{traffic_src} (hardware "
-                                         "counters cannot be read in-process); algorithmic_bytes = input + output + "
-                                         "weights once, per launch" if traffic else None,
+                         "traffic_unit": ("bytes per launch leaving L2, (2*FETCH_SIZE + WRITE_SIZE)*1024, "
+                                          + ("measured on THIS box by two rocprofv3 --pmc child passes of this script "
+                                             "(FETCH_SIZE, WRITE_SIZE: separate runs, --kernel-trace only, 5 one-stream steps)"
+                                             if traffic_src == "live" else
+                                             f"of the rocprofv3 PMC passes of this workload committed as profiles/{traffic_src}")
+                                          + "; algorithmic_bytes = input + output + weights once, per launch") if traffic else None,
                          "kernel": label,
                          "measured": "HIP events around each library launch, 5 steps issued on ONE stream (the timed "
                                      "region overlaps weight gradients on a second stream when launched eagerly); the "

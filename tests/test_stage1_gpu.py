@@ -69,7 +69,13 @@ def _run_engine(cfg_e, B, seed, perturb, steps, noise, x, masks_out=None):
     return outs
 
 
-@pytest.mark.parametrize("arch,B,seed,perturb", [("px64", 4, 0, True), ("px100", 4, 3, True)])
+# (B = 5, 7: the last, partial batch of an epoch -- the reference's DataLoader does not drop it, train_vgan_stage1.py:195 --
+# is rarely a multiple of the four-image tiles of the 8 x 8 layers.  Not B = 3: BatchNorm statistics over three samples
+# leave features whose batch variance is within fp16 rounding of zero, and one ulp of the stored pre-activation then
+# moves xhat by O(1) -- the engine's gradients read 2 % off the 16-bit-storage oracle there, uniformly, without any
+# element being wrong.)
+@pytest.mark.parametrize("arch,B,seed,perturb", [("px64", 4, 0, True), ("px100", 4, 3, True), ("px64", 5, 1, True),
+                                                 ("px64", 7, 2, True)])
 def test_stage1_step_matches_oracle(arch, B, seed, perturb):
     from oracle import vaegan_oracle as O
     from fmri_hip.params import ArchConfig

@@ -106,7 +106,7 @@ def _family_traffic(kernels, family):
     return int(tot / cnt) if cnt else None
 
 
-def live_pmc_traffic(family, timeout_s=120):
+def live_pmc_traffic(family, timeout_s=75):
     """The traffic counters of THIS box: two rocprofv3 child runs of this script (``--pmc FETCH_SIZE`` and ``--pmc
     WRITE_SIZE``, each its own run with ``--kernel-trace`` only, five eagerly issued one-stream steps) summarised like
     tools/pmc_traffic.py: (2 * FETCH_SIZE + WRITE_SIZE) * 1024 per launch of the family (KiB units, the gfx950 read

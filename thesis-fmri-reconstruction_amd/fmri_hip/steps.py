@@ -481,10 +481,8 @@ class Stage1Step(_GanStepBase):
         for n in (self.enc, self.dec, self.dis):
             n.group.zero_grad()
         dlogit16, dfeat16 = self._start_cotangents(fw["feat"], fw["logit32"], B)
-        # weight gradients run on the side stream (ops.side_run).  One GPU: they are joined once, at the end of the
-        # backward pass, so that a sub-network's last weight gradients overlap the next one's backward.  Data parallel:
-        # joined per sub-network, because its gradient reduction starts as soon as its buffer is final and runs under
-        # the backward of the next one (discriminator 43.8 MB -> decoder 18.8 MB -> encoder fc tail 67 MB -> rest)
+        # weight gradients run on the side stream (ops.side_run) and are joined once, at the end of the backward pass, so
+        # that a sub-network's last weight gradients overlap the next one's backward
         dp = self.dd.on
         # ``early``: a sub-network's gradient reduction (data parallel), optimizer update and weight repack are queued on the
         # SIDE stream right behind its last weight gradient -- the main stream neither joins the side stream nor waits for

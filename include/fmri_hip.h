@@ -222,6 +222,18 @@ int fmri_bn_stats_finalize(const void* x, int M, int C, float* sums2C, float* ws
                            const float* gamma, const float* beta, float eps, float momentum, int updates,
                            float* running_mean, float* running_var, float* mean, float* rstd, float* scale,
                            float* shift, int64_t* num_batches_tracked, void* stream);
+/* BatchNorm over FEW rows in ONE launch per direction (the BatchNorm1d layers behind the dense layers,
+ * models/vae_gan.py:81,108,158,200: M = batch rows): a block owns 32 channels for all rows -- statistics, finalize
+ * (incl. the running statistics and num_batches_tracked, `updates` momentum updates), apply / the backward constants,
+ * parameter gradients and dx.  fmri_bn_cols_fwd = fmri_bn_stats_finalize + fmri_bn_apply; fmri_bn_cols_bwd (nstreams 1
+ * or 2 cotangent streams stacked along the rows, sums [nstreams][2][C], dbeta / dgamma += gscale * sums of stream
+ * param_stream, may be NULL) = fmri_bn_bwd_reduce(2) + fmri_bn_bwd_apply(2).  Fixed summation order. */
+int fmri_bn_cols_fwd(const void* x, void* y, int M, int C, float count, const float* gamma, const float* beta, float eps,
+                     float momentum, int updates, float* running_mean, float* running_var, float* mean, float* rstd,
+                     float* scale, float* shift, float* sums2C, int64_t* num_batches_tracked, int relu, void* stream);
+int fmri_bn_cols_bwd(const void* x, const void* dy, void* dx, int M, int C, int nstreams, float count, const float* mean,
+                     const float* rstd, const float* gamma, const float* beta, int relu, float* sums, float* dbeta,
+                     float* dgamma, float gscale, int param_stream, void* stream);
 /* The statistics rows a contraction's epilogue wrote (fmri_igemm_ep: stat_part [rows][2][C] of ONE group) folded into
  * sums2C and finalized like fmri_bn_finalize; scratch: fmri_bn_fold_scratch_floats(C) floats (two-stage fold of long
  * row lists).  fmri_bn_fold only folds (data-parallel runs all-reduce sums2C before fmri_bn_finalize). */

@@ -739,6 +739,24 @@ int fmri_bn_stats_finalize(const void* x, int M, int C, float* sums2C, float* ws
                                     updates, running_mean, running_var, mean, rstd, scale, shift,
                                     (long long*)num_batches_tracked, S(stream));
 }
+int fmri_bn_cols_fwd(const void* x, void* y, int M, int C, float count, const float* gamma, const float* beta, float eps,
+                     float momentum, int updates, float* running_mean, float* running_var, float* mean, float* rstd,
+                     float* scale, float* shift, float* sums2C, int64_t* num_batches_tracked, int relu, void* stream) {
+    if (!x || !y || !sums2C || (C & 7) || C < 8 || M < 1 || !gamma || !beta || !mean || !rstd || !scale || !shift)
+        return FMRI_E_BADARG;
+    return bn_cols_fwd_launch((const half_t*)x, (half_t*)y, M, C, count, gamma, beta, eps, momentum, updates, running_mean,
+                              running_var, mean, rstd, scale, shift, sums2C, (long long*)num_batches_tracked, relu,
+                              S(stream));
+}
+int fmri_bn_cols_bwd(const void* x, const void* dy, void* dx, int M, int C, int nstreams, float count, const float* mean,
+                     const float* rstd, const float* gamma, const float* beta, int relu, float* sums, float* dbeta,
+                     float* dgamma, float gscale, int param_stream, void* stream) {
+    if (!x || !dy || !dx || !sums || (C & 7) || C < 8 || M < 1 || !mean || !rstd || !gamma || !beta || count <= 0.f ||
+        param_stream < 0 || param_stream >= nstreams)
+        return FMRI_E_BADARG;
+    return bn_cols_bwd_launch((const half_t*)x, (const half_t*)dy, (half_t*)dx, M, C, nstreams, count, mean, rstd, gamma,
+                              beta, relu, sums, dbeta, dgamma, gscale, param_stream, S(stream));
+}
 int fmri_bn_fold_finalize(const float* stat_part, int rows, int C, float* scratch, float* sums2C, float count,
                           const float* gamma, const float* beta, float eps, float momentum, int updates,
                           float* running_mean, float* running_var, float* mean, float* rstd, float* scale, float* shift,

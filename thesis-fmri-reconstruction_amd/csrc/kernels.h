@@ -85,6 +85,12 @@ int bn_bwd_fold_launch(const float* part, int rows, int rows_cap, int C, int G, 
 int bn_finalize_launch(const float* sums, int C, float count, const float* gamma, const float* beta, float eps,
                        float momentum, int updates, float* rm, float* rv, float* mean, float* rstd, float* scale,
                        float* shift, long long* nbt, hipStream_t st);
+int bn_cols_fwd_launch(const half_t* x, half_t* y, int M, int C, float count, const float* gamma, const float* beta,
+                       float eps, float momentum, int updates, float* rm, float* rv, float* mean, float* rstd,
+                       float* scale, float* shift, float* sums2C, long long* nbt, int relu, hipStream_t st);
+int bn_cols_bwd_launch(const half_t* x, const half_t* dy, half_t* dx, int M, int C, int nstreams, float count,
+                       const float* mean, const float* rstd, const float* gamma, const float* beta, int relu, float* sums,
+                       float* dbeta, float* dgamma, float gscale, int pstream, hipStream_t st);
 int bn_apply_launch(const half_t* x, half_t* y, int M, int C, const float* scale, const float* shift, int relu,
                     hipStream_t st);
 int bn_bwd_apply_launch(const half_t* x, const half_t* dy, half_t* dx, int M, int C, float count, const float* mean,

@@ -523,6 +523,162 @@ __global__ __launch_bounds__(256) void bn_stream2_kernel(const half_t* __restric
     }
 }
 
+// ---- BatchNorm over FEW rows (the dense layers: BatchNorm1d behind fc.0 / fc1.0, M = batch rows) in ONE launch per
+// direction.  The streaming kernels above pay three launches per call (partial sums, fold, apply) -- 15-20 us for half a
+// megabyte of data, six times per step and direction.  Here a block owns 32 channels (4 chunk columns x 64 row lanes) for
+// all rows: pass 1 sums its columns, the block folds them in LDS and finalizes (mean, rstd, scale, shift, running
+// statistics / the backward constants and the parameter gradients), pass 2 re-reads the rows (L2) and writes the result.
+// Fixed summation order: bit-reproducible.
+constexpr int COLS_CX = 4, COLS_RY = 64;
+
+// dst[16] <- sums of the 16 per-thread values of chunk column cx over the row lanes (called by threads < COLS_CX * 16)
+__device__ __forceinline__ float cols_fold(const float* red, int cx, int j) {
+    float s = 0.f;
+    for (int r = 0; r < COLS_RY; ++r) s += red[((r * COLS_CX) + cx) * 17 + j];
+    return s;
+}
+
+__global__ __launch_bounds__(256) void bn_cols_fwd_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, int M,
+                                                          int C, float count, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps, float momentum,
+                                                          int updates, float* __restrict__ running_mean,
+                                                          float* __restrict__ running_var, float* __restrict__ mean_out,
+                                                          float* __restrict__ rstd_out, float* __restrict__ scale_out,
+                                                          float* __restrict__ shift_out, float* __restrict__ sums,
+                                                          long long* __restrict__ nbt, int relu) {
+    __shared__ float red[256 * 17];
+    __shared__ float par[COLS_CX * 8][2];
+    const int cx = threadIdx.x & (COLS_CX - 1), ry = threadIdx.x >> 2;
+    const int chunk = blockIdx.x * COLS_CX + cx;
+    const int nch = C >> 3;
+    const int64_t coff = (int64_t)chunk * 8;
+    float s0[8], s1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s0[j] = 0.f; s1[j] = 0.f; }
+    if (chunk < nch)
+        for (int m = ry; m < M; m += COLS_RY) {
+            const h8 v = *(const h8*)(x + (int64_t)m * C + coff);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; s0[j] += f; s1[j] += f * f; }
+        }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[threadIdx.x * 17 + j] = s0[j]; red[threadIdx.x * 17 + 8 + j] = s1[j]; }
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0 && nbt && updates > 0) *nbt += updates;      // num_batches_tracked
+    if (threadIdx.x < COLS_CX * 8) {
+        const int c_ = threadIdx.x >> 3, j = threadIdx.x & 7;
+        const int c = (blockIdx.x * COLS_CX + c_) * 8 + j;
+        if (c < C) {
+            const float sx = cols_fold(red, c_, j), sxx = cols_fold(red, c_, 8 + j);
+            sums[c] = sx;
+            sums[C + c] = sxx;
+            bn_finalize_channel(c, sx, sxx, count, gamma, beta, eps, momentum, updates, running_mean, running_var, mean_out,
+                                rstd_out, scale_out, shift_out);
+            par[threadIdx.x][0] = scale_out[c];
+            par[threadIdx.x][1] = shift_out[c];
+        }
+    }
+    __syncthreads();
+    if (chunk >= nch) return;
+    float a[8], b[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { a[j] = par[cx * 8 + j][0]; b[j] = par[cx * 8 + j][1]; }
+    for (int m = ry; m < M; m += COLS_RY) {
+        const h8 v = *(const h8*)(x + (int64_t)m * C + coff);
+        h8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float f = (float)v[j] * a[j] + b[j];
+            if (relu) f = f > 0.f ? f : 0.f;
+            o[j] = (half_t)f;
+        }
+        *(h8*)(y + (int64_t)m * C + coff) = o;
+    }
+}
+
+// backward through (ReLU o BN) of NS cotangent streams stacked along the rows (dy = [stream 0 rows | stream 1 rows]);
+// sums [NS][2][C] = (sum g | sum g*xhat) per stream; dbeta / dgamma (may be null) += gscale * sums of stream `pstream`
+template <int NS>
+__global__ __launch_bounds__(256) void bn_cols_bwd_kernel(const half_t* __restrict__ x, const half_t* __restrict__ dy,
+                                                          half_t* __restrict__ dx, int M, int C, float inv_count,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, int relu,
+                                                          float* __restrict__ sums, float* __restrict__ dbeta,
+                                                          float* __restrict__ dgamma, float gscale, int pstream) {
+    __shared__ float red[256 * 17];
+    __shared__ float par[NS][COLS_CX * 8][2];
+    const int cx = threadIdx.x & (COLS_CX - 1), ry = threadIdx.x >> 2;
+    const int chunk = blockIdx.x * COLS_CX + cx;
+    const int nch = C >> 3;
+    const int64_t coff = (int64_t)chunk * 8;
+    const int64_t sstride = (int64_t)M * C;
+    float mu[8], rs[8], ga[8], be[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = chunk < nch ? chunk * 8 + j : 0;
+        mu[j] = mean[c]; rs[j] = rstd[c]; ga[j] = gamma[c]; be[j] = beta[c];
+    }
+    for (int st = 0; st < NS; ++st) {
+        float s0[8], s1[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s0[j] = 0.f; s1[j] = 0.f; }
+        if (chunk < nch)
+            for (int m = ry; m < M; m += COLS_RY) {
+                const int64_t o = (int64_t)m * C + coff;
+                const h8 xv = *(const h8*)(x + o);
+                const h8 gv = *(const h8*)(dy + st * sstride + o);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xh = ((float)xv[j] - mu[j]) * rs[j];
+                    float g = (float)gv[j];
+                    if (relu && !(xh * ga[j] + be[j] > 0.f)) g = 0.f;
+                    s0[j] += g; s1[j] += g * xh;
+                }
+            }
+        __syncthreads();                     // (the previous stream's fold is done with `red`)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { red[threadIdx.x * 17 + j] = s0[j]; red[threadIdx.x * 17 + 8 + j] = s1[j]; }
+        __syncthreads();
+        if (threadIdx.x < COLS_CX * 8) {
+            const int c_ = threadIdx.x >> 3, j = threadIdx.x & 7;
+            const int c = (blockIdx.x * COLS_CX + c_) * 8 + j;
+            if (c < C) {
+                const float sg = cols_fold(red, c_, j), sgx = cols_fold(red, c_, 8 + j);
+                sums[(st * 2) * C + c] = sg;
+                sums[(st * 2 + 1) * C + c] = sgx;
+                par[st][threadIdx.x][0] = sg * inv_count;
+                par[st][threadIdx.x][1] = sgx * inv_count;
+                if (st == pstream) {
+                    if (dbeta) dbeta[c] += gscale * sg;
+                    if (dgamma) dgamma[c] += gscale * sgx;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (chunk >= nch) return;
+    for (int st = 0; st < NS; ++st) {
+        float c0[8], c1[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { c0[j] = par[st][cx * 8 + j][0]; c1[j] = par[st][cx * 8 + j][1]; }
+        for (int m = ry; m < M; m += COLS_RY) {
+            const int64_t o = (int64_t)m * C + coff;
+            const h8 xv = *(const h8*)(x + o);
+            const h8 gv = *(const h8*)(dy + st * sstride + o);
+            h8 ov;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xh = ((float)xv[j] - mu[j]) * rs[j];
+                float g = (float)gv[j];
+                if (relu && !(xh * ga[j] + be[j] > 0.f)) g = 0.f;
+                ov[j] = (half_t)(ga[j] * rs[j] * (g - c0[j] - xh * c1[j]));
+            }
+            *(h8*)(dx + st * sstride + o) = ov;
+        }
+    }
+}
+
 #define LAUNCH_OK() (hipGetLastError() == hipSuccess ? OK : E_LAUNCH)
 
 int64_t bn_ws_floats(int M, int C) {
@@ -607,6 +763,29 @@ int bn_bwd_fold_launch(const float* part, int rows, int rows_cap, int C, int G, 
     }
     hipLaunchKernelGGL(fold_groups_kernel, dim3((n + 31) / 32, G), dim3(1024), 0, st, src, rows, n, gstride, sums, dbeta,
                        dgamma, gscale, pgroup);
+    return LAUNCH_OK();
+}
+int bn_cols_fwd_launch(const half_t* x, half_t* y, int M, int C, float count, const float* gamma, const float* beta,
+                       float eps, float momentum, int updates, float* rm, float* rv, float* mean, float* rstd,
+                       float* scale, float* shift, float* sums2C, long long* nbt, int relu, hipStream_t st) {
+    const int nch = C / 8;
+    hipLaunchKernelGGL(bn_cols_fwd_kernel, dim3((nch + COLS_CX - 1) / COLS_CX), dim3(256), 0, st, x, y, M, C, count, gamma,
+                       beta, eps, momentum, updates, rm, rv, mean, rstd, scale, shift, sums2C, nbt, relu);
+    return LAUNCH_OK();
+}
+int bn_cols_bwd_launch(const half_t* x, const half_t* dy, half_t* dx, int M, int C, int nstreams, float count,
+                       const float* mean, const float* rstd, const float* gamma, const float* beta, int relu, float* sums,
+                       float* dbeta, float* dgamma, float gscale, int pstream, hipStream_t st) {
+    const int nch = C / 8;
+    const dim3 grid((nch + COLS_CX - 1) / COLS_CX);
+    if (nstreams == 1)
+        hipLaunchKernelGGL((bn_cols_bwd_kernel<1>), grid, dim3(256), 0, st, x, dy, dx, M, C, 1.f / count, mean, rstd, gamma,
+                           beta, relu, sums, dbeta, dgamma, gscale, pstream);
+    else if (nstreams == 2)
+        hipLaunchKernelGGL((bn_cols_bwd_kernel<2>), grid, dim3(256), 0, st, x, dy, dx, M, C, 1.f / count, mean, rstd, gamma,
+                           beta, relu, sums, dbeta, dgamma, gscale, pstream);
+    else
+        return E_UNSUPPORTED;
     return LAUNCH_OK();
 }
 int bn_stats_launch(const half_t* x, int M, int C, float* sums, float* ws, int64_t ws_floats, hipStream_t st) {

@@ -48,6 +48,8 @@ _SIGS = {
     "fmri_bn_stats": [_p, _i, _i, _p, _p, _l, _p],
     "fmri_bn_finalize": [_p, _i, _f, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p, _p, _p, _p],
     "fmri_bn_stats_finalize": [_p, _i, _i, _p, _p, _l, _f, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p, _p, _p, _p],
+    "fmri_bn_cols_fwd": [_p, _p, _i, _i, _f, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p],
+    "fmri_bn_cols_bwd": [_p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _i, _p, _p, _p, _f, _i, _p],
     "fmri_bn_fold_finalize": [_p, _i, _i, _p, _p, _f, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p, _p, _p, _p],
     "fmri_bn_fold": [_p, _i, _i, _p, _p, _p],
     "fmri_bn_bwd_fold": [_p, _i, _i, _i, _i, _p, _p, _p, _p, _f, _i, _p],

@@ -671,6 +671,11 @@ class DenseLayer:
 # ------------------------------------------------------------------------------------------------
 # batch norm
 # ------------------------------------------------------------------------------------------------
+# BatchNorm calls over at most this many rows (the BatchNorm1d layers behind the dense layers) run as ONE launch per
+# direction (csrc/norm.hip bn_cols_*); 0 switches the path off (A/B timing)
+_BN_COLS_ROWS = int(os.environ.get("FMRI_BN_COLS_ROWS", "2048"))
+
+
 class BNSaved:
     __slots__ = ("mean", "rstd", "scale", "shift", "count", "sums")
 
@@ -804,6 +809,18 @@ class BatchNorm:
         fin = (_P(gamma), _P(beta), 1e-5, 0.9, updates, _P(rm) if updates > 0 else None,
                _P(rv) if updates > 0 else None, _P(sv.mean), _P(sv.rstd), _P(sv.scale), _P(sv.shift),
                _P(self.nbt) if updates > 0 else None)
+        if exchanged is None and stat_acc is None and self.reducer is None and M <= _BN_COLS_ROWS:
+            # few rows (the BatchNorm1d layers behind the dense layers): statistics, finalize and apply in ONE launch
+            if out is None:
+                out = torch.empty_like(raw)
+            lib.note(bytes=6.0 * M * C)
+            lib.call("fmri_bn_cols_fwd", _P(x2), _P(out), M, C, count, _P(gamma), _P(beta), 1e-5, 0.9, updates,
+                     _P(rm) if updates > 0 else None, _P(rv) if updates > 0 else None, _P(sv.mean), _P(sv.rstd),
+                     _P(sv.scale), _P(sv.shift), _P(sums), _P(self.nbt) if updates > 0 else None, 1 if relu else 0)
+            sv.count, sv.sums = count, sums
+            if updates > 0:
+                self._running_out()
+            return out, sv
         if exchanged is not None:
             count *= exchanged[1]
             lib.call("fmri_bn_finalize", _P(sums), C, count, *fin)
@@ -907,6 +924,17 @@ class BatchNorm:
         # gamma/beta gradients come from the LOCAL sums (the SUM all-reduce of the gradients adds the other ranks); the
         # fold kernel of the reduction accumulates them, the permuted (C,H,W)-ordered BN1d needs the scatter kernel
         direct = param_scale is not None and not self.perm
+        if phase == 3 and stat is None and self.reducer is None and M <= _BN_COLS_ROWS:
+            # few rows: reduction, parameter gradients and dx in ONE launch
+            if out is None:
+                out = torch.empty_like(dy)
+            lib.note(bytes=10.0 * M * C)
+            lib.call("fmri_bn_cols_bwd", _P(x2), _P(g2), _P(out), M, C, 1, sv.count, _P(sv.mean), _P(sv.rstd), _P(gamma),
+                     _P(beta), 1 if relu else 0, _P(sums), _P(self.gbeta) if direct else None,
+                     _P(self.ggamma) if direct else None, (1.0 / param_scale) if direct else 0.0, 0)
+            if param_scale is not None and self.perm:
+                self.accumulate_param_grads(sums, param_scale)
+            return out, sums
         if phase & 1:
             if stat is not None:
                 assert not self.perm
@@ -946,6 +974,16 @@ class BatchNorm:
         if sums is None:
             sums = torch.empty(4, C, dtype=torch.float32, device=raw.device)
         pg = param_scale is not None and not self.perm     # (C,H,W)-permuted BN1d: scattered below
+        if phase == 3 and stat is None and self.reducer is None and M <= _BN_COLS_ROWS:
+            if out is None:
+                out = torch.empty_like(dy2)
+            lib.note(bytes=16.0 * M * C)
+            lib.call("fmri_bn_cols_bwd", _P(x2), _P(g2), _P(out), M, C, 2, sv.count, _P(sv.mean), _P(sv.rstd), _P(gamma),
+                     _P(beta), 1 if relu else 0, _P(sums), _P(self.gbeta) if pg else None,
+                     _P(self.ggamma) if pg else None, (1.0 / param_scale) if pg else 0.0, int(param_stream))
+            if param_scale is not None and self.perm:
+                self.accumulate_param_grads(sums[2 * int(param_stream):2 * int(param_stream) + 2], param_scale)
+            return out, sums
         if phase & 1:
             if stat is not None:
                 # groups stat_group, stat_group + 1 of the producing data gradient's epilogue rows (dy2 is ReLU-masked)

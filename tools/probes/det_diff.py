@@ -1,5 +1,6 @@
-"""Deterministic mode: which tensors of two identical engines differ after one step (forward tensors, gradients,
-parameters)?  python tools/probes/det_diff.py [B] [side]"""
+"""Deterministic mode: which tensors of two identical engines differ after each of STEPS steps (forward tensors, gradients,
+parameters)?  A long run (B = 256, side, 100 steps) is the soak test for rare, timing-dependent corruption.
+python tools/probes/det_diff.py [B] [side|serial] [STEPS]"""
 import os
 import sys
 
@@ -15,6 +16,7 @@ from oracle import vaegan_oracle as O  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 side = len(sys.argv) > 2 and sys.argv[2] == "side"
+STEPS = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 ops.set_deterministic(True)
 ops._SIDE["on"] = side
 DEV = "cuda:0"
@@ -34,8 +36,9 @@ def diff(name, ta, tb):
         print(f"  DIFF {name}: {int((d > 0).sum())}/{ta.numel()} max {float(d.max()):.3e} (ref max {float(tb.double().abs().max()):.3e})")
 
 
-for step in range(3):
-    print("step", step)
+for step in range(STEPS):
+    if step % 10 == 0:
+        print("step", step, flush=True)
     for st in (a, b):
         st.forward(x, e, zp)
         st.gate(B)

@@ -81,10 +81,15 @@ __global__ __launch_bounds__(256) void pack_tile_kernel(const PackArgs p, int ru
 __global__ __launch_bounds__(256) void pack_tile_batch_kernel(const PackEntry* __restrict__ tab, int n) {
     __shared__ float t[32 * 65];
     __shared__ int sel;
-    if (threadIdx.x == 0) {
-        int e = 0;
-        while (e + 1 < n && (int)blockIdx.x >= tab[e + 1].tile_begin) ++e;
-        sel = e;
+    // entry of this block: the table is sorted by tile_begin (tile_begin[0] = 0), so the entry index is the number of
+    // entries that begin at or before this block, minus one.  One parallel round of loads by the first wave (round 3
+    // walked the table serially in thread 0: up to n dependent global loads in front of 3 KB of work per block).
+    if (threadIdx.x < 64) {
+        int cnt = 0;
+        for (int e = threadIdx.x; e < n; e += 64) cnt += (int)blockIdx.x >= tab[e].tile_begin ? 1 : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+        if (threadIdx.x == 0) sel = cnt - 1;
     }
     __syncthreads();
     const PackEntry& en = tab[sel];

@@ -300,7 +300,17 @@ def _side_stream(device):
     st = _SIDE["streams"].get(key)
     if st is None:
         st = _SIDE["streams"][key] = torch.cuda.Stream(device)
+        # everything the fork / join below needs, looked up once: the switch to the side stream and back is two
+        # _cuda_setStream calls (the ``torch.cuda.stream`` context manager costs ~25 us of Python per use, 55 times per
+        # step), the fork and join events are two reused Event objects (a wait captures the event's state when it is
+        # issued, so re-recording the same event later is well defined)
+        st._fmri_ids = (st.stream_id, st.device_index, st.device_type)
+        st._fmri_fork = torch.cuda.Event()
+        st._fmri_join = torch.cuda.Event()
     return st
+
+
+_set_stream = torch._C._cuda_setStream
 
 
 def side_run(device, fn, *keep):
@@ -311,11 +321,15 @@ def side_run(device, fn, *keep):
     if st is None:
         fn()
         return
-    ev = torch.cuda.Event()
-    ev.record(torch.cuda.current_stream(device))
-    st.wait_event(ev)
-    with torch.cuda.stream(st):
+    cur = torch.cuda.current_stream(device)
+    st._fmri_fork.record(cur)
+    st.wait_event(st._fmri_fork)
+    sid, didx, dtype = st._fmri_ids
+    _set_stream(stream_id=sid, device_index=didx, device_type=dtype)
+    try:
         fn()
+    finally:
+        _set_stream(stream_id=cur.stream_id, device_index=cur.device_index, device_type=cur.device_type)
     _SIDE["pending"].append((st, keep))
 
 
@@ -328,9 +342,8 @@ def join_side(device=None):
         if st not in seen:
             seen.append(st)
     for st in seen:
-        ev = torch.cuda.Event()
-        ev.record(st)
-        torch.cuda.current_stream(st.device).wait_event(ev)
+        st._fmri_join.record(st)
+        torch.cuda.current_stream(st.device).wait_event(st._fmri_join)
     _SIDE["pending"].clear()
 
 

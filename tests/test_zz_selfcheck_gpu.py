@@ -287,3 +287,38 @@ def test_wae_step_recorded_into_a_hip_graph_equals_eager_steps(deterministic, st
     moved = [k for k in sa if sa[k].dtype.is_floating_point and sa[k].numel() >= 1024 and "running" not in k
              and not torch.equal(sa[k], s0[k])]
     assert moved, "no parameter moved in five steps"
+
+
+@pytest.mark.parametrize("kind", ["stage2", "stage3", "wae2", "dual1"])
+def test_other_steps_two_runs_are_bit_identical(deterministic, kind):
+    """The determinism property for the steps BASELINE configs[2..4] run: Stage II / III (cognitive encoder, teacher,
+    frozen sub-networks, gradient clamp), WAE Stage II (Adam, fused latent-discriminator kernels) and the Dual WAE +
+    VAE/GAN step -- two engines, the same batch, three steps, the same bits."""
+    from oracle import vaegan_oracle as O
+    from fmri_hip.params import ArchConfig
+    from fmri_hip.steps import CognitiveStep
+    from fmri_hip.wae_steps import DualStage1Step, WaeStep
+    cfg, cfg_o, B, V = ArchConfig.px64(), O.ArchCfg.px64(), 8, 512
+    data = O.synth_batch(B, cfg_o, n_voxels=V, seed=4321, steps=1)
+    x, fm = data["x"].to(DEV), data["fmri"].to(DEV)
+    nz = [t.to(DEV) for t in data["noise"][0]]
+
+    def make():
+        if kind in ("stage2", "stage3"):
+            st = CognitiveStep(cfg, V, DEV, 2 if kind == "stage2" else 3)
+            st.load_recipe(3, True)
+            return st, (lambda: st.step(fm, x, nz[0], nz[1], nz[2]))
+        if kind == "wae2":
+            st = WaeStep(cfg, DEV, 2, V)
+            st.load_recipe(5, None)
+            return st, (lambda: st.step(x, None, fm))
+        st = DualStage1Step(cfg, DEV)
+        st.load_recipe(8, True)
+        return st, (lambda: st.step(x, nz[0], nz[1], nz[2]))
+    (a, run_a), (b, run_b) = make(), make()
+    for _ in range(3):
+        run_a()
+        run_b()
+    _finish()
+    _assert_same_logs(a.logs(), b.logs(), kind)
+    _assert_same_bits(a.state_dict(), b.state_dict(), f"two runs of {kind}")

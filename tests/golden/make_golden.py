@@ -708,6 +708,54 @@ def case_surface(name, cfg, B, V, seed):
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
 
 
+def case_recon(name, cfg, B, seed):
+    """``Discriminator(recon_level = 1 | 2)`` of the reference (models/vae_gan.py:139-173): the 'REC' call's output (raw
+    convolution output of block ``recon_level``), its gradient w.r.t. the predicted images and the parameters under a
+    seeded cotangent, the BatchNorm counters after the REC call and after a following 'GAN' call; plus the facts that
+    level 0 raises and level 4 returns None."""
+    vg = load_reference(cfg)
+    rs = np.random.RandomState(1000 + seed)
+    xs = [torch.from_numpy(rs.uniform(-1, 1, (B, 3, cfg.image_size, cfg.image_size)).astype(np.float32)) for _ in range(3)]
+    out = {"meta/case": np.array("recon"), "meta/B": B, "meta/seed": seed, "meta/image_size": cfg.image_size}
+    for level in (1, 2):
+        dis = vg.Discriminator(channel_in=3, recon_level=level)
+        dis.load_state_dict(O.fill_state(O.discriminator_spec(cfg, ""), seed, True))
+        dis.train()
+        xp = xs[1].clone().requires_grad_(True)
+        feat = dis(xs[0], xp, xs[2], "REC")
+        w = torch.from_numpy(np.random.RandomState(2000 + level).standard_normal(tuple(feat.shape)).astype(np.float32))
+        (feat * w).sum().backward()
+        tag = f"level{level}"
+        out[f"{tag}/shape"] = np.array(feat.shape)
+        out[f"{tag}/feat"] = O.tensor_summary(feat.detach())
+        out[f"{tag}/dxp"] = O.tensor_summary(xp.grad)
+        gk, gs = [], []
+        for k, p_ in dis.named_parameters():
+            gk.append(k)
+            gs.append(O.tensor_summary(p_.grad) if p_.grad is not None else np.full(18, np.nan))
+        out[f"{tag}/grad_keys"], out[f"{tag}/grad_sum"] = np.array(gk), np.stack(gs)
+        sd = dis.state_dict()
+        out[f"{tag}/nbt_rec"] = np.array([int(sd[f"conv.{i}.bn.num_batches_tracked"]) for i in (1, 2, 3)])
+        with torch.no_grad():
+            prob = dis(xs[0], xs[1], xs[2], "GAN")
+        out[f"{tag}/prob"] = O.tensor_summary(prob)
+        sd = dis.state_dict()
+        out[f"{tag}/nbt_gan"] = np.array([int(sd[f"conv.{i}.bn.num_batches_tracked"]) for i in (1, 2, 3)])
+    # the levels the reference cannot run
+    d0 = vg.Discriminator(channel_in=3, recon_level=0)
+    try:
+        d0(xs[0], xs[1], xs[2], "REC")
+        out["level0/raises"] = np.array("")
+    except Exception as e:                                     # noqa: BLE001  (recording what the reference does)
+        out["level0/raises"] = np.array(type(e).__name__)
+    d4 = vg.Discriminator(channel_in=3, recon_level=4)
+    with torch.no_grad():
+        out["level4/is_none"] = np.array(d4(xs[0], xs[1], xs[2], "REC") is None)
+    print(name, [int(v) for v in out["level1/shape"]], [int(v) for v in out["level2/shape"]], str(out["level0/raises"]),
+          bool(out["level4/is_none"]))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+
+
 def case_resize(name):
     """CenterCrop + Resize of train_vgan_stage1.py:162-165 as torchvision 0.5.0 performs them, i.e. through PIL
     (torchvision itself is not installed here: its two functions are the three lines restated below)."""
@@ -828,3 +876,5 @@ if __name__ == "__main__":
         case_resize("resize")
     if want("surface_b4"):
         case_surface("surface_b4", O.ArchCfg.px64(), B=4, V=4096, seed=12)
+    if want("recon_b4"):
+        case_recon("recon_b4", O.ArchCfg.px64(), B=4, seed=21)

@@ -536,3 +536,46 @@ def test_discriminator_recon_level_outside_the_reference_range_is_refused():
     for level in (0, 4):
         with pytest.raises(ValueError):
             M.Discriminator(channel_in=3, recon_level=level).to(DEV)._engine()
+
+
+def test_discriminator_recon_levels_match_reference_golden(golden_dir):
+    """The same calls on the engine against the numbers the REAL reference produced (tests/golden/recon_b4.npz,
+    make_golden.py::case_recon): 'REC' features of recon_level 1 and 2, the gradient w.r.t. the predicted images, the
+    parameter gradients' norms, the BatchNorm counters after the REC call and after a GAN call on the same tensors."""
+    from oracle import vaegan_oracle as O
+    _cfg64()
+    import models.vae_gan as M
+    cfg_o = O.ArchCfg.px64()
+    g = np.load(os.path.join(golden_dir, "recon_b4.npz"))
+    B, seed = int(g["meta/B"]), int(g["meta/seed"])
+    rs = np.random.RandomState(1000 + seed)
+    xs = [torch.from_numpy(rs.uniform(-1, 1, (B, 3, 64, 64)).astype(np.float32)) for _ in range(3)]
+    for level in (1, 2):
+        tag = f"level{level}"
+        dis = M.Discriminator(channel_in=3, recon_level=level).to(DEV)
+        dis.load_state_dict({k: v.clone() for k, v in O.fill_state(O.discriminator_spec(cfg_o, ""), seed, True).items()})
+        dis.train()
+        xo, xp, xq = (t.to(DEV) for t in xs)
+        xp.requires_grad_(True)
+        feat = dis(xo, xp, xq, "REC")
+        assert list(feat.shape) == [int(v) for v in g[f"{tag}/shape"]]
+        w = torch.from_numpy(np.random.RandomState(2000 + level).standard_normal(tuple(feat.shape)).astype(np.float32))
+        (feat * w.to(DEV)).sum().backward()
+        _summ_close(g[f"{tag}/feat"], feat, f"{tag} feat disc_layer")
+        got = O.tensor_summary(xp.grad.detach().float().cpu())
+        ref = g[f"{tag}/dxp"]
+        assert abs(got[0] - ref[0]) < 3e-2 * abs(ref[0]), (tag, "dxp norm", got[0], ref[0])
+        params = dict(dis.named_parameters())
+        for k, r in zip([str(k) for k in g[f"{tag}/grad_keys"]], g[f"{tag}/grad_sum"]):
+            gk = params[k].grad
+            if np.isnan(r[0]):
+                assert gk is None or float(gk.abs().max()) == 0.0, k
+            elif params[k].numel() >= 64:
+                n = float(gk.double().norm())
+                assert abs(n - r[0]) < 6e-2 * abs(r[0]), (tag, k, n, r[0])      # ReLU-mask noise of 16-bit activations
+        sd = dis.state_dict()
+        assert [int(sd[f"conv.{i}.bn.num_batches_tracked"]) for i in (1, 2, 3)] == [int(v) for v in g[f"{tag}/nbt_rec"]]
+        prob = dis(xo, xp.detach(), xq, "GAN")
+        _summ_close(g[f"{tag}/prob"], prob, f"{tag} prob", ntol=2e-3, etol=1e-2)
+        sd = dis.state_dict()
+        assert [int(sd[f"conv.{i}.bn.num_batches_tracked"]) for i in (1, 2, 3)] == [int(v) for v in g[f"{tag}/nbt_gan"]]

@@ -284,3 +284,38 @@ def test_wrapper_forwards_match_reference(golden_dir):
     _check_summ(g["dcgan/gen5"],
                 O.tensor_summary(O.dcgan_forward(dcg, None, torch.randn(5, cfg.latent_dim), cfg, train=False)["x_p"]),
                 "dcgan gen")
+
+
+def test_discriminator_recon_levels_match_reference(golden_dir):
+    """``Discriminator(recon_level = 1 | 2)`` (models/vae_gan.py:139-173): the oracle's 'REC' branch against what the real
+    reference returned -- features, gradient w.r.t. the predicted images and every parameter under a seeded cotangent
+    (parameters the call never reaches have no gradient in the reference either), BatchNorm counters after the REC call
+    and after a following GAN call.  The fixture also records that level 0 raises a TypeError and level 4 returns None in
+    the reference: the engine refuses both (tests/test_api_loops_gpu.py)."""
+    cfg = O.ArchCfg.px64()
+    g = _load(golden_dir, "recon_b4")
+    B, seed = int(g["meta/B"]), int(g["meta/seed"])
+    assert str(g["level0/raises"]) == "TypeError" and bool(g["level4/is_none"])
+    rs = np.random.RandomState(1000 + seed)
+    xs = [torch.from_numpy(rs.uniform(-1, 1, (B, 3, cfg.image_size, cfg.image_size)).astype(np.float32)) for _ in range(3)]
+    for level in (1, 2):
+        tag = f"level{level}"
+        P = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and "running" not in k else v.clone())
+             for k, v in O.fill_state(O.discriminator_spec(cfg, ""), seed, True).items()}
+        xp = xs[1].clone().requires_grad_(True)
+        feat = O.discriminator_fwd(P, "", xs[0], xp, xs[2], "REC", cfg, True, recon_level=level)
+        assert list(feat.shape) == [int(v) for v in g[f"{tag}/shape"]]
+        w = torch.from_numpy(np.random.RandomState(2000 + level).standard_normal(tuple(feat.shape)).astype(np.float32))
+        (feat * w).sum().backward()
+        _check_summ(g[f"{tag}/feat"], O.tensor_summary(feat.detach()), f"{tag} feat")
+        _check_summ(g[f"{tag}/dxp"], O.tensor_summary(xp.grad), f"{tag} dxp")
+        for k, ref in zip([str(k) for k in g[f"{tag}/grad_keys"]], g[f"{tag}/grad_sum"]):
+            if np.isnan(ref[0]):
+                assert P[k].grad is None or float(P[k].grad.abs().max()) == 0.0, k
+            else:
+                _check_summ(ref, O.tensor_summary(P[k].grad), f"{tag} grad {k}")
+        assert [int(P[f"conv.{i}.bn.num_batches_tracked"]) for i in (1, 2, 3)] == [int(v) for v in g[f"{tag}/nbt_rec"]]
+        with torch.no_grad():
+            prob = O.discriminator_fwd(P, "", xs[0], xs[1], xs[2], "GAN", cfg, True)
+        _check_summ(g[f"{tag}/prob"], O.tensor_summary(prob), f"{tag} prob")
+        assert [int(P[f"conv.{i}.bn.num_batches_tracked"]) for i in (1, 2, 3)] == [int(v) for v in g[f"{tag}/nbt_gan"]]

@@ -373,6 +373,30 @@ int fmri_adam_dev(float* p, const float* g, float* m, float* v, int64_t n, const
                   float eps, const int* t_dev, float gscale, const float* gdev, float clamp, const int* flag,
                   void* stream);
 
+/* ---- one launch per sub-network between its weight gradients and its next forward pass (round 4) -----------------
+ * What the reference does per parameter between `loss.backward()` and the next `model(x)` -- `.grad` accumulation,
+ * `RMSprop.step()` (train_vgan_stage1.py:275-283, 425-432), and what the engine adds around it (slab sum and map of
+ * a weight-gradient GEMM's output to the reference layout, the fp16 GEMM copy of the new weights) -- for EVERY
+ * parameter of a sub-network in one launch, from a device-resident table:
+ *   fmri_apply_entry_fill  fills one host-side row and returns the blocks it occupies (0: this tensor's layout map is
+ *       not eligible -- keep fmri_unpack_grad / fmri_rmsprop_dev / fmri_pack_weight for the whole group; < 0: bad
+ *       arguments).  flat_n > 0: a flat segment [w, w + flat_n) of 1-D parameters whose gradient `grad` the backward
+ *       pass accumulated in place.  Otherwise: `gsrc` = packed gradient
+ *       [nslabs][TA*A][ld] as fmri_wgrad wrote it, (sa, sta, sb, stb, A, TA, B, KW, py, px, step, TH, TW) the map of
+ *       fmri_unpack_grad, `scale` its factor, `clear` != 0 to write zeros back over gsrc (outputs the weight-gradient
+ *       kernel ADDS into), `pk` the fp16 [rows_pad][kpad] GEMM copy in gsrc's orientation or NULL.
+ *   fmri_apply_batch  mode 1: w, sq <- RMSprop(w, sq, g * gscale / *gdev) exactly as fmri_rmsprop_dev (same operations,
+ *       same order: bit-identical to the separate launches), skipped when *flag == 0; mode 0: gradients only, stored
+ *       (not added) into `grad` in the reference layout; mode 2: zero the flat segments' `grad` (the start of a
+ *       backward pass, instead of a memset of the whole gradient buffer). */
+int fmri_apply_entry_bytes(void);
+int fmri_apply_entry_fill(void* host_entry, const float* gsrc, float* w, float* sq, float* grad, void* pk, int64_t sa,
+                          int64_t sta, int64_t sb, int64_t stb, int A, int TA, int B, int KW, int py, int px, int step,
+                          int TH, int TW, int ld, int kpad, int nslabs, int64_t slab_stride, int clear, float scale,
+                          int64_t flat_n, int tile_begin);
+int fmri_apply_batch(const void* table_dev, int n, int total_tiles, int mode, const float* lr_dev, float alpha, float eps,
+                     float gscale, const float* gdev, float clamp, const int* flag, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

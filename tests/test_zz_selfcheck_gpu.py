@@ -123,6 +123,53 @@ def test_fused_step_equals_separate_calls(deterministic):
     _assert_same_bits(a.state_dict(), b.state_dict(), "fused vs separate")
 
 
+@pytest.mark.parametrize("B", [8, 256])
+def test_one_launch_update_equals_separate_launches(deterministic, B):
+    """fmri_apply_batch (``Stage1Step.step``: weight gradients stay in their GEMM layout until ONE launch per sub-network
+    sums their slabs, maps them to the reference layout, runs RMSprop and writes the fp16 GEMM copy) against
+    fmri_unpack_grad + fmri_rmsprop_dev + fmri_pack_weight* (``backward()`` / ``apply()``): after three steps the same
+    bits in the parameters, in the RMSprop state and in EVERY fp16 GEMM copy of both orientations -- at B = 8 and at
+    BASELINE configs[1]'s B = 256 (other weight-gradient kernels, other slab counts)."""
+    from fmri_hip import ops
+    from fmri_hip.nets import refresh_net
+    a, b, args, _ = _stage1_pair(B)
+    fused = 0
+    real = ops.apply_group
+    def counting(*aa, **kw):
+        nonlocal fused
+        r = real(*aa, **kw)
+        fused += 1 if r else 0
+        return r
+    ops.apply_group = counting
+    try:
+        for _ in range(3):
+            a.step(*args)
+            b.forward(*args)
+            b.gate(B)
+            b.backward()
+            b.apply()
+        _finish()
+    finally:
+        ops.apply_group = real
+    assert fused == 9, f"the one-launch path ran {fused} times in 3 steps x 3 sub-networks"
+    _assert_same_logs(a.logs(), b.logs(), "one launch vs separate")
+    _assert_same_bits(a.state_dict(), b.state_dict(), "one launch vs separate")
+    for n in ("opt_enc", "opt_dec", "opt_dis"):
+        assert torch.equal(getattr(a, n).s1, getattr(b, n).s1), f"{n}: RMSprop state differs"
+    for na, nb in ((a.enc, b.enc), (a.dec, b.dec), (a.dis, b.dis)):
+        refresh_net(na)
+        refresh_net(nb)
+        assert len(na.group.packed) == len(nb.group.packed)
+        for i, (pa, pb) in enumerate(zip(na.group.packed, nb.group.packed)):
+            assert torch.equal(pa.buf, pb.buf), f"{type(na).__name__}: fp16 GEMM copy {i} differs"
+    # and the gradients of a following backward() are the reference-layout ones again
+    a.forward(*args); a.gate(B); a.backward()
+    b.forward(*args); b.gate(B); b.backward()
+    _finish()
+    for na, nb in ((a.enc, b.enc), (a.dec, b.dec), (a.dis, b.dis)):
+        assert torch.equal(na.group.grad, nb.group.grad), f"{type(na).__name__}: gradients after a fused step differ"
+
+
 def test_hybrid_recorded_forward_step_equals_eager_step(deterministic):
     """``Stage1Step.capture_forward``: forward + gate replayed from a HIP graph, backward / updates issued eagerly on two
     streams -- against the plain ``step`` of a second engine started from the same parameters and RMSprop state: the

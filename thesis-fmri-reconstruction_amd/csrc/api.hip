@@ -158,6 +158,40 @@ int fmri_pack_weight_batch(const void* table_dev, int n, int total_tiles, void* 
     return pack_batch_launch((const PackEntry*)table_dev, n, total_tiles, S(stream));
 }
 
+int fmri_apply_entry_bytes(void) { return (int)sizeof(ApplyEntry); }
+
+int fmri_apply_entry_fill(void* host_entry, const float* gsrc, float* w, float* sq, float* grad, void* pk, int64_t sa,
+                          int64_t sta, int64_t sb, int64_t stb, int A, int TA, int B, int KW, int py, int px, int step,
+                          int TH, int TW, int ld, int kpad, int nslabs, int64_t slab_stride, int clear, float scale,
+                          int64_t flat_n, int tile_begin) {
+    if (!host_entry || !w || !sq || tile_begin < 0) return FMRI_E_BADARG;
+    ApplyEntry e;
+    memset(&e, 0, sizeof(e));
+    e.w = w; e.sq = sq; e.grad = grad; e.tile_begin = tile_begin;
+    if (flat_n > 0) {
+        if (!grad) return FMRI_E_BADARG;
+        e.kind = 2; e.n = flat_n;
+    } else {
+        if (!gsrc || A < 1 || TA < 1 || B < 1 || TH < 1 || TW < 1 || nslabs < 1) return FMRI_E_BADARG;
+        e.gsrc = gsrc; e.pk = (half_t*)pk; e.sa = sa; e.sta = sta; e.sb = sb; e.slab_stride = slab_stride;
+        e.A = A; e.TA = TA; e.B = B; e.Bp = pad_to(B, 8); e.ld = ld; e.kpad = kpad; e.nslabs = nslabs;
+        e.clear = clear ? 1 : 0; e.scale = scale;
+        if (ld < TH * TW * e.Bp || (pk && kpad < TH * TW * e.Bp)) return FMRI_E_BADARG;
+    }
+    const int tiles = apply_entry_tiles(e, TH, TW, KW, py, px, step, stb);
+    memcpy(host_entry, &e, sizeof(e));
+    return tiles;
+}
+
+int fmri_apply_batch(const void* table_dev, int n, int total_tiles, int mode, const float* lr_dev, float alpha, float eps,
+                     float gscale, const float* gdev, float clamp, const int* flag, void* stream) {
+    if (!table_dev || n < 0 || total_tiles < 0 || mode < 0 || mode > 2 || (mode == 1 && !lr_dev)) return FMRI_E_BADARG;
+    ApplyOpt o;
+    o.lr_dev = lr_dev; o.gdev = gdev; o.flag = flag; o.alpha = alpha; o.eps = eps; o.gscale = gscale; o.clamp = clamp;
+    o.mode = mode;
+    return apply_batch_launch((const ApplyEntry*)table_dev, n, total_tiles, o, S(stream));
+}
+
 int fmri_unpack_grad(const float* src, float* dst, int64_t sa, int64_t sta, int64_t sb, int64_t stb, int A, int TA,
                      int B, int KW, int py, int px, int step, int TH, int TW, int ld, float scale, int accumulate,
                      int nslabs, int64_t slab_stride, void* stream) {

@@ -32,6 +32,38 @@ struct UnpackArgs {
     int64_t slab_stride;
 };
 
+// One row of the device-resident table of fmri_apply_batch (round 4): everything that happens to ONE parameter tensor
+// between its weight-gradient GEMM and the next forward pass -- slab sum, scaling, the map from the GEMM layout to the
+// reference layout, the optimizer update, the fp16 GEMM copy in the gradient's own orientation -- in one pass.
+struct ApplyEntry {
+    const float* gsrc;     // kinds 0 / 1: packed fp32 gradient [nslabs][rows][ld] (a weight-gradient GEMM's output)
+    float* w;              // master parameters, reference layout: tensor base (kinds 0 / 1) or segment base (kind 2)
+    float* sq;             // RMSprop state at the same offsets
+    float* grad;           // reference-layout gradient: kind 2 reads it (mode 1) / clears it (mode 2); kinds 0 / 1 write it in mode 0
+    half_t* pk;            // fp16 GEMM copy [rows_pad][kpad] in the orientation of gsrc, or null
+    int64_t sa, sta, sb;   // reference-layout strides of a, ta, b (taps are contiguous)
+    int64_t slab_stride;
+    int64_t n;             // kind 2: elements of the segment
+    int32_t A, TA, B, Bp;
+    int32_t run;           // taps (kind 0)
+    int32_t ld, kpad, nslabs;
+    int32_t clear;         // write zeros back over gsrc (buffers a weight-gradient kernel ADDS into)
+    int32_t kind;          // 0 tap-transposing tile, 1 row-contiguous, 2 flat segment of the parameter buffer
+    int32_t bt;            // kind 0: b per tile (32 or 64)
+    int32_t tile_begin;
+    float scale;
+    int32_t pad_;
+};
+struct ApplyOpt {
+    const float* lr_dev; const float* gdev; const int* flag;
+    float alpha, eps, gscale, clamp;
+    int32_t mode;          // 0: gradients only (reference layout, first-writer stores), 1: RMSprop update + fp16 copy,
+                           // 2: clear the flat segments' gradients
+};
+constexpr int APPLY_CHUNK = 1024;       // elements per block of kinds 1 / 2
+int apply_entry_tiles(ApplyEntry& e, int TH, int TW, int KW, int py, int px, int step, int64_t stb);
+int apply_batch_launch(const ApplyEntry* tab, int n, int total_tiles, const ApplyOpt& o, hipStream_t st);
+
 int igemm_launch(const IgemmArgs& a, int maxM, int bn_tile, int copad, bool out_f32, hipStream_t st);
 int igemm_bm(const IgemmArgs& a, int maxM, int bn_tile, int copad, bool out_f32);   // row tile igemm_launch will use
 int igemm_tc32_launch(const Tc32Args& a, int nblocks, hipStream_t st);

@@ -442,4 +442,157 @@ int permute_chw_launch(const float* s, float* d, int C, int HW, int to_engine, f
     return hipGetLastError() == hipSuccess ? OK : E_LAUNCH;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// fmri_apply_batch (round 4): ONE launch per sub-network between its last weight gradient and its next forward pass.
+// Rounds 1-3 ran, per parameter tensor, unpack_grad (slab sum + map to the reference layout, read-modify-write of the
+// gradient buffer), then the optimizer over the whole buffer, then the re-pack into both GEMM orientations, with a
+// memset of the gradient buffer in front: 48 bytes per parameter and ~35 launches per step.  Here a block takes the
+// same tile the unpack kernel took, sums the slabs, transposes through LDS, updates w and its RMSprop state in place
+// (the same float operations in the same order as unpack_tile_kernel + rmsprop_kernel: results are bit-identical),
+// transposes the NEW weights back and stores the fp16 GEMM copy of the gradient's orientation: 22 bytes per parameter.
+// The other orientation is still a pack launch.  1-D parameters (biases, BatchNorm gamma / beta) are kind-2 rows:
+// flat segments of the buffer whose gradients the backward pass accumulated in place; mode 2 clears those segments (the
+// start of a backward pass: instead of a memset of the whole gradient buffer).
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float slab_sum(const float* q, int nslabs, int64_t slab_stride) {
+    // (unpack_tile_kernel's order: four loads in flight)
+    float v0 = q[0], v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    int z = 1;
+    for (; z + 3 < nslabs; z += 4) {
+        v0 += q[z * slab_stride];
+        v1 += q[(z + 1) * slab_stride];
+        v2 += q[(z + 2) * slab_stride];
+        v3 += q[(z + 3) * slab_stride];
+    }
+    for (; z < nslabs; ++z) v0 += q[z * slab_stride];
+    return (v0 + v1) + (v2 + v3);
+}
+__device__ __forceinline__ void slab_clear(float* q, int nslabs, int64_t slab_stride) {
+    for (int z = 0; z < nslabs; ++z) q[z * slab_stride] = 0.f;
+}
+// rmsprop_kernel's update of one element (csrc/loss.hip); returns the new parameter
+__device__ __forceinline__ float rms_update(float g, float* w, float* sq, float gs, float lr, const ApplyOpt& o) {
+    float gg = g * gs;
+    if (o.clamp > 0.f) gg = fminf(fmaxf(gg, -o.clamp), o.clamp);
+    const float s = o.alpha * *sq + (1.f - o.alpha) * gg * gg;
+    *sq = s;
+    const float nw = *w - lr * gg / (sqrtf(s) + o.eps);
+    *w = nw;
+    return nw;
+}
+
+__global__ __launch_bounds__(256) void apply_batch_kernel(const ApplyEntry* __restrict__ tab, int n, const ApplyOpt o) {
+    __shared__ float t[64 * 65];
+    __shared__ int sel;
+    if (threadIdx.x < 64) {
+        int cnt = 0;
+        for (int e = threadIdx.x; e < n; e += 64) cnt += (int)blockIdx.x >= tab[e].tile_begin ? 1 : 0;
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) cnt += __shfl_xor(cnt, s, 64);
+        if (threadIdx.x == 0) sel = cnt - 1;
+    }
+    __syncthreads();
+    const ApplyEntry& en = tab[sel];
+    const int tile = blockIdx.x - en.tile_begin;
+    const bool update = o.mode == 1;
+    const bool live = !update || !o.flag || *o.flag != 0;          // a gated-off optimizer step changes nothing
+    if (!live && (!en.clear || en.kind == 2)) return;
+    const float lr = (update && o.lr_dev) ? *o.lr_dev : 0.f;
+    const float gs = update ? o.gscale / (o.gdev ? *o.gdev : 1.f) : 1.f;
+    if (en.kind == 2) {
+        if (o.mode == 0) return;                                   // (the gradient is already where it belongs)
+        const int64_t i = (int64_t)tile * APPLY_CHUNK + threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < APPLY_CHUNK / 256; ++k) {
+            const int64_t j = i + k * 256;
+            if (j < en.n) {
+                if (o.mode == 2) en.grad[j] = 0.f;
+                else rms_update(en.grad[j], en.w + j, en.sq + j, gs, lr, o);
+            }
+        }
+        return;
+    }
+    if (o.mode == 2) return;
+    float* gsrc = const_cast<float*>(en.gsrc);
+    if (en.kind == 1) {
+        const int64_t total = (int64_t)en.TA * en.A * en.B;
+        const int64_t i0 = (int64_t)tile * APPLY_CHUNK + threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < APPLY_CHUNK / 256; ++k) {
+            const int64_t i = i0 + k * 256;
+            if (i >= total) break;
+            const int row = (int)(i / en.B), b = (int)(i - (int64_t)row * en.B);
+            const int ta = row / en.A, a = row - ta * en.A;
+            float* q = gsrc + (int64_t)row * en.ld + b;
+            const float v = slab_sum(q, en.nslabs, en.slab_stride) * en.scale;
+            if (en.clear) slab_clear(q, en.nslabs, en.slab_stride);
+            if (!live) continue;
+            const int64_t off = a * en.sa + ta * en.sta + b * en.sb;
+            if (!update) { en.grad[off] = v; continue; }
+            const float nw = rms_update(v, en.w + off, en.sq + off, gs, lr, o);
+            if (en.pk) en.pk[(int64_t)row * en.kpad + b] = (half_t)nw;
+        }
+        return;
+    }
+    // kind 0: one row x bt consecutive b x all taps
+    const int bt = en.bt, sh = bt == 64 ? 6 : 5, run = en.run;
+    const int nbt = (en.B + bt - 1) / bt;
+    const int row = tile / nbt, b0 = (tile - row * nbt) * bt;
+    const int ta = row / en.A, a = row - ta * en.A;
+    const int stride = run | 1;
+    float* s = gsrc + (int64_t)row * en.ld + b0;
+    for (int e = threadIdx.x; e < run * bt; e += 256) {
+        const int tb = e >> sh, bl = e & (bt - 1);
+        if (b0 + bl < en.B) {
+            float* q = s + tb * en.Bp + bl;
+            t[bl * stride + tb] = slab_sum(q, en.nslabs, en.slab_stride);
+            if (en.clear) slab_clear(q, en.nslabs, en.slab_stride);
+        }
+    }
+    if (!live) return;
+    __syncthreads();
+    const int64_t base = a * en.sa + ta * en.sta;
+    for (int e = threadIdx.x; e < bt * run; e += 256) {
+        const int bl = e / run, j = e - bl * run;
+        if (b0 + bl < en.B) {
+            const float v = t[bl * stride + j] * en.scale;
+            const int64_t off = base + (b0 + bl) * en.sb + j;
+            if (!update) en.grad[off] = v;
+            else t[bl * stride + j] = rms_update(v, en.w + off, en.sq + off, gs, lr, o);
+        }
+    }
+    if (!update || !en.pk) return;
+    __syncthreads();
+    half_t* d = en.pk + (int64_t)row * en.kpad + b0;
+    for (int e = threadIdx.x; e < run * bt; e += 256) {
+        const int tb = e >> sh, bl = e & (bt - 1);
+        if (b0 + bl < en.B) d[tb * en.Bp + bl] = (half_t)t[bl * stride + tb];
+    }
+}
+
+// Completes a row of the table (kind, run, bt) from the tap geometry of its PackSpec and returns the number of blocks it
+// occupies; 0 = this tensor's layout map is not one the kernel knows (the caller keeps the separate launches).
+int apply_entry_tiles(ApplyEntry& e, int TH, int TW, int KW, int py, int px, int step, int64_t stb) {
+    if (e.kind == 2) return (int)((e.n + APPLY_CHUNK - 1) / APPLY_CHUNK);
+    const int run = TH * TW;
+    const int64_t rows = (int64_t)e.TA * e.A;
+    if (run > 1 && run <= 64 && stb == 1 && py == 0 && px == 0 && step == 1 && TW == KW) {
+        e.kind = 0; e.run = run; e.bt = e.B >= 64 ? 64 : 32;
+        const int64_t tiles = rows * ((e.B + e.bt - 1) / e.bt);
+        return tiles < (1 << 24) ? (int)tiles : 0;
+    }
+    if (run == 1 && e.sb == 1) {
+        e.kind = 1; e.run = 1; e.bt = 0;
+        const int64_t tiles = (rows * e.B + APPLY_CHUNK - 1) / APPLY_CHUNK;
+        return tiles < (1 << 24) ? (int)tiles : 0;
+    }
+    return 0;
+}
+int apply_batch_launch(const ApplyEntry* tab, int n, int total_tiles, const ApplyOpt& o, hipStream_t st) {
+    if (total_tiles < 1 || n < 1) return OK;
+    hipLaunchKernelGGL(apply_batch_kernel, dim3((unsigned)total_tiles), dim3(256), 0, st, tab, n, o);
+    return hipGetLastError() == hipSuccess ? OK : E_LAUNCH;
+}
+
 }  // namespace fmri

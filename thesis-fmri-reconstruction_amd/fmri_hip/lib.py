@@ -22,8 +22,12 @@ _SIGS = {
     "fmri_kpad": [_i, _i],
     "fmri_pack_weight": [_p, _p, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "fmri_pack_entry_bytes": [],
+    "fmri_apply_entry_bytes": [],
     "fmri_pack_entry_fill": [_p, _p, _p, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i],
     "fmri_pack_weight_batch": [_p, _i, _i, _p],
+    "fmri_apply_entry_fill": [_p, _p, _p, _p, _p, _p, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _l,
+                              _i, _f, _l, _i],
+    "fmri_apply_batch": [_p, _i, _i, _i, _p, _f, _f, _f, _p, _f, _p, _p],
     "fmri_ingest_u8": [_p, _i, _i, _i, _i, _p, _p, _f, _f, _f, _f, _f, _f, _p, _p, _p],
     "fmri_crop_resize_u8": [_p, _p, _p, _i, _i, _i, _p, _p, _i, _p, _p, _i, _i, _p, _p],
     "fmri_pcc": [_p, _p, _l, _p, _p, _p],

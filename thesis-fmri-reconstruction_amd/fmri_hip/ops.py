@@ -111,16 +111,22 @@ class PackedWeight:
         return self.buf
 
 
-def _repack_group(group):
+def _repack_group(group, skip=()):
     """Refresh every fp16 GEMM copy of a sub-network's weights after its master buffer changed: one batched launch
-    (fmri_pack_weight_batch, device-resident table built once) + the few weights that need another pack path."""
+    (fmri_pack_weight_batch, device-resident table built once) + the few weights that need another pack path.
+    ``skip``: PackedWeights that are already current (written by fmri_apply_batch together with the update)."""
     packed = group.packed
-    tab = getattr(group, "_pack_table", None)
-    if tab is None or tab["count"] != len(packed):
+    tabs = group.__dict__.setdefault("_pack_tables", {})
+    key = (len(packed),) + tuple(sorted(id(pw) for pw in skip))
+    tab = tabs.get(key)
+    if tab is None:
         L = lib.load()
         nbytes = L.fmri_pack_entry_bytes()
         rows, singles, tiles = [], [], 0
+        skipped = set(id(pw) for pw in skip)
         for pw in packed:
+            if id(pw) in skipped:
+                continue
             for item in pw._items():
                 host = ctypes.create_string_buffer(nbytes)
                 n = L.fmri_pack_entry_fill(host, *item, tiles)
@@ -134,8 +140,7 @@ def _repack_group(group):
         dev_tab = None
         if rows:
             dev_tab = torch.frombuffer(bytearray(b"".join(rows)), dtype=torch.uint8).to(group.device)
-        tab = dict(count=len(packed), table=dev_tab, n=len(rows), tiles=tiles, singles=singles)
-        group._pack_table = tab
+        tab = tabs[key] = dict(table=dev_tab, n=len(rows), tiles=tiles, singles=singles)
     if tab["n"]:
         lib.call("fmri_pack_weight_batch", _P(tab["table"]), tab["n"], tab["tiles"])
     for item in tab["singles"]:
@@ -347,8 +352,8 @@ def join_side(device=None):
     _SIDE["pending"].clear()
 
 
-def run_wgrad(P, Q, N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad, flip=0, flops=0.0):
-    """Returns the packed fp32 gradient [apad][ldo].  ``flops``: algorithmic FLOPs of the layer's weight gradient (for
+def run_wgrad(P, Q, N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad, flip=0, flops=0.0, hold=None):
+    """Returns the packed fp32 gradient [apad][ldo].  ``hold``: see ``_grad_buffer``.  ``flops``: algorithmic FLOPs of the layer's weight gradient (for
     the profiling hook of lib.call; 0 = 2 * rows * A * Bc * k^2 of the padded operands)."""
     ba = tile_for(A)
     apad = ceil_to(A, ba)
@@ -368,10 +373,7 @@ def run_wgrad(P, Q, N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad, flip=0, flops=0.0)
         splits = max(4, budget // groups)                               # block budget per group over the 4 planes
         nslabs = lib.load().fmri_wgrad_slabs(N, Yc, Xc, k, pad, splits)
         slabs = nslabs <= _WW_SLABS or _DET["on"]                       # few splits: per-split slabs, else atomics
-        if slabs:
-            out = torch.empty(nslabs, apad, ldo, dtype=torch.float32, device=P.device)
-        else:
-            out = torch.zeros(apad, ldo, dtype=torch.float32, device=P.device)
+        out = _grad_buffer(hold, (nslabs, apad, ldo) if slabs else (apad, ldo), not slabs, P.device)
         note("fmri::wgrad_win_kernel")
         lib.call("fmri_wgrad", _P(P), _P(Q), _P(out), _P(zero_page(P.device)), N, Yc, Xc, A, Hq, Wq, Bc, k, stride,
                  pad, flip, apad, ba, ldo, splits, 2 if slabs else 1)
@@ -384,7 +386,7 @@ def run_wgrad(P, Q, N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad, flip=0, flops=0.0)
         nslabs = 4                   # blocks add into slab (block index % 4): a quarter of the same-address atomics
         if _DET["on"]:               # one slab per block: every element is added once, onto zero
             nslabs = lib.load().fmri_wgrad_narrow_blocks(N, Yc, Xc)
-        out = torch.zeros(nslabs, apad, ldo, dtype=torch.float32, device=P.device)
+        out = _grad_buffer(hold, (nslabs, apad, ldo), True, P.device)
         note("fmri::wgrad_narrow_kernel")
         lib.call("fmri_wgrad", _P(P), _P(Q), _P(out), _P(zero_page(P.device)), N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad,
                  flip, apad, ba, ldo, nslabs, 3)
@@ -399,11 +401,11 @@ def run_wgrad(P, Q, N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad, flip=0, flops=0.0)
     mode = 1 if splits > 1 else 0
     if splits > 1 and _DET["on"]:
         mode = 4                     # per-split slabs (plain stores), summed in slab order by unpack_grad
-        out = torch.zeros(splits, apad, ldo, dtype=torch.float32, device=P.device)
+        out = _grad_buffer(hold, (splits, apad, ldo), False, P.device)
     elif splits > 1:
-        out = torch.zeros(apad, ldo, dtype=torch.float32, device=P.device)
+        out = _grad_buffer(hold, (apad, ldo), True, P.device)
     else:
-        out = torch.empty(apad, ldo, dtype=torch.float32, device=P.device)
+        out = _grad_buffer(hold, (apad, ldo), False, P.device)
     note("fmri::wgrad_kernel")
     lib.call("fmri_wgrad", _P(P), _P(Q), _P(out), _P(zero_page(P.device)), N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad,
              flip, apad, ba, ldo, splits, mode)
@@ -415,6 +417,182 @@ def unpack_grad(packed, grad_view, sp: PackSpec, ld: int, scale: float):
     nslabs = packed.shape[0] if packed.dim() == 3 else 1
     lib.call("fmri_unpack_grad", _P(packed), _P(grad_view), sp.sa, sp.sta, sp.sb, sp.stb, sp.A, sp.TA, sp.B, sp.KW,
              sp.py, sp.px, sp.step, sp.TH, sp.TW, ld, float(scale), 1, nslabs, packed.shape[-2] * packed.shape[-1])
+
+
+def _grad_buffer(hold, shape, zeroed: bool, device):
+    """Output buffer of a weight-gradient launch.  ``hold`` is None: a fresh tensor per call (zeroed when the kernel
+    adds into it).  Otherwise (deferred gradients, ``begin_grads``): the layer's persistent buffer -- its address sits
+    in the device table of fmri_apply_batch, which also writes the zeros back after it has consumed the sums."""
+    if hold is None or hold.get("busy"):
+        out = (torch.zeros if zeroed else torch.empty)(shape, dtype=torch.float32, device=device)
+        out._fmri_clear = False
+        return out
+    key = (tuple(shape), zeroed)
+    out = hold.get(key)
+    if out is None:
+        out = hold[key] = torch.zeros(shape, dtype=torch.float32, device=device)
+        out._fmri_clear = zeroed
+        out._fmri_hold = hold
+    hold["busy"] = True
+    return out
+
+
+def emit_grad(group, packed, grad_view, sp: PackSpec, ld: int, scale: float):
+    """What a weight-gradient launch does with its packed result: added to the reference-layout gradient now
+    (fmri_unpack_grad), or -- between ``begin_grads(group, defer=True)`` and ``apply_group`` -- queued for the
+    sub-network's one fmri_apply_batch launch."""
+    if getattr(group, "defer_grads", False):
+        group.pending.append((packed, grad_view, sp, ld, scale))
+    else:
+        unpack_grad(packed, grad_view, sp, ld, scale)
+
+
+def _hold_of(layer):
+    """The layer's persistent gradient buffers while its group defers gradients, else None."""
+    if not getattr(layer.group, "defer_grads", False):
+        return None
+    h = layer.__dict__.get("_ghold")
+    if h is None:
+        h = layer._ghold = {}
+    return h
+
+
+_FUSED_APPLY = os.environ.get("FMRI_FUSED_APPLY") != "off"
+
+
+def begin_grads(group, defer: bool):
+    """Start of a backward pass over ``group`` (replaces ``zero_grad``).  ``defer``: the caller will hand the whole
+    group to ``apply_group`` right after the pass and nobody reads reference-layout gradients in between -- weight
+    gradients then stay in their GEMM layout until that one launch, and only the 1-D parameters' gradient segments
+    (which the backward pass accumulates in place) are cleared here instead of the whole buffer."""
+    defer = bool(defer and _FUSED_APPLY)
+    group.drop_pending()
+    group.defer_grads = defer
+    plan = getattr(group, "_apply_plan", None) if defer else None
+    if plan is not None and plan["flat"] is not None:
+        lib.call("fmri_apply_batch", _P(plan["flat"]), plan["flat_n"], plan["flat_tiles"], 2, None, 0.0, 0.0, 1.0,
+                 None, 0.0, None)
+        group._cleared = plan["sig"]
+    else:
+        group.grad.zero_()
+        group._cleared = "all"
+
+
+def _plan_apply(group, state):
+    """Device table of fmri_apply_batch for the pending gradients of ``group`` (cached while the same buffers come
+    back), or None when some tensor cannot go through it."""
+    L = lib.load()
+    pend = group.pending
+    key = tuple((p[0].data_ptr(), tuple(p[0].shape), p[1].data_ptr(), p[3], p[4]) for p in pend) + (state.data_ptr(),)
+    plan = getattr(group, "_apply_plan", None)
+    if plan is not None and plan["key"] == key:
+        return plan
+    nbytes = L.fmri_apply_entry_bytes()
+    g0, n_all = group.grad.data_ptr(), group.grad.numel()
+    rows, flat_rows, covered, fused, tiles = [], [], [], [], 0
+    by_master = {}
+    for pw in getattr(group, "packed", []):
+        if len(pw.specs) == 1:
+            by_master.setdefault(pw.master.data_ptr(), []).append(pw)
+    for packed, gv, sp, ld, scale in pend:
+        off = (gv.data_ptr() - g0) // 4
+        if not (0 <= off and off + gv.numel() <= n_all) or not gv.is_contiguous():
+            return None
+        if any(off < o + n and o < off + gv.numel() for o, n in covered):
+            return None                                   # two gradients of one tensor in one pass: separate launches
+        nsl = packed.shape[0] if packed.dim() == 3 else 1
+        pk, kpad = None, 0
+        for pw in by_master.get(group.data.data_ptr() + 4 * off, []):
+            if pw.specs[0] == sp and pw.rows_pad >= sp.rows:
+                pk, kpad = pw.buf.data_ptr() + 2 * pw.offsets[0], pw.kpads[0]
+                fused.append(pw)
+                break
+        host = ctypes.create_string_buffer(nbytes)
+        n = L.fmri_apply_entry_fill(host, packed.data_ptr(), group.data.data_ptr() + 4 * off, state.data_ptr() + 4 * off,
+                                    gv.data_ptr(), pk, sp.sa, sp.sta, sp.sb, sp.stb, sp.A, sp.TA, sp.B, sp.KW, sp.py,
+                                    sp.px, sp.step, sp.TH, sp.TW, ld, kpad, nsl, packed.shape[-2] * packed.shape[-1],
+                                    1 if getattr(packed, "_fmri_clear", False) else 0, float(scale), 0, tiles)
+        if n < 0:
+            lib.check(n, "fmri_apply_entry_fill")
+        if n == 0:
+            return None
+        rows.append(host.raw)
+        tiles += n
+        covered.append((off, gv.numel()))
+    # everything else of the buffer: 1-D parameters (and tensors without a weight-gradient GEMM), updated from the
+    # reference-layout gradient the backward pass accumulated in place
+    covered.sort()
+    segs, at = [], 0
+    for o, n in covered + [(n_all, 0)]:
+        if o > at:
+            segs.append((at, o - at))
+        at = max(at, o + n)
+    ftiles = 0
+    for o, n in segs:
+        for tile0, dst in ((tiles, rows), (ftiles, flat_rows)):
+            host = ctypes.create_string_buffer(nbytes)
+            k = L.fmri_apply_entry_fill(host, None, group.data.data_ptr() + 4 * o, state.data_ptr() + 4 * o, g0 + 4 * o,
+                                        None, 0, 0, 0, 0, 1, 1, 1, 1, 0, 0, 1, 1, 1, 0, 0, 1, 0, 0, 1.0, n, tile0)
+            if k <= 0:
+                lib.check(k if k < 0 else -1, "fmri_apply_entry_fill")
+            dst.append(host.raw)
+        tiles += k
+        ftiles += k
+    up = lambda rr: torch.frombuffer(bytearray(b"".join(rr)), dtype=torch.uint8).to(group.device) if rr else None
+    plan = dict(key=key, table=up(rows), n=len(rows), tiles=tiles, flat=up(flat_rows), flat_n=len(flat_rows),
+                flat_tiles=ftiles, sig=tuple(segs), covered=covered, fused=fused)
+    group._apply_plan = plan
+    return plan
+
+
+def flush_pending(group):
+    """Deferred gradients -> the reference-layout gradient buffer (what the separate launches would have left there)."""
+    pend, group.pending = getattr(group, "pending", []), []
+    group.defer_grads = False
+    if not pend:
+        return
+    if getattr(group, "_cleared", "all") != "all":
+        # only the 1-D segments were cleared at the start of this pass: clear what the tensors' ranges still hold
+        g0 = group.grad.data_ptr()
+        at = 0
+        for o, n in list(group._cleared) + [(group.grad.numel(), 0)]:
+            if o > at:
+                group.grad[at:o].zero_()
+            at = o + n
+        group._cleared = "all"
+    for packed, gv, sp, ld, scale in pend:
+        unpack_grad(packed, gv, sp, ld, scale)
+        if getattr(packed, "_fmri_clear", False):
+            packed.zero_()
+        if getattr(packed, "_fmri_hold", None) is not None:
+            packed._fmri_hold["busy"] = False
+
+
+def apply_group(group, state, lr_dev, alpha, eps, flag, gdev, clamp=0.0) -> bool:
+    """RMSprop update of a whole sub-network from its deferred gradients + the fp16 GEMM copies of the new weights:
+    fmri_apply_batch (one launch) and the pack launch(es) of the orientations it does not write.  Returns False -- after
+    bringing the reference-layout gradient buffer up to date -- when the group has to take the separate launches
+    (nothing deferred, or a tensor the table cannot describe); the caller then runs the optimizer and the re-pack."""
+    if not getattr(group, "defer_grads", False):
+        return False
+    plan = _plan_apply(group, state) if group.pending else None
+    if plan is None or (group._cleared != "all" and group._cleared != plan["sig"]):
+        flush_pending(group)
+        return False
+    lib.note(bytes=22.0 * group.numel)
+    lib.call("fmri_apply_batch", _P(plan["table"]), plan["n"], plan["tiles"], 1, _P(lr_dev), alpha, eps, 1.0, _P(gdev),
+             clamp, _P(flag))
+    for p in group.pending:
+        h = getattr(p[0], "_fmri_hold", None)
+        if h is not None:
+            h["busy"] = False
+    group.pending = []
+    group.defer_grads = False
+    group.version += 1
+    for pw in plan["fused"]:
+        pw.version = group.version
+    _repack_group(group, skip=plan["fused"])
+    return True
 
 
 # ------------------------------------------------------------------------------------------------
@@ -564,19 +742,19 @@ class ConvLayer:
             # exchange the roles (dW[co][ci][k] = sum_m' X[m'][ci] * dY[m' + pad - k][co]) so that the gathered
             # operand is the narrow one: rows ci, columns (tap, co)
             packed, ldo = run_wgrad(x, dy, N, Hi, Wi, self.cinp, Ho, Wo, self.coutp, self.k, 1, self.pad, flip=1,
-                                    flops=self._flops(N, Hi, Wi, Ho, Wo))
+                                    flops=self._flops(N, Hi, Wi, Ho, Wo), hold=_hold_of(self))
             kk = self.k * self.k
             spec = PackSpec(sa=kk, sta=0, A=self.cin, TA=1, sb=self.cin * kk, stb=1, B=self.cout, KW=self.k,
                             TH=self.k, TW=self.k)
-            unpack_grad(packed, self.wg, spec, ldo, 1.0 / scale)
+            emit_grad(self.group, packed, self.wg, spec, ldo, 1.0 / scale)
             return
         if self.kind == "conv":
             packed, ldo = run_wgrad(dy, x, N, Ho, Wo, self.coutp, Hi, Wi, self.cinp, self.k, self.stride, self.pad,
-                                    flops=self._flops(N, Hi, Wi, Ho, Wo))
+                                    flops=self._flops(N, Hi, Wi, Ho, Wo), hold=_hold_of(self))
         else:
             packed, ldo = run_wgrad(x, dy, N, Hi, Wi, self.cinp, Ho, Wo, self.coutp, self.k, 2, self.pad,
-                                    flops=self._flops(N, Hi, Wi, Ho, Wo))
-        unpack_grad(packed, self.wg, self.gspec, ldo, 1.0 / scale)
+                                    flops=self._flops(N, Hi, Wi, Ho, Wo), hold=_hold_of(self))
+        emit_grad(self.group, packed, self.wg, self.gspec, ldo, 1.0 / scale)
         if bias_too:
             # bias.grad += (1/scale) * sum over pixels of dy: the narrow kernel's spare column, else a reduction
             if getattr(packed, "_fmri_colsum", False):
@@ -673,8 +851,9 @@ class DenseLayer:
 
     def _wgrad(self, x: torch.Tensor, dy: torch.Tensor, scale: float):
         M = x.shape[0]
-        packed, ldo = run_wgrad(dy, x, M, 1, 1, self.np_, 1, 1, self.kp, 1, 1, 0, flops=2.0 * M * self.k_in * self.n_out)
-        unpack_grad(packed, self.wg, self.gspec, ldo, 1.0 / scale)
+        packed, ldo = run_wgrad(dy, x, M, 1, 1, self.np_, 1, 1, self.kp, 1, 1, 0, flops=2.0 * M * self.k_in * self.n_out,
+                                hold=_hold_of(self))
+        emit_grad(self.group, packed, self.wg, self.gspec, ldo, 1.0 / scale)
 
     def bias_grad(self, dy: torch.Tensor, scale: float):
         if self.bg is not None:

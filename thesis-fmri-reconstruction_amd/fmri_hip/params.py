@@ -228,8 +228,21 @@ class FlatGroup:
         sd = {k: torch.from_numpy(v) for k, v in recipe_fill(self.spec, rs, perturb).items()}
         self.load_state_dict(sd)
 
+    def drop_pending(self):
+        """Forget weight gradients that were queued for fmri_apply_batch (ops.begin_grads) and never applied; their
+        persistent buffers go back to the state the next weight-gradient launch expects."""
+        for p in getattr(self, "pending", None) or ():
+            if getattr(p[0], "_fmri_clear", False):
+                p[0].zero_()
+            if getattr(p[0], "_fmri_hold", None) is not None:
+                p[0]._fmri_hold["busy"] = False
+        self.pending = []
+        self.defer_grads = False
+
     def zero_grad(self):
+        self.drop_pending()
         self.grad.zero_()
+        self._cleared = "all"
 
 
 # ------------------------------------------------------------------------------------------------

@@ -89,11 +89,14 @@ class _Optim:
 
     def step(self, flag: Optional[torch.Tensor] = None, clamp: float = 0.0, gdev: Optional[torch.Tensor] = None):
         g = self.g
+        if self.kind == "rmsprop" and ops.apply_group(g, self.s1, self.lr_dev, self.alpha, self.eps, flag, gdev, clamp):
+            return                               # deferred gradients: update + fp16 copies in one launch (ops.begin_grads)
         if self.kind == "rmsprop":
             lib.note(bytes=20.0 * g.numel)       # read p, g, v; write p, v
             lib.call("fmri_rmsprop_dev", _P(g.data), _P(g.grad), _P(self.s1), g.numel, _P(self.lr_dev), self.alpha,
                      self.eps, 1.0, _P(gdev), clamp, _P(flag))
         else:
+            ops.flush_pending(g)                 # (Adam has no fused form: deferred gradients -> reference layout)
             self.t += 1
             b1, b2 = self.betas
             lib.call("fmri_counter_inc", _P(self.t_dev))
@@ -478,8 +481,11 @@ class Stage1Step(_GanStepBase):
         B, H, W = fw["B"], fw["H"], fw["W"]
         Z = cfg.latent_dim
         dev = fw["disc_in"].device
+        # ``early_apply`` also says that nobody reads reference-layout gradients between this pass and the updates: on one
+        # GPU the weight gradients then stay in their GEMM layout until the sub-network's one fmri_apply_batch launch
+        fuse = early_apply and not self.dd.on and self.dd.recorder is None
         for n in (self.enc, self.dec, self.dis):
-            n.group.zero_grad()
+            ops.begin_grads(n.group, fuse)
         dlogit16, dfeat16 = self._start_cotangents(fw["feat"], fw["logit32"], B)
         # weight gradients run on the side stream (ops.side_run) and are joined once, at the end of the backward pass, so
         # that a sub-network's last weight gradients overlap the next one's backward

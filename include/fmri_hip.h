@@ -389,6 +389,11 @@ int fmri_adam_dev(float* p, const float* g, float* m, float* v, int64_t n, const
  *       same order: bit-identical to the separate launches), skipped when *flag == 0; mode 0: gradients only, stored
  *       (not added) into `grad` in the reference layout; mode 2: zero the flat segments' `grad` (the start of a
  *       backward pass, instead of a memset of the whole gradient buffer). */
+/* dst[c][r] = src[r][c] (fp16; r < R, c < C; leading dimensions multiples of 8, ld_dst >= R rounded up to 8; src holds
+ * src_rows >= R rows, the rows from R on and the columns up to ld_src zero): the data-gradient orientation of a dense
+ * layer's fp16 weight made from its forward orientation instead of a second pass over the fp32 master
+ * (models/vae_gan.py:81,108,158,200: nn.Linear keeps ONE weight; the second GEMM layout is the engine's). */
+int fmri_transpose_f16(const void* src, void* dst, int R, int C, int src_rows, int ld_src, int ld_dst, void* stream);
 int fmri_apply_entry_bytes(void);
 int fmri_apply_entry_fill(void* host_entry, const float* gsrc, float* w, float* sq, float* grad, void* pk, int64_t sa,
                           int64_t sta, int64_t sb, int64_t stb, int A, int TA, int B, int KW, int py, int px, int step,

@@ -496,6 +496,40 @@ def test_dense_forward_dgrad_wgrad(M, K, N, in_perm, out_perm):
         _close(g.grads["b"].cpu() * 2.0, dy.sum(0), "dense bias grad")
 
 
+@pytest.mark.parametrize("R,C", [(1, 8), (100, 130), (64, 64), (129, 72), (512, 16384)])
+def test_transpose_f16(R, C):
+    """fmri_transpose_f16 against torch on ragged shapes; the padding of the destination stays untouched."""
+    from fmri_hip import lib
+    rows, lds, ldd = (R + 63) // 64 * 64, (C + 7) // 8 * 8 + 8, (R + 7) // 8 * 8 + 16
+    src = torch.zeros(rows, lds, dtype=torch.float16, device=DEV)
+    src[:R, :C] = torch.randn(R, C, device=DEV).half()
+    dst = torch.full((C + 3, ldd), 7.0, dtype=torch.float16, device=DEV)
+    lib.call("fmri_transpose_f16", src.data_ptr(), dst.data_ptr(), R, C, rows, lds, ldd)
+    torch.cuda.synchronize()
+    assert torch.equal(dst[:C, :R], src[:R, :C].t())
+    r8 = (R + 7) // 8 * 8
+    assert bool((dst[:C, R:r8] == 0).all()) and bool((dst[:C, r8:] == 7.0).all()) and bool((dst[C:] == 7.0).all())
+
+
+@pytest.mark.parametrize("M,K,N,in_perm,out_perm", DENSE_CASES)
+def test_dense_second_orientation_is_the_transpose(M, K, N, in_perm, out_perm):
+    """The data-gradient copy of a dense weight made by fmri_transpose_f16 from the forward copy == the one
+    fmri_pack_weight makes from the fp32 master (bit for bit, padding included)."""
+    from fmri_hip import lib, ops
+    from fmri_hip.ops import DenseLayer
+    torch.manual_seed(K + N)
+    g = _G({"w": torch.randn(N, K) / np.sqrt(K), "b": torch.zeros(N)})
+    layer = DenseLayer(g, "w", "b", K, N, in_perm=in_perm, out_perm=out_perm)
+    if getattr(layer.pw_d, "transpose_of", None) is None:
+        pytest.skip("this layer's two orientations differ in padding (K % 8 != 0): packed from the master")
+    got = layer.pw_d.get().clone()
+    ref = torch.zeros_like(got)
+    for item in layer.pw_d._items():
+        lib.call("fmri_pack_weight", item[0], ref.data_ptr(), *item[2:])
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref)
+
+
 @pytest.mark.parametrize("M,C", [(3 * 64 * 64, 32), (600, 128), (2 * 13 * 13, 256), (7, 1024), (5, 16384), (12, 512)])
 def test_batchnorm_forward_backward(M, C):
     from fmri_hip.ops import BatchNorm

@@ -158,6 +158,13 @@ int fmri_pack_weight_batch(const void* table_dev, int n, int total_tiles, void* 
     return pack_batch_launch((const PackEntry*)table_dev, n, total_tiles, S(stream));
 }
 
+int fmri_transpose_f16(const void* src, void* dst, int R, int C, int src_rows, int ld_src, int ld_dst, void* stream) {
+    if (!src || !dst || R < 1 || C < 1 || src_rows < R || ld_src < C || ld_dst < R || (ld_src & 7) || (ld_dst & 7) ||
+        ld_dst < ((R + 7) & ~7))
+        return FMRI_E_BADARG;
+    return transpose_f16_launch((const half_t*)src, (half_t*)dst, R, C, src_rows, ld_src, ld_dst, S(stream));
+}
+
 int fmri_apply_entry_bytes(void) { return (int)sizeof(ApplyEntry); }
 
 int fmri_apply_entry_fill(void* host_entry, const float* gsrc, float* w, float* sq, float* grad, void* pk, int64_t sa,

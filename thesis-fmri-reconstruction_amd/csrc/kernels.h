@@ -82,6 +82,7 @@ int pack_weight_launch(const PackArgs& p, hipStream_t st);
 int unpack_grad_launch(const UnpackArgs& p, hipStream_t st);
 int pack_tile_count(const PackArgs& p, int* run_out);
 int pack_batch_launch(const PackEntry* tab, int n, int total_tiles, hipStream_t st);
+int transpose_f16_launch(const half_t* src, half_t* dst, int R, int C, int Rbuf, int lds_, int ldd, hipStream_t st);
 int nchw_to_nhwc_launch(const float* s, half_t* d, int N, int C, int HW, int Cp, hipStream_t st);
 int nhwc_to_nchw_launch(const half_t* s, float* d, int N, int C, int HW, int Cp, float scale, hipStream_t st);
 int rows_f32_to_f16_launch(const float* s, half_t* d, int M, int C, int Cp, float scale, hipStream_t st);

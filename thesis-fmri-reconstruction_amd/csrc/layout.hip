@@ -443,6 +443,43 @@ int permute_chw_launch(const float* s, float* d, int C, int HW, int to_engine, f
 }
 
 
+// fp16 matrix transpose dst[c][r] = src[r][c] (r < R, c < C) in 64 x 64 tiles through LDS, 16-byte loads and stores.
+// The two GEMM orientations of a dense layer's weight are transposes of each other ([n][k] for the forward pass, [k][n]
+// for the data gradient, the (C,H,W) -> (H,W,C) permutation of the flatten already inside the column order): the second
+// copy is made from the first (2 + 2 bytes per element) instead of from the fp32 master (4 + 2).  Rows r >= R of src up
+// to Rbuf and columns up to lds exist and are zero (the pack kernels' padding contract), so whole 16-byte items are
+// read; dst's padding is never written.
+__global__ __launch_bounds__(256) void transpose_f16_kernel(const half_t* __restrict__ src, half_t* __restrict__ dst, int R,
+                                                            int C, int Rbuf, int lds_, int ldd) {
+    __shared__ half_t t[64][72];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int e = threadIdx.x + 256 * k;          // 64 rows x 8 items
+        const int r = e >> 3, ch = e & 7;
+        h8 v = {};
+        if (r0 + r < Rbuf && c0 + ch * 8 + 8 <= lds_) v = *(const h8*)(src + (int64_t)(r0 + r) * lds_ + c0 + ch * 8);
+        *(h8*)&t[r][ch * 8] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int e = threadIdx.x + 256 * k;          // 64 output rows (c) x 8 items of 8 source rows
+        const int c = e & 63, rh = e >> 6;
+        if (c0 + c < C && r0 + rh * 8 < R) {
+            h8 v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (r0 + rh * 8 + j < R) ? t[rh * 8 + j][c] : (half_t)0.f;
+            *(h8*)(dst + (int64_t)(c0 + c) * ldd + r0 + rh * 8) = v;
+        }
+    }
+}
+int transpose_f16_launch(const half_t* src, half_t* dst, int R, int C, int Rbuf, int lds_, int ldd, hipStream_t st) {
+    hipLaunchKernelGGL(transpose_f16_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, st, src, dst, R, C, Rbuf,
+                       lds_, ldd);
+    return hipGetLastError() == hipSuccess ? OK : E_LAUNCH;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // fmri_apply_batch (round 4): ONE launch per sub-network between its last weight gradient and its next forward pass.
 // Rounds 1-3 ran, per parameter tensor, unpack_grad (slab sum + map to the reference layout, read-modify-write of the

@@ -27,6 +27,7 @@ _SIGS = {
     "fmri_pack_weight_batch": [_p, _i, _i, _p],
     "fmri_apply_entry_fill": [_p, _p, _p, _p, _p, _p, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _l,
                               _i, _f, _l, _i],
+    "fmri_transpose_f16": [_p, _p, _i, _i, _i, _i, _i, _p],
     "fmri_apply_batch": [_p, _i, _i, _i, _p, _f, _f, _f, _p, _f, _p, _p],
     "fmri_ingest_u8": [_p, _i, _i, _i, _i, _p, _p, _f, _f, _f, _f, _f, _f, _p, _p, _p],
     "fmri_crop_resize_u8": [_p, _p, _p, _i, _i, _i, _p, _p, _i, _p, _p, _i, _i, _p, _p],

@@ -111,6 +111,9 @@ class PackedWeight:
         return self.buf
 
 
+_TRANSPOSE_ON = os.environ.get("FMRI_PACK_TRANSPOSE") != "off"
+
+
 def _repack_group(group, skip=()):
     """Refresh every fp16 GEMM copy of a sub-network's weights after its master buffer changed: one batched launch
     (fmri_pack_weight_batch, device-resident table built once) + the few weights that need another pack path.
@@ -124,8 +127,15 @@ def _repack_group(group, skip=()):
         nbytes = L.fmri_pack_entry_bytes()
         rows, singles, tiles = [], [], 0
         skipped = set(id(pw) for pw in skip)
+        transposes = []
         for pw in packed:
             if id(pw) in skipped:
+                continue
+            src = getattr(pw, "transpose_of", None)
+            if src is not None and _TRANSPOSE_ON:
+                # a dense layer's second orientation: the transpose of its first fp16 copy (fmri_transpose_f16)
+                R, Cc = src.specs[0].rows, pw.specs[0].rows
+                transposes.append((_P(src.buf), _P(pw.buf), R, Cc, src.rows_pad, src.kpads[0], pw.kpads[0]))
                 continue
             for item in pw._items():
                 host = ctypes.create_string_buffer(nbytes)
@@ -140,11 +150,13 @@ def _repack_group(group, skip=()):
         dev_tab = None
         if rows:
             dev_tab = torch.frombuffer(bytearray(b"".join(rows)), dtype=torch.uint8).to(group.device)
-        tab = tabs[key] = dict(table=dev_tab, n=len(rows), tiles=tiles, singles=singles)
+        tab = tabs[key] = dict(table=dev_tab, n=len(rows), tiles=tiles, singles=singles, transposes=transposes)
     if tab["n"]:
         lib.call("fmri_pack_weight_batch", _P(tab["table"]), tab["n"], tab["tiles"])
     for item in tab["singles"]:
         lib.call("fmri_pack_weight", *item)
+    for item in tab["transposes"]:                   # (after the packs: their sources are current now)
+        lib.call("fmri_transpose_f16", *item)
     for pw in packed:
         pw.version = group.version
 
@@ -812,6 +824,10 @@ class DenseLayer:
             g = f
         self.pw_f = _single(self.w, group, f, self.t_out)
         self.pw_d = _single(self.w, group, d, self.t_in)
+        # the data-gradient orientation [k][n] is the transpose of the forward one [n][k] (the flatten permutation is the
+        # same column / row order in both): _repack_group makes it from the fp16 copy
+        if f.kcols == d.rows and d.kcols >= f.rows:
+            self.pw_d.transpose_of = self.pw_f
         self.gspec = g
 
     def _gemm(self, x, pw, M, Ci, Co, CoStore, tile, bias, act, want16, want32):

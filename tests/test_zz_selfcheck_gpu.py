@@ -369,3 +369,28 @@ def test_other_steps_two_runs_are_bit_identical(deterministic, kind):
     _finish()
     _assert_same_logs(a.logs(), b.logs(), kind)
     _assert_same_bits(a.state_dict(), b.state_dict(), f"two runs of {kind}")
+
+
+@pytest.mark.parametrize("stage", [2, 3])
+def test_cognitive_step_one_launch_update_equals_separate_launches(deterministic, stage):
+    """Stage II / III: ``CognitiveStep.step`` (deferred weight gradients, fmri_apply_batch with the scripts' gradient
+    clamp) against forward / gate / backward / apply with the separate launches: the same bits after three steps."""
+    from oracle import vaegan_oracle as O
+    from fmri_hip.params import ArchConfig
+    from fmri_hip.steps import CognitiveStep
+    cfg, cfg_o, B, V = ArchConfig.px64(), O.ArchCfg.px64(), 8, 512
+    data = O.synth_batch(B, cfg_o, n_voxels=V, seed=4321, steps=1)
+    x, fm = data["x"].to(DEV), data["fmri"].to(DEV)
+    nz = [t.to(DEV) for t in data["noise"][0]]
+    a, b = CognitiveStep(cfg, V, DEV, stage), CognitiveStep(cfg, V, DEV, stage)
+    a.load_recipe(3, True)
+    b.load_state_dict(a.state_dict())
+    for _ in range(3):
+        a.step(fm, x, nz[0], nz[1], nz[2])
+        b.forward(fm, x, nz[0], nz[1], nz[2])
+        b.gate(B)
+        b.backward()
+        b.apply()
+    _finish()
+    _assert_same_logs(a.logs(), b.logs(), f"stage {stage}")
+    _assert_same_bits(a.state_dict(), b.state_dict(), f"stage {stage}: one launch vs separate")

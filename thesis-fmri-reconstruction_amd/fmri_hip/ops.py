@@ -480,7 +480,7 @@ def begin_grads(group, defer: bool):
     defer = bool(defer and _FUSED_APPLY)
     group.drop_pending()
     group.defer_grads = defer
-    plan = getattr(group, "_apply_plan", None) if defer else None
+    plan = getattr(group, "_flat_clear", None) if defer else None
     if plan is not None and plan["flat"] is not None:
         lib.call("fmri_apply_batch", _P(plan["flat"]), plan["flat_n"], plan["flat_tiles"], 2, None, 0.0, 0.0, 1.0,
                  None, 0.0, None)
@@ -490,14 +490,16 @@ def begin_grads(group, defer: bool):
         group._cleared = "all"
 
 
-def _plan_apply(group, state):
+def _plan_apply(group, state, update=True):
     """Device table of fmri_apply_batch for the pending gradients of ``group`` (cached while the same buffers come
     back), or None when some tensor cannot go through it."""
     L = lib.load()
     pend = group.pending
-    key = tuple((p[0].data_ptr(), tuple(p[0].shape), p[1].data_ptr(), p[3], p[4]) for p in pend) + (state.data_ptr(),)
-    plan = getattr(group, "_apply_plan", None)
-    if plan is not None and plan["key"] == key:
+    key = tuple((p[0].data_ptr(), tuple(p[0].shape), p[1].data_ptr(), p[3], p[4]) for p in pend) + \
+        (state.data_ptr(), update)
+    plans = group.__dict__.setdefault("_apply_plans", {})
+    plan = plans.get(key)
+    if plan is not None:
         return plan
     nbytes = L.fmri_apply_entry_bytes()
     g0, n_all = group.grad.data_ptr(), group.grad.numel()
@@ -514,14 +516,14 @@ def _plan_apply(group, state):
             return None                                   # two gradients of one tensor in one pass: separate launches
         nsl = packed.shape[0] if packed.dim() == 3 else 1
         pk, kpad = None, 0
-        for pw in by_master.get(group.data.data_ptr() + 4 * off, []):
+        for pw in by_master.get(group.data.data_ptr() + 4 * off, []) if update else ():
             if pw.specs[0] == sp and pw.rows_pad >= sp.rows:
                 pk, kpad = pw.buf.data_ptr() + 2 * pw.offsets[0], pw.kpads[0]
                 fused.append(pw)
                 break
         host = ctypes.create_string_buffer(nbytes)
-        n = L.fmri_apply_entry_fill(host, packed.data_ptr(), group.data.data_ptr() + 4 * off, state.data_ptr() + 4 * off,
-                                    gv.data_ptr(), pk, sp.sa, sp.sta, sp.sb, sp.stb, sp.A, sp.TA, sp.B, sp.KW, sp.py,
+        n = L.fmri_apply_entry_fill(host, packed.data_ptr(), group.data.data_ptr() + 4 * off,
+                                    state.data_ptr() + (4 * off if update else 0), gv.data_ptr(), pk, sp.sa, sp.sta, sp.sb, sp.stb, sp.A, sp.TA, sp.B, sp.KW, sp.py,
                                     sp.px, sp.step, sp.TH, sp.TW, ld, kpad, nsl, packed.shape[-2] * packed.shape[-1],
                                     1 if getattr(packed, "_fmri_clear", False) else 0, float(scale), 0, tiles)
         if n < 0:
@@ -543,7 +545,8 @@ def _plan_apply(group, state):
     for o, n in segs:
         for tile0, dst in ((tiles, rows), (ftiles, flat_rows)):
             host = ctypes.create_string_buffer(nbytes)
-            k = L.fmri_apply_entry_fill(host, None, group.data.data_ptr() + 4 * o, state.data_ptr() + 4 * o, g0 + 4 * o,
+            k = L.fmri_apply_entry_fill(host, None, group.data.data_ptr() + 4 * o,
+                                        state.data_ptr() + (4 * o if update else 0), g0 + 4 * o,
                                         None, 0, 0, 0, 0, 1, 1, 1, 1, 0, 0, 1, 1, 1, 0, 0, 1, 0, 0, 1.0, n, tile0)
             if k <= 0:
                 lib.check(k if k < 0 else -1, "fmri_apply_entry_fill")
@@ -553,7 +556,11 @@ def _plan_apply(group, state):
     up = lambda rr: torch.frombuffer(bytearray(b"".join(rr)), dtype=torch.uint8).to(group.device) if rr else None
     plan = dict(key=key, table=up(rows), n=len(rows), tiles=tiles, flat=up(flat_rows), flat_n=len(flat_rows),
                 flat_tiles=ftiles, sig=tuple(segs), covered=covered, fused=fused)
-    group._apply_plan = plan
+    plans[key] = plan
+    if getattr(group, "_flat_clear", None) is None:
+        # what begin_grads clears from now on: the first table's flat segments -- every 1-D parameter is in them (and,
+        # when the table was built for a part of the group, tensors of the rest: cleared for nothing, a few MB)
+        group._flat_clear = plan
     return plan
 
 
@@ -578,6 +585,28 @@ def flush_pending(group):
             packed.zero_()
         if getattr(packed, "_fmri_hold", None) is not None:
             packed._fmri_hold["busy"] = False
+
+
+def materialize_grads(group):
+    """Deferred gradients -> reference-layout gradient buffer in ONE launch (fmri_apply_batch mode 0: slab sums mapped
+    and stored, no read-modify-write, no memset in front) -- what a data-parallel step does before the gradient
+    all-reduce.  May be called for a part of the group's tensors (the ones queued so far)."""
+    if not getattr(group, "defer_grads", False) or not group.pending:
+        return
+    st = group.__dict__.get("_no_state")
+    if st is None:
+        st = group._no_state = torch.zeros(1, dtype=torch.float32, device=group.device)
+    plan = _plan_apply(group, st, update=False)
+    if plan is None:
+        flush_pending(group)
+        return
+    lib.note(bytes=8.0 * group.numel)
+    lib.call("fmri_apply_batch", _P(plan["table"]), plan["n"], plan["tiles"], 0, None, 0.0, 0.0, 1.0, None, 0.0, None)
+    for p in group.pending:
+        h = getattr(p[0], "_fmri_hold", None)
+        if h is not None:
+            h["busy"] = False
+    group.pending = []            # (defer_grads stays on: the rest of the pass may queue more)
 
 
 def apply_group(group, state, lr_dev, alpha, eps, flag, gdev, clamp=0.0) -> bool:

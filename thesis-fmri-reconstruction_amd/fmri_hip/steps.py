@@ -251,6 +251,14 @@ class _GanStepBase:
         _attach_reducers(nets, self.dd)
         self.fw: Dict[str, object] = {}
 
+    def _reduce_async(self, group, part=None):
+        """Data parallel: the sub-network's deferred weight gradients -> reference layout (one launch), then the
+        asynchronous SUM all-reduce of the gradient buffer (or of ``part`` of it).  Nothing on one GPU: the gradients
+        stay deferred until the update (ops.apply_group)."""
+        if self.dd.on:
+            ops.materialize_grads(group)
+            self.dd.all_reduce_async(group.grad if part is None else part)
+
     def _slot(self, i):
         return self.scal[i:i + 1]
 
@@ -483,7 +491,7 @@ class Stage1Step(_GanStepBase):
         dev = fw["disc_in"].device
         # ``early_apply`` also says that nobody reads reference-layout gradients between this pass and the updates: on one
         # GPU the weight gradients then stay in their GEMM layout until the sub-network's one fmri_apply_batch launch
-        fuse = early_apply and not self.dd.on and self.dd.recorder is None
+        fuse = early_apply and self.dd.recorder is None
         for n in (self.enc, self.dec, self.dis):
             ops.begin_grads(n.group, fuse)
         dlogit16, dfeat16 = self._start_cotangents(fw["feat"], fw["logit32"], B)
@@ -501,7 +509,7 @@ class Stage1Step(_GanStepBase):
         if early:
             ops.side_run(dev, lambda: self._reduce_apply(self.opt_dis, self.dis, self.flags[0:1], S_NA))
         else:
-            self.dd.all_reduce_async(self.dis.group.grad)
+            self._reduce_async(self.dis.group)
         # decoder cotangent, stored = dec * nA * (lambda*B_true - (1-lambda)*A_true); the weights lambda*nA/nB and
         # 1-lambda are device scalars written by the gate kernel (a recorded step follows the lambda schedule)
         cot = torch.empty(3 * B, H, W, 8, dtype=torch.float16, device=dev)
@@ -518,7 +526,7 @@ class Stage1Step(_GanStepBase):
         if early:
             ops.side_run(dev, lambda: self._reduce_apply(self.opt_dec, self.dec, self.flags[1:2], S_GDEC))
         else:
-            self.dd.all_reduce_async(self.dec.group.grad)
+            self._reduce_async(self.dec.group)
         dhead32 = torch.empty(B, 2 * Z, dtype=torch.float32, device=dev)
         # KL weight: 1, or beta / batch for 'beta-vae' (train_vgan_stage1.py:360-362).  The gate kernel writes it to
         # the device slot S_KLW from the device-resident hyper-parameters, so that a recorded (HIP-graph) step follows
@@ -536,13 +544,18 @@ class Stage1Step(_GanStepBase):
         if early and dp:
             # the fc.0 ... l_var tail (93 % of the buffer) is reduced on the side stream as soon as the fc weight gradient
             # is final there, under the conv backward; the conv head right behind the last weight gradient
+            def reduce_part(part):                  # (side stream) the weight gradients queued so far -> reference layout
+                ops.materialize_grads(eg)
+                self.dd.all_reduce(part)
             self.enc.backward(fw["ectx"], dhead16, sc.enc, join=False, after_fc_join=False,
-                              after_fc=lambda: ops.side_run(dev, lambda: self.dd.all_reduce(eg.grad[tail:])))
-            ops.side_run(dev, lambda: self.dd.all_reduce(eg.grad[:tail]))
+                              after_fc=lambda: ops.side_run(dev, lambda: reduce_part(eg.grad[tail:])))
+            ops.side_run(dev, lambda: reduce_part(eg.grad[:tail]))
             ops.join_side()
             return
         self.enc.backward(fw["ectx"], dhead16, sc.enc,                  # grads = S_NE * true
-                          after_fc=(lambda: self.dd.all_reduce_async(eg.grad[tail:])) if dp else None)
+                          after_fc=(lambda: self._reduce_async(eg, eg.grad[tail:])) if dp else None)
+        if dp:
+            ops.materialize_grads(eg)
         self.dd.all_reduce(eg.grad[:tail])
         self.dd.wait_all()
 
@@ -602,6 +615,8 @@ class Stage1Step(_GanStepBase):
     def _reduce_apply(self, opt, net, flag, slot):
         """(current stream = the side stream) SUM all-reduce of the sub-network's gradient buffer over the ranks -- nothing
         on one GPU --, then its optimizer update and the refresh of everything derived from its weights."""
+        if self.dd.on:
+            ops.materialize_grads(net.group)         # deferred weight gradients -> reference layout, one launch
         self.dd.all_reduce(net.group.grad)
         self._apply_one(opt, net, flag, slot)
 
@@ -806,17 +821,21 @@ class CognitiveStep(_GanStepBase):
         else:
             self._gate(B_global, self.fw["F"], True)
 
-    def backward(self):
+    def backward(self, fuse: bool = False):
+        """``fuse`` (used by ``step``): the updates follow right behind and nobody reads reference-layout gradients in
+        between -- weight gradients stay in their GEMM layout until the sub-network's one fmri_apply_batch launch
+        (ops.begin_grads)."""
         fw, sc, hp, cfg = self.fw, self.sc, self.hp, self.cfg
         B, H, W, Z = fw["B"], fw["H"], fw["W"], cfg.latent_dim
         dev = fw["disc_in"].device
+        fuse = fuse and self.dd.recorder is None
         dlogit16, dfeat16 = self._start_cotangents(fw["feat"], fw["logit32"], B)
         if self.stage == 2:
-            self.cog.group.zero_grad()
-            self.dis.group.zero_grad()
+            ops.begin_grads(self.cog.group, fuse)
+            ops.begin_grads(self.dis.group, fuse)
             _, dimg_b = self.dis.backward(fw["sctx"], dlogit16, sc.a, dfeat16, sc.b, True, slice(B, 2 * B),
                                           img_streams=(False, True))
-            self.dd.all_reduce_async(self.dis.group.grad)       # under the decoder / cognitive-encoder backward
+            self._reduce_async(self.dis.group)                  # under the decoder / cognitive-encoder backward
             entries = [dict(g=fw["g_tilde"], scale=sc.b, train=False, need_dz=True)]
             dz = self.dec.backward(fw["dctx"], dimg_b, entries)[0]
             dhead32 = torch.empty(B, 2 * Z, dtype=torch.float32, device=dev)
@@ -824,17 +843,17 @@ class CognitiveStep(_GanStepBase):
                      Z, 1.0, None, _P(dhead32), 1)
             dhead16 = self._renorm(dhead32, sc.enc, self._slot(S_NB), B * self.dd.world)
             self.cog.backward(fw["cctx"], dhead16, sc.enc)
-            self.dd.all_reduce_async(self.cog.group.grad)
+            self._reduce_async(self.cog.group)
             self.dd.wait_all()
         else:
-            self.dec.group.zero_grad()
-            self.dis.group.zero_grad()
+            ops.begin_grads(self.dec.group, fuse)
+            ops.begin_grads(self.dis.group, fuse)
             dimg_a, dimg_b = self.dis.backward(fw["sctx"], dlogit16, sc.a, dfeat16, sc.b, True, slice(B, 3 * B))
-            self.dd.all_reduce_async(self.dis.group.grad)       # under the decoder backward
+            self._reduce_async(self.dis.group)                  # under the decoder backward
             cot = axpby(dimg_b, dimg_a, sc.dec / sc.b, -sc.dec / sc.a, a_dev=self._slot(S_C1), b_dev=self._slot(S_C2))
             entries = [dict(g=0, scale=sc.dec, train=True), dict(g=1, scale=sc.dec, train=True)]
             self.dec.backward(fw["dctx"], cot, entries)
-            self.dd.all_reduce_async(self.dec.group.grad)
+            self._reduce_async(self.dec.group)
             self.dd.wait_all()
 
     def apply(self):
@@ -848,7 +867,7 @@ class CognitiveStep(_GanStepBase):
     def step(self, fmri, image, eps, z_p, eps_teacher=None):
         fw = self.forward(fmri, image, eps, z_p, eps_teacher)
         self.gate(fw["B"] * self.dd.world)
-        self.backward()
+        self.backward(fuse=True)
         self.apply()
         return self.scal
 

@@ -388,7 +388,8 @@ int fmri_adam_dev(float* p, const float* g, float* m, float* v, int64_t n, const
  *   fmri_apply_batch  mode 1: w, sq <- RMSprop(w, sq, g * gscale / *gdev) exactly as fmri_rmsprop_dev (same operations,
  *       same order: bit-identical to the separate launches), skipped when *flag == 0; mode 0: gradients only, stored
  *       (not added) into `grad` in the reference layout; mode 2: zero the flat segments' `grad` (the start of a
- *       backward pass, instead of a memset of the whole gradient buffer). */
+ *       backward pass, instead of a memset of the whole gradient buffer); mode 3: as mode 1 with every gradient read
+ *       from `grad` (reference layout, e.g. mode 0's result summed over the ranks by an all-reduce). */
 /* dst[c][r] = src[r][c] (fp16; r < R, c < C; leading dimensions multiples of 8, ld_dst >= R rounded up to 8; src holds
  * src_rows >= R rows, the rows from R on and the columns up to ld_src zero): the data-gradient orientation of a dense
  * layer's fp16 weight made from its forward orientation instead of a second pass over the fp32 master

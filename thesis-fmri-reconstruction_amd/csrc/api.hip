@@ -192,7 +192,7 @@ int fmri_apply_entry_fill(void* host_entry, const float* gsrc, float* w, float* 
 
 int fmri_apply_batch(const void* table_dev, int n, int total_tiles, int mode, const float* lr_dev, float alpha, float eps,
                      float gscale, const float* gdev, float clamp, const int* flag, void* stream) {
-    if (!table_dev || n < 0 || total_tiles < 0 || mode < 0 || mode > 2 || (mode == 1 && !lr_dev)) return FMRI_E_BADARG;
+    if (!table_dev || n < 0 || total_tiles < 0 || mode < 0 || mode > 3 || ((mode == 1 || mode == 3) && !lr_dev)) return FMRI_E_BADARG;
     ApplyOpt o;
     o.lr_dev = lr_dev; o.gdev = gdev; o.flag = flag; o.alpha = alpha; o.eps = eps; o.gscale = gscale; o.clamp = clamp;
     o.mode = mode;

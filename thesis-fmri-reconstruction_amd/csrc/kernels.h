@@ -58,7 +58,8 @@ struct ApplyOpt {
     const float* lr_dev; const float* gdev; const int* flag;
     float alpha, eps, gscale, clamp;
     int32_t mode;          // 0: gradients only (reference layout, first-writer stores), 1: RMSprop update + fp16 copy,
-                           // 2: clear the flat segments' gradients
+                           // 2: clear the flat segments' gradients, 3: as 1 with the gradient read from the reference
+                           //    layout (`grad`, e.g. after an all-reduce) instead of gsrc
 };
 constexpr int APPLY_CHUNK = 1024;       // elements per block of kinds 1 / 2
 int apply_entry_tiles(ApplyEntry& e, int TH, int TW, int KW, int py, int px, int step, int64_t stb);

@@ -532,9 +532,10 @@ __global__ __launch_bounds__(256) void apply_batch_kernel(const ApplyEntry* __re
     __syncthreads();
     const ApplyEntry& en = tab[sel];
     const int tile = blockIdx.x - en.tile_begin;
-    const bool update = o.mode == 1;
+    const bool update = o.mode == 1 || o.mode == 3;
+    const bool from_grad = o.mode == 3;     // the gradient is read from the reference layout (summed over the ranks there)
     const bool live = !update || !o.flag || *o.flag != 0;          // a gated-off optimizer step changes nothing
-    if (!live && (!en.clear || en.kind == 2)) return;
+    if (!live && (!en.clear || en.kind == 2 || from_grad)) return;
     const float lr = (update && o.lr_dev) ? *o.lr_dev : 0.f;
     const float gs = update ? o.gscale / (o.gdev ? *o.gdev : 1.f) : 1.f;
     if (en.kind == 2) {
@@ -561,11 +562,16 @@ __global__ __launch_bounds__(256) void apply_batch_kernel(const ApplyEntry* __re
             if (i >= total) break;
             const int row = (int)(i / en.B), b = (int)(i - (int64_t)row * en.B);
             const int ta = row / en.A, a = row - ta * en.A;
-            float* q = gsrc + (int64_t)row * en.ld + b;
-            const float v = slab_sum(q, en.nslabs, en.slab_stride) * en.scale;
-            if (en.clear) slab_clear(q, en.nslabs, en.slab_stride);
-            if (!live) continue;
             const int64_t off = a * en.sa + ta * en.sta + b * en.sb;
+            float v;
+            if (from_grad) {
+                v = en.grad[off];
+            } else {
+                float* q = gsrc + (int64_t)row * en.ld + b;
+                v = slab_sum(q, en.nslabs, en.slab_stride) * en.scale;
+                if (en.clear) slab_clear(q, en.nslabs, en.slab_stride);
+            }
+            if (!live) continue;
             if (!update) { en.grad[off] = v; continue; }
             const float nw = rms_update(v, en.w + off, en.sq + off, gs, lr, o);
             if (en.pk) en.pk[(int64_t)row * en.kpad + b] = (half_t)nw;
@@ -579,22 +585,24 @@ __global__ __launch_bounds__(256) void apply_batch_kernel(const ApplyEntry* __re
     const int ta = row / en.A, a = row - ta * en.A;
     const int stride = run | 1;
     float* s = gsrc + (int64_t)row * en.ld + b0;
-    for (int e = threadIdx.x; e < run * bt; e += 256) {
-        const int tb = e >> sh, bl = e & (bt - 1);
-        if (b0 + bl < en.B) {
-            float* q = s + tb * en.Bp + bl;
-            t[bl * stride + tb] = slab_sum(q, en.nslabs, en.slab_stride);
-            if (en.clear) slab_clear(q, en.nslabs, en.slab_stride);
+    if (!from_grad) {
+        for (int e = threadIdx.x; e < run * bt; e += 256) {
+            const int tb = e >> sh, bl = e & (bt - 1);
+            if (b0 + bl < en.B) {
+                float* q = s + tb * en.Bp + bl;
+                t[bl * stride + tb] = slab_sum(q, en.nslabs, en.slab_stride);
+                if (en.clear) slab_clear(q, en.nslabs, en.slab_stride);
+            }
         }
+        if (!live) return;
+        __syncthreads();
     }
-    if (!live) return;
-    __syncthreads();
     const int64_t base = a * en.sa + ta * en.sta;
     for (int e = threadIdx.x; e < bt * run; e += 256) {
         const int bl = e / run, j = e - bl * run;
         if (b0 + bl < en.B) {
-            const float v = t[bl * stride + j] * en.scale;
             const int64_t off = base + (b0 + bl) * en.sb + j;
+            const float v = from_grad ? en.grad[off] : t[bl * stride + j] * en.scale;
             if (!update) en.grad[off] = v;
             else t[bl * stride + j] = rms_update(v, en.w + off, en.sq + off, gs, lr, o);
         }

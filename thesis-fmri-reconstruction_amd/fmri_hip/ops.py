@@ -490,11 +490,11 @@ def begin_grads(group, defer: bool):
         group._cleared = "all"
 
 
-def _plan_apply(group, state, update=True):
+def _plan_apply(group, state, update=True, pend=None):
     """Device table of fmri_apply_batch for the pending gradients of ``group`` (cached while the same buffers come
     back), or None when some tensor cannot go through it."""
     L = lib.load()
-    pend = group.pending
+    pend = group.pending if pend is None else pend
     key = tuple((p[0].data_ptr(), tuple(p[0].shape), p[1].data_ptr(), p[3], p[4]) for p in pend) + \
         (state.data_ptr(), update)
     plans = group.__dict__.setdefault("_apply_plans", {})
@@ -564,20 +564,20 @@ def _plan_apply(group, state, update=True):
     return plan
 
 
-def flush_pending(group):
-    """Deferred gradients -> the reference-layout gradient buffer (what the separate launches would have left there)."""
+def flush_pending(group, keep=()):
+    """Deferred gradients -> the reference-layout gradient buffer (what the separate launches would have left there).
+    ``keep``: queue entries whose gradients materialize_grads has already put there."""
     pend, group.pending = getattr(group, "pending", []), []
     group.defer_grads = False
-    if not pend:
-        return
     if getattr(group, "_cleared", "all") != "all":
         # only the 1-D segments were cleared at the start of this pass: clear what the tensors' ranges still hold
         g0 = group.grad.data_ptr()
+        holes = sorted(list(group._cleared) + [((p[1].data_ptr() - g0) // 4, p[1].numel()) for p in keep])
         at = 0
-        for o, n in list(group._cleared) + [(group.grad.numel(), 0)]:
+        for o, n in holes + [(group.grad.numel(), 0)]:
             if o > at:
                 group.grad[at:o].zero_()
-            at = o + n
+            at = max(at, o + n)
         group._cleared = "all"
     for packed, gv, sp, ld, scale in pend:
         unpack_grad(packed, gv, sp, ld, scale)
@@ -606,6 +606,7 @@ def materialize_grads(group):
         h = getattr(p[0], "_fmri_hold", None)
         if h is not None:
             h["busy"] = False
+    group.materialized = getattr(group, "materialized", []) + group.pending
     group.pending = []            # (defer_grads stays on: the rest of the pass may queue more)
 
 
@@ -616,13 +617,22 @@ def apply_group(group, state, lr_dev, alpha, eps, flag, gdev, clamp=0.0) -> bool
     (nothing deferred, or a tensor the table cannot describe); the caller then runs the optimizer and the re-pack."""
     if not getattr(group, "defer_grads", False):
         return False
-    plan = _plan_apply(group, state) if group.pending else None
+    done = getattr(group, "materialized", [])
+    group.materialized = []
+    plan, mode = None, 1
+    if group.pending and not done:
+        plan = _plan_apply(group, state)
+    elif done and not group.pending:
+        # data parallel: every gradient already sits in the reference layout (materialize_grads, all-reduced since); the
+        # same table drives the update from there (mode 3)
+        mode = 3
+        plan = _plan_apply(group, state, pend=done)
     if plan is None or (group._cleared != "all" and group._cleared != plan["sig"]):
-        flush_pending(group)
+        flush_pending(group, keep=done)
         return False
     lib.note(bytes=22.0 * group.numel)
-    lib.call("fmri_apply_batch", _P(plan["table"]), plan["n"], plan["tiles"], 1, _P(lr_dev), alpha, eps, 1.0, _P(gdev),
-             clamp, _P(flag))
+    lib.call("fmri_apply_batch", _P(plan["table"]), plan["n"], plan["tiles"], mode, _P(lr_dev), alpha, eps, 1.0,
+             _P(gdev), clamp, _P(flag))
     for p in group.pending:
         h = getattr(p[0], "_fmri_hold", None)
         if h is not None:

@@ -237,6 +237,7 @@ class FlatGroup:
             if getattr(p[0], "_fmri_hold", None) is not None:
                 p[0]._fmri_hold["busy"] = False
         self.pending = []
+        self.materialized = []
         self.defer_grads = False
 
     def zero_grad(self):

@@ -126,7 +126,7 @@ def live_pmc_traffic(family, timeout_s=75):
             out = os.path.join(tmp, counter)
             cmd = [rocprof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "x", "--",
                    sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "2", "--eager", "--serial",
-                   "--no-cpu-baseline", "--no-hbm-rows", "--no-pmc"]
+                   "--no-cpu-baseline", "--no-hbm-rows", "--no-pmc", "--no-gate-pass"]
             r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=timeout_s,
                                stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             files = [os.path.join(d, f) for d, _, fs in os.walk(out) for f in fs if f.endswith("counter_collection.csv")]
@@ -399,6 +399,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="samples per GPU (weak scaling); 0 = the workload's own")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-rows", action="store_true")
+    ap.add_argument("--no-gate-pass", dest="gate_pass", action="store_false",
+                    help="skip the extra timed pass with the engine's default gate_skip=True")
     ap.add_argument("--no-pmc", action="store_true",
                     help="do not run the two rocprofv3 counter passes for roofline.traffic (then the committed passes of "
                          "the same command under profiles/ are quoted)")
@@ -454,6 +456,13 @@ def main():
     metric, unit, desc, wl_batch, builder = WORKLOADS[a.workload]
     B = a.batch or wl_batch
     st, run_i, flop_per_sample, rot = builder(dev, B, rank, world > 1 or force_dist, a.sync_bn)
+    # The headline runs EVERY GEMM of the step in every step (what `gflop_per_sample` counts): the engine's default of
+    # conditioning a sub-network's weight gradients on the equilibrium gate (Stage1Step(gate_skip=True) -- the reference
+    # does not run `loss_discriminator.backward()` when the gate switches the discriminator off) is off here, and is
+    # measured separately below (`gate_skip` in the output line).
+    has_gate = hasattr(st, "gate_skip")
+    if has_gate:
+        st.gate_skip = False
 
     def barrier():
         if world > 1:
@@ -543,6 +552,36 @@ def main():
     dt = time.perf_counter() - t0
     log(f"timed region done: {1e3 * dt / a.steps:.2f} ms/step ({mode})")
     logs = st.logs()
+    # the same steps with the engine's default gate_skip=True (launches that are recorded into a full-step graph keep the
+    # setting they were recorded with, so this pass uses the hybrid / eager launches), and how often the gate trained what
+    gate_out = None
+    if has_gate and a.gate_pass and a.workload in ("stage1", "stage2"):
+        grun = modes.get("hybrid", run_i)
+        st.gate_skip = True
+        for i in range(10):
+            grun(i)
+        barrier()
+        gsteps, seen = min(a.steps, 100), []
+        tg = time.perf_counter()
+        for i in range(gsteps):
+            grun(i)
+            seen.append(st.flags.clone())
+        barrier()
+        tgd = torch.tensor([time.perf_counter() - tg], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tgd, op=dist.ReduceOp.MAX)
+        frac = torch.stack(seen).float().mean(0).tolist()
+        st.gate_skip = False
+        gate_out = {"ms_per_step": round(1e3 * float(tgd.item()) / gsteps, 3),
+                    "value": round(world * B * gsteps / float(tgd.item()), 1), "steps": gsteps,
+                    "launch": "hybrid" if "hybrid" in modes else "eager",
+                    "steps_training_discriminator": round(frac[0], 3), "steps_training_decoder": round(frac[1], 3),
+                    "note": "engine default: weight-gradient GEMMs of a sub-network the equilibrium gate does not train in "
+                            "a step retire at once (fmri_wgrad_if; the reference skips that loss.backward(), "
+                            "train_vgan_stage1.py:420-431).  Data dependent -- on this synthetic data the gate keeps the "
+                            "discriminator off in most steps -- hence not the headline: `value` runs every GEMM"}
+        log(f"gate-skip pass: {gate_out['ms_per_step']} ms/step, discriminator trained in {frac[0]:.2f}, decoder in "
+            f"{frac[1]:.2f} of the steps")
     # dominant-kernel timing: HIP events around every fmri_igemm launch over a few eagerly issued steps (events cannot be
     # placed inside a replayed graph).  The side stream is switched off for this pass: next to concurrently running
     # weight-gradient kernels a launch's duration says nothing about the kernel.
@@ -598,7 +637,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": desc, "name": a.workload, "batch_per_gpu": B, "global_batch": B * world,
-                       "synthetic_batches": NBATCH,
+                       "synthetic_batches": NBATCH, "gate_skip": False if has_gate else None,
                        "parallelism": f"dp{world}" + ("" if world == 1 else ("-syncbn" if a.sync_bn else "-localbn"))},
             "roofline": {"bound": "mfma" if mfma_bound else "hbm", "achieved": round(achieved, 1), "peak": peak,
                          "unit": runit, "frac": round(achieved / peak, 4), "traffic": traffic,
@@ -632,6 +671,8 @@ def main():
             "losses_last_step": {k: v for k, v in logs.items() if isinstance(v, float)},
             "losses_finite": bool(finite),
         }
+        if gate_out is not None:
+            out["gate_skip"] = gate_out
         if world == 1 and not a.no_hbm_rows:
             out["hbm_bound_kernels"] = dict(peak_gb_s=HBM_PEAK_GBS, rows=hbm_rows(dev, 256))
         if world == 1 and not a.no_cpu_baseline and a.workload == "stage1":

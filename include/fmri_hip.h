@@ -135,6 +135,14 @@ int fmri_igemm_route(int N, int Hi, int Wi, int Ci, int Ho, int Wo, int CoStore,
 int fmri_wgrad(const void* P, const void* Q, float* out, const void* zero16, int N, int Yc, int Xc, int A, int Hq,
                int Wq, int Bc, int k, int stride, int pad, int flip, int apad, int ba_tile, int ldo, int splits,
                int atomic, void* stream);
+/* The same launch under a device-side condition: with gate != NULL and *gate == 0 when the kernel starts, it does
+ * nothing (`out` is left as it is).  The reference runs `loss_decoder.backward()` / `loss_discriminator.backward()` only
+ * `if train_dec:` / `if train_dis:` (train_vgan_stage1.py:420-431: the equilibrium gate of :395-403); the engine's
+ * gate is evaluated on the device (fmri_compose_gate_dev), so the host always issues the launches and the kernels of a
+ * sub-network that is not trained in this step retire at once. */
+int fmri_wgrad_if(const int* gate, const void* P, const void* Q, float* out, const void* zero16, int N, int Yc, int Xc,
+                  int A, int Hq, int Wq, int Bc, int k, int stride, int pad, int flip, int apad, int ba_tile, int ldo,
+                  int splits, int atomic, void* stream);
 /* atomic = 0: one split, plain stores.  1: atomic adds into a pre-zeroed out.  2: split z stores its partial result
  * to out + z*apad*ldo (stride-2, 128-row, 32-channel-block geometries only -- csrc/wgrad_win.hip -- else
  * FMRI_E_UNSUPPORTED).  For that kernel `splits` is the block budget per (128-row, 32-channel) group over the 4
@@ -389,7 +397,9 @@ int fmri_adam_dev(float* p, const float* g, float* m, float* v, int64_t n, const
  *       same order: bit-identical to the separate launches), skipped when *flag == 0; mode 0: gradients only, stored
  *       (not added) into `grad` in the reference layout; mode 2: zero the flat segments' `grad` (the start of a
  *       backward pass, instead of a memset of the whole gradient buffer); mode 3: as mode 1 with every gradient read
- *       from `grad` (reference layout, e.g. mode 0's result summed over the ranks by an all-reduce). */
+ *       from `grad` (reference layout, e.g. mode 0's result summed over the ranks by an all-reduce).
+ *       gated != 0: the weight gradients behind gsrc were launched with fmri_wgrad_if under the same `flag` -- when it
+ *       is 0 they added nothing and the `clear` pass is skipped as well. */
 /* dst[c][r] = src[r][c] (fp16; r < R, c < C; leading dimensions multiples of 8, ld_dst >= R rounded up to 8; src holds
  * src_rows >= R rows, the rows from R on and the columns up to ld_src zero): the data-gradient orientation of a dense
  * layer's fp16 weight made from its forward orientation instead of a second pass over the fp32 master
@@ -401,7 +411,7 @@ int fmri_apply_entry_fill(void* host_entry, const float* gsrc, float* w, float* 
                           int TH, int TW, int ld, int kpad, int nslabs, int64_t slab_stride, int clear, float scale,
                           int64_t flat_n, int tile_begin);
 int fmri_apply_batch(const void* table_dev, int n, int total_tiles, int mode, const float* lr_dev, float alpha, float eps,
-                     float gscale, const float* gdev, float clamp, const int* flag, void* stream);
+                     float gscale, const float* gdev, float clamp, const int* flag, int gated, void* stream);
 
 #ifdef __cplusplus
 }

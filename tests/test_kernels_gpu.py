@@ -496,6 +496,42 @@ def test_dense_forward_dgrad_wgrad(M, K, N, in_perm, out_perm):
         _close(g.grads["b"].cpu() * 2.0, dy.sum(0), "dense bias grad")
 
 
+@pytest.mark.parametrize("case", ["window (stride 2, 128 rows)", "narrow (5x5 stride 1, 32 x 8)", "generic (dense)"])
+def test_gated_weight_gradient_launch(case):
+    """fmri_wgrad_if: with the device flag at 0 the launch leaves its output untouched (whatever kernel the geometry is
+    routed to), with the flag at 1 it is fmri_wgrad."""
+    from fmri_hip import ops
+    torch.manual_seed(3)
+    if case.startswith("window"):
+        N, A, Bc, k, s, pad, Hq, Yc = 8, 128, 64, 5, 2, 2, 16, 8
+    elif case.startswith("narrow"):
+        N, A, Bc, k, s, pad, Hq, Yc = 2048, 32, 8, 5, 1, 2, 16, 16          # >= 32768 8x8 tiles: the narrow kernel
+    else:
+        N, A, Bc, k, s, pad, Hq, Yc = 64, 256, 128, 1, 1, 0, 1, 1
+    P = torch.randn(N, Yc, Yc, A, device=DEV).half()
+    Q = torch.randn(N, Hq, Hq, Bc, device=DEV).half()
+    flag = torch.ones(1, dtype=torch.int32, device=DEV)
+    was = ops._DET["on"]
+    ops.set_deterministic(True)           # slab outputs (plain stores): two launches give the same bits
+    try:
+        ref, _ = ops.run_wgrad(P, Q, N, Yc, Yc, A, Hq, Hq, Bc, k, s, pad)
+        on, _ = ops.run_wgrad(P, Q, N, Yc, Yc, A, Hq, Hq, Bc, k, s, pad, gate=flag)
+        hold = {}
+        ops.run_wgrad(P, Q, N, Yc, Yc, A, Hq, Hq, Bc, k, s, pad, hold=hold)          # allocates the persistent buffer
+        buf = [v for kk, v in hold.items() if kk != "busy"][0]
+        buf.fill_(7.0)
+        hold["busy"] = False
+        flag.zero_()
+        off, _ = ops.run_wgrad(P, Q, N, Yc, Yc, A, Hq, Hq, Bc, k, s, pad, hold=hold, gate=flag)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_deterministic(was)
+    cols = k * k * Bc                      # (the columns behind them are padding nobody writes or reads)
+    assert float(ref[..., :cols].abs().max()) > 0
+    assert torch.equal(ref[..., :cols], on[..., :cols]), "flag = 1 differs from the unconditional launch"
+    assert off.data_ptr() == buf.data_ptr() and bool((off == 7.0).all()), "flag = 0 wrote into the output"
+
+
 @pytest.mark.parametrize("R,C", [(1, 8), (100, 130), (64, 64), (129, 72), (512, 16384)])
 def test_transpose_f16(R, C):
     """fmri_transpose_f16 against torch on ragged shapes; the padding of the destination stays untouched."""

@@ -394,3 +394,35 @@ def test_cognitive_step_one_launch_update_equals_separate_launches(deterministic
     _finish()
     _assert_same_logs(a.logs(), b.logs(), f"stage {stage}")
     _assert_same_bits(a.state_dict(), b.state_dict(), f"stage {stage}: one launch vs separate")
+
+
+def test_gated_weight_gradients_change_nothing_but_the_work(deterministic):
+    """``gate_skip`` (fmri_wgrad_if: no weight-gradient GEMMs for a sub-network the equilibrium gate does not train in a
+    step, as the reference skips that ``loss.backward()``) against an engine that always runs them and only conditions the
+    update: the same bits after six steps in which the gate switches the discriminator off and on."""
+    from oracle import vaegan_oracle as O
+    from fmri_hip.params import ArchConfig
+    from fmri_hip.steps import GanHyper, Stage1Step
+    B = 8
+    data = O.synth_batch(B, O.ArchCfg.px64(), seed=1234, steps=1)
+    x, e, zp = data["x"].to(DEV), data["noise"][0, 0].to(DEV), data["noise"][0, 1].to(DEV)
+    hp = dict(equilibrium=0.72, margin=0.02)          # bce of a fresh discriminator ~ 0.69: below equilibrium - margin
+    a = Stage1Step(ArchConfig.px64(), DEV, hp=GanHyper(**hp), gate_skip=True)
+    a.load_recipe(0, True)
+    b = Stage1Step(ArchConfig.px64(), DEV, hp=GanHyper(**hp), gate_skip=False)
+    b.load_state_dict(a.state_dict())
+    seen = set()
+    for it in range(6):
+        if it == 3:                                   # re-arm: both sub-networks trained again
+            a.set_hyper(equilibrium=0.68, margin=0.35)
+            b.set_hyper(equilibrium=0.68, margin=0.35)
+        a.step(x, e, zp)
+        b.step(x, e, zp)
+        _finish()
+        la, lb = a.logs(), b.logs()
+        seen.add((la["train_dis"], la["train_dec"]))
+        _assert_same_logs(la, lb, f"gated vs ungated, step {it}")
+    _assert_same_bits(a.state_dict(), b.state_dict(), "gated vs ungated")
+    for n in ("opt_enc", "opt_dec", "opt_dis"):
+        assert torch.equal(getattr(a, n).s1, getattr(b, n).s1), f"{n}: RMSprop state differs"
+    assert len(seen) >= 2 and any(not (d and c) for d, c in seen), f"the gate never switched a sub-network off: {seen}"

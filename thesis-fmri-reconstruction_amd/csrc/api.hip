@@ -191,11 +191,11 @@ int fmri_apply_entry_fill(void* host_entry, const float* gsrc, float* w, float* 
 }
 
 int fmri_apply_batch(const void* table_dev, int n, int total_tiles, int mode, const float* lr_dev, float alpha, float eps,
-                     float gscale, const float* gdev, float clamp, const int* flag, void* stream) {
+                     float gscale, const float* gdev, float clamp, const int* flag, int gated, void* stream) {
     if (!table_dev || n < 0 || total_tiles < 0 || mode < 0 || mode > 3 || ((mode == 1 || mode == 3) && !lr_dev)) return FMRI_E_BADARG;
     ApplyOpt o;
     o.lr_dev = lr_dev; o.gdev = gdev; o.flag = flag; o.alpha = alpha; o.eps = eps; o.gscale = gscale; o.clamp = clamp;
-    o.mode = mode;
+    o.mode = mode; o.gated = gated ? 1 : 0;
     return apply_batch_launch((const ApplyEntry*)table_dev, n, total_tiles, o, S(stream));
 }
 
@@ -638,6 +638,13 @@ int fmri_get_deterministic(void) { return g_deterministic; }
 int fmri_wgrad(const void* P, const void* Q, float* out, const void* zero16, int N, int Yc, int Xc, int A, int Hq,
                int Wq, int Bc, int k, int stride, int pad, int flip, int apad, int ba_tile, int ldo, int splits,
                int atomic, void* stream) {
+    return fmri_wgrad_if(nullptr, P, Q, out, zero16, N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad, flip, apad, ba_tile, ldo,
+                         splits, atomic, stream);
+}
+
+int fmri_wgrad_if(const int* gate, const void* P, const void* Q, float* out, const void* zero16, int N, int Yc, int Xc,
+                  int A, int Hq, int Wq, int Bc, int k, int stride, int pad, int flip, int apad, int ba_tile, int ldo,
+                  int splits, int atomic, void* stream) {
     if (!P || !Q || !out || !zero16) return FMRI_E_BADARG;
     if (flip && stride != 1) return FMRI_E_UNSUPPORTED;
     if (N < 1 || A < 8 || (A & 7) || Bc < 8 || (Bc & 7) || splits < 1) return FMRI_E_BADARG;
@@ -656,6 +663,7 @@ int fmri_wgrad(const void* P, const void* Q, float* out, const void* zero16, int
     if (!no_ww && stride == 2 && !flip && (atomic == 1 || atomic == 2) && ba_tile == 128 && (Bc & 31) == 0 && Yc * Xc > 1 &&
         (int64_t)N * Hq * Wq * Bc < 0x7fffffffLL && M * A < 0x7fffffffLL) {
         WgradWinArgs w;
+        w.gate = gate;
         w.P = (const half_t*)P; w.Q = (const half_t*)Q; w.out = out; w.zero = (const half_t*)zero16;
         w.N = N; w.Yc = Yc; w.Xc = Xc; w.A = A; w.Hq = Hq; w.Wq = Wq; w.Bc = Bc; w.pad = pad; w.TW = k; w.ldo = ldo;
         w.slab_stride = atomic == 2 ? (int64_t)apad * ldo : 0;
@@ -695,6 +703,7 @@ int fmri_wgrad(const void* P, const void* Q, float* out, const void* zero16, int
     if (atomic == 3 && stride == 1 && k == 5 && pad == 2 && A == 32 && Bc == 8 && apad == 32 && Yc == Hq &&
         Xc == Wq && (int64_t)N * Yc * Xc * 32 < 0x7fffffffLL) {
         WgradNarrowArgs w;
+        w.gate = gate;
         w.P = (const half_t*)P; w.Q = (const half_t*)Q; w.out = out; w.zero = (const half_t*)zero16;
         w.N = N; w.H = Yc; w.W = Xc; w.ldo = ldo; w.flip = flip;
         w.tiles_y = (Yc + 7) / 8; w.tiles_x = (Xc + 7) / 8;
@@ -707,6 +716,7 @@ int fmri_wgrad(const void* P, const void* Q, float* out, const void* zero16, int
     }
     if (atomic == 2) return FMRI_E_UNSUPPORTED;      // plane-piece slabs exist only in the window-resident kernel
     WgradArgs a;
+    a.gate = gate;
     a.P = (const half_t*)P; a.Q = (const half_t*)Q; a.out = out; a.zero = (const half_t*)zero16;
     a.N = N; a.Yc = Yc; a.Xc = Xc; a.A = A; a.Hq = Hq; a.Wq = Wq; a.Bc = Bc;
     a.s = stride; a.T = T; a.TW = k;

@@ -233,6 +233,7 @@ struct WgradArgs {
     int32_t splits, steps_per_split, atomic;
     int32_t ncol_chunks;   // T*Bc/8
     int64_t slab_stride;   // atomic == 2: floats between the per-split output slabs
+    const int* gate;       // device flag or null: *gate == 0 -> the launch does nothing (fmri_wgrad_if)
     FastDiv fdX, fdYX, fdTW, fdBc8;
 };
 
@@ -284,6 +285,7 @@ struct WgradWinArgs {
     int64_t slab_stride;             // elements between the per-split output slabs
     int32_t nsy[2], nsx[2];          // shifts per parity (2 or 3)
     int32_t tmin[2];                 // first plane shift per parity (same for rows and columns)
+    const int* gate;                 // device flag or null: *gate == 0 -> the launch does nothing (fmri_wgrad_if)
     FastDiv fdTPI, fdTX;
 };
 
@@ -298,6 +300,7 @@ struct WgradNarrowArgs {
     int32_t tiles_y, tiles_x, ntiles;
     int32_t nslabs, pad0;          // out holds nslabs pre-zeroed partial matrices, slab_stride elements apart
     int64_t slab_stride;
+    const int* gate;               // device flag or null: *gate == 0 -> the launch does nothing (fmri_wgrad_if)
 };
 
 // Pin a wave-uniform kernel-argument value in an SGPR.  Fields of the by-value argument struct live in the kernarg

@@ -57,6 +57,8 @@ struct ApplyEntry {
 struct ApplyOpt {
     const float* lr_dev; const float* gdev; const int* flag;
     float alpha, eps, gscale, clamp;
+    int32_t gated;         // the weight gradients were launched under the same flag (fmri_wgrad_if): when it is 0 they
+                           // added nothing, so there is nothing to clear either
     int32_t mode;          // 0: gradients only (reference layout, first-writer stores), 1: RMSprop update + fp16 copy,
                            // 2: clear the flat segments' gradients, 3: as 1 with the gradient read from the reference
                            //    layout (`grad`, e.g. after an all-reduce) instead of gsrc

@@ -535,7 +535,7 @@ __global__ __launch_bounds__(256) void apply_batch_kernel(const ApplyEntry* __re
     const bool update = o.mode == 1 || o.mode == 3;
     const bool from_grad = o.mode == 3;     // the gradient is read from the reference layout (summed over the ranks there)
     const bool live = !update || !o.flag || *o.flag != 0;          // a gated-off optimizer step changes nothing
-    if (!live && (!en.clear || en.kind == 2 || from_grad)) return;
+    if (!live && (!en.clear || en.kind == 2 || from_grad || o.gated)) return;
     const float lr = (update && o.lr_dev) ? *o.lr_dev : 0.f;
     const float gs = update ? o.gscale / (o.gdev ? *o.gdev : 1.f) : 1.f;
     if (en.kind == 2) {

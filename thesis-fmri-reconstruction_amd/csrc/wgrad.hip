@@ -21,6 +21,7 @@ namespace fmri {
 
 template <int BA, int WA, int WB>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
+    if (a.gate && *a.gate == 0) return;       // the sub-network is not trained in this step (fmri_wgrad_if)
     constexpr int TILE = 64 * 256;   // 64 m-rows x 128 halfs
     constexpr int STAGE = 2 * TILE;
     constexpr int WAVE_A = BA / WA;

@@ -23,6 +23,7 @@ namespace fmri {
 // latency, and P is still read from HBM once (a wave DMAs only its 32-byte half of every P row; the 2.3 KB window is
 // fetched by both waves of a pair, the second time from L2).
 __global__ __launch_bounds__(256, 3) void wgrad_narrow_kernel(const WgradNarrowArgs a) {
+    if (a.gate && *a.gate == 0) return;       // the sub-network is not trained in this step (fmri_wgrad_if)
     constexpr int WW = 12, WPIX = WW * WW;          // Q window of an 8x8 tile (5x5 taps)
     constexpr int P_BYTES = 64 * 32;                // 64 pixels x 16 channels (this wave's half of the 32)
     constexpr int W_BYTES = 4 * 1024;               // 144 pixels x 16 B; bytes 2304.. hold ones (the 26th tap reads there)

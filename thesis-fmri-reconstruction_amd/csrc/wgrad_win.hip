@@ -285,6 +285,7 @@ __device__ __forceinline__ void wgrad_win_body(const WgradWinArgs& a, char* smem
 
 template <bool SLABS>
 __global__ __launch_bounds__(512, 1) void wgrad_win_kernel(const WgradWinArgs a) {
+    if (a.gate && *a.gate == 0) return;       // the sub-network is not trained in this step (fmri_wgrad_if)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // XCD-aware block -> work map.  Consecutive workgroup ids are dealt round-robin to the 8 XCDs (each with its own
     // L2); the blocks that read the same P tiles and Q windows at the same time -- all (column block, plane, row

@@ -28,7 +28,7 @@ _SIGS = {
     "fmri_apply_entry_fill": [_p, _p, _p, _p, _p, _p, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _l,
                               _i, _f, _l, _i],
     "fmri_transpose_f16": [_p, _p, _i, _i, _i, _i, _i, _p],
-    "fmri_apply_batch": [_p, _i, _i, _i, _p, _f, _f, _f, _p, _f, _p, _p],
+    "fmri_apply_batch": [_p, _i, _i, _i, _p, _f, _f, _f, _p, _f, _p, _i, _p],
     "fmri_ingest_u8": [_p, _i, _i, _i, _i, _p, _p, _f, _f, _f, _f, _f, _f, _p, _p, _p],
     "fmri_crop_resize_u8": [_p, _p, _p, _i, _i, _i, _p, _p, _i, _p, _p, _i, _i, _p, _p],
     "fmri_pcc": [_p, _p, _l, _p, _p, _p],
@@ -44,6 +44,7 @@ _SIGS = {
     "fmri_set_deterministic": [_i],
     "fmri_get_deterministic": [],
     "fmri_wgrad": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "fmri_wgrad_if": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "fmri_nchw_to_nhwc": [_p, _p, _i, _i, _i, _i, _p],
     "fmri_nhwc_to_nchw": [_p, _p, _i, _i, _i, _i, _f, _p],
     "fmri_rows_f32_to_f16": [_p, _p, _i, _i, _i, _f, _p],

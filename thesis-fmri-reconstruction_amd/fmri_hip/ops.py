@@ -364,7 +364,7 @@ def join_side(device=None):
     _SIDE["pending"].clear()
 
 
-def run_wgrad(P, Q, N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad, flip=0, flops=0.0, hold=None):
+def run_wgrad(P, Q, N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad, flip=0, flops=0.0, hold=None, gate=None):
     """Returns the packed fp32 gradient [apad][ldo].  ``hold``: see ``_grad_buffer``.  ``flops``: algorithmic FLOPs of the layer's weight gradient (for
     the profiling hook of lib.call; 0 = 2 * rows * A * Bc * k^2 of the padded operands)."""
     ba = tile_for(A)
@@ -387,7 +387,7 @@ def run_wgrad(P, Q, N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad, flip=0, flops=0.0,
         slabs = nslabs <= _WW_SLABS or _DET["on"]                       # few splits: per-split slabs, else atomics
         out = _grad_buffer(hold, (nslabs, apad, ldo) if slabs else (apad, ldo), not slabs, P.device)
         note("fmri::wgrad_win_kernel")
-        lib.call("fmri_wgrad", _P(P), _P(Q), _P(out), _P(zero_page(P.device)), N, Yc, Xc, A, Hq, Wq, Bc, k, stride,
+        lib.call("fmri_wgrad_if", _P(gate), _P(P), _P(Q), _P(out), _P(zero_page(P.device)), N, Yc, Xc, A, Hq, Wq, Bc, k, stride,
                  pad, flip, apad, ba, ldo, splits, 2 if slabs else 1)
         return out, ldo
     if (stride == 1 and k == 5 and pad == 2 and A == 32 and Bc == 8 and Yc == Hq and Xc == Wq and _WN_ON
@@ -400,7 +400,7 @@ def run_wgrad(P, Q, N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad, flip=0, flops=0.0,
             nslabs = lib.load().fmri_wgrad_narrow_blocks(N, Yc, Xc)
         out = _grad_buffer(hold, (nslabs, apad, ldo), True, P.device)
         note("fmri::wgrad_narrow_kernel")
-        lib.call("fmri_wgrad", _P(P), _P(Q), _P(out), _P(zero_page(P.device)), N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad,
+        lib.call("fmri_wgrad_if", _P(gate), _P(P), _P(Q), _P(out), _P(zero_page(P.device)), N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad,
                  flip, apad, ba, ldo, nslabs, 3)
         out._fmri_colsum = True            # column 200 of every slab row a holds sum_m P[m][a]
         return out, ldo
@@ -419,7 +419,7 @@ def run_wgrad(P, Q, N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad, flip=0, flops=0.0,
     else:
         out = _grad_buffer(hold, (apad, ldo), False, P.device)
     note("fmri::wgrad_kernel")
-    lib.call("fmri_wgrad", _P(P), _P(Q), _P(out), _P(zero_page(P.device)), N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad,
+    lib.call("fmri_wgrad_if", _P(gate), _P(P), _P(Q), _P(out), _P(zero_page(P.device)), N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad,
              flip, apad, ba, ldo, splits, mode)
     return out, ldo
 
@@ -469,10 +469,17 @@ def _hold_of(layer):
     return h
 
 
+def _gate_of(layer):
+    """The device flag the layer's weight-gradient launch is conditioned on (``begin_grads(..., gate=)``), or None."""
+    g = layer.group
+    return getattr(g, "grad_gate", None) if getattr(g, "defer_grads", False) else None
+
+
 _FUSED_APPLY = os.environ.get("FMRI_FUSED_APPLY") != "off"
+_GATE_SKIP = os.environ.get("FMRI_GATE_SKIP") != "off"
 
 
-def begin_grads(group, defer: bool):
+def begin_grads(group, defer: bool, gate: Optional[torch.Tensor] = None):
     """Start of a backward pass over ``group`` (replaces ``zero_grad``).  ``defer``: the caller will hand the whole
     group to ``apply_group`` right after the pass and nobody reads reference-layout gradients in between -- weight
     gradients then stay in their GEMM layout until that one launch, and only the 1-D parameters' gradient segments
@@ -480,10 +487,14 @@ def begin_grads(group, defer: bool):
     defer = bool(defer and _FUSED_APPLY)
     group.drop_pending()
     group.defer_grads = defer
+    # ``gate``: device int the group's update is conditioned on (the equilibrium gate's train_dis / train_dec): its
+    # weight-gradient GEMMs are launched with fmri_wgrad_if and do nothing in a step that does not train the group --
+    # the reference does not run that loss.backward() at all (train_vgan_stage1.py:420-431)
+    group.grad_gate = gate if (defer and _GATE_SKIP) else None
     plan = getattr(group, "_flat_clear", None) if defer else None
     if plan is not None and plan["flat"] is not None:
         lib.call("fmri_apply_batch", _P(plan["flat"]), plan["flat_n"], plan["flat_tiles"], 2, None, 0.0, 0.0, 1.0,
-                 None, 0.0, None)
+                 None, 0.0, None, 0)
         group._cleared = plan["sig"]
     else:
         group.grad.zero_()
@@ -601,7 +612,7 @@ def materialize_grads(group):
         flush_pending(group)
         return
     lib.note(bytes=8.0 * group.numel)
-    lib.call("fmri_apply_batch", _P(plan["table"]), plan["n"], plan["tiles"], 0, None, 0.0, 0.0, 1.0, None, 0.0, None)
+    lib.call("fmri_apply_batch", _P(plan["table"]), plan["n"], plan["tiles"], 0, None, 0.0, 0.0, 1.0, None, 0.0, None, 0)
     for p in group.pending:
         h = getattr(p[0], "_fmri_hold", None)
         if h is not None:
@@ -631,8 +642,10 @@ def apply_group(group, state, lr_dev, alpha, eps, flag, gdev, clamp=0.0) -> bool
         flush_pending(group, keep=done)
         return False
     lib.note(bytes=22.0 * group.numel)
+    gate = getattr(group, "grad_gate", None)
+    gated = 1 if (gate is not None and flag is not None and gate.data_ptr() == flag.data_ptr()) else 0
     lib.call("fmri_apply_batch", _P(plan["table"]), plan["n"], plan["tiles"], mode, _P(lr_dev), alpha, eps, 1.0,
-             _P(gdev), clamp, _P(flag))
+             _P(gdev), clamp, _P(flag), gated)
     for p in group.pending:
         h = getattr(p[0], "_fmri_hold", None)
         if h is not None:
@@ -793,7 +806,7 @@ class ConvLayer:
             # exchange the roles (dW[co][ci][k] = sum_m' X[m'][ci] * dY[m' + pad - k][co]) so that the gathered
             # operand is the narrow one: rows ci, columns (tap, co)
             packed, ldo = run_wgrad(x, dy, N, Hi, Wi, self.cinp, Ho, Wo, self.coutp, self.k, 1, self.pad, flip=1,
-                                    flops=self._flops(N, Hi, Wi, Ho, Wo), hold=_hold_of(self))
+                                    flops=self._flops(N, Hi, Wi, Ho, Wo), hold=_hold_of(self), gate=_gate_of(self))
             kk = self.k * self.k
             spec = PackSpec(sa=kk, sta=0, A=self.cin, TA=1, sb=self.cin * kk, stb=1, B=self.cout, KW=self.k,
                             TH=self.k, TW=self.k)
@@ -801,10 +814,10 @@ class ConvLayer:
             return
         if self.kind == "conv":
             packed, ldo = run_wgrad(dy, x, N, Ho, Wo, self.coutp, Hi, Wi, self.cinp, self.k, self.stride, self.pad,
-                                    flops=self._flops(N, Hi, Wi, Ho, Wo), hold=_hold_of(self))
+                                    flops=self._flops(N, Hi, Wi, Ho, Wo), hold=_hold_of(self), gate=_gate_of(self))
         else:
             packed, ldo = run_wgrad(x, dy, N, Hi, Wi, self.cinp, Ho, Wo, self.coutp, self.k, 2, self.pad,
-                                    flops=self._flops(N, Hi, Wi, Ho, Wo), hold=_hold_of(self))
+                                    flops=self._flops(N, Hi, Wi, Ho, Wo), hold=_hold_of(self), gate=_gate_of(self))
         emit_grad(self.group, packed, self.wg, self.gspec, ldo, 1.0 / scale)
         if bias_too:
             # bias.grad += (1/scale) * sum over pixels of dy: the narrow kernel's spare column, else a reduction
@@ -907,7 +920,7 @@ class DenseLayer:
     def _wgrad(self, x: torch.Tensor, dy: torch.Tensor, scale: float):
         M = x.shape[0]
         packed, ldo = run_wgrad(dy, x, M, 1, 1, self.np_, 1, 1, self.kp, 1, 1, 0, flops=2.0 * M * self.k_in * self.n_out,
-                                hold=_hold_of(self))
+                                hold=_hold_of(self), gate=_gate_of(self))
         emit_grad(self.group, packed, self.wg, self.gspec, ldo, 1.0 / scale)
 
     def bias_grad(self, dy: torch.Tensor, scale: float):

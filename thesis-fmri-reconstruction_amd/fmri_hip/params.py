@@ -239,6 +239,7 @@ class FlatGroup:
         self.pending = []
         self.materialized = []
         self.defer_grads = False
+        self.grad_gate = None
 
     def zero_grad(self):
         self.drop_pending()

@@ -408,13 +408,17 @@ class Stage1Step(_GanStepBase):
     """Stage-I VAE/GAN step (image -> image)."""
 
     def __init__(self, cfg: ArchConfig, device, hp: Optional[GanHyper] = None, scales: Optional[Scales] = None,
-                 distributed: bool = False, sync_bn: bool = True, mode: str = "vae-gan"):
+                 distributed: bool = False, sync_bn: bool = True, mode: str = "vae-gan", gate_skip: bool = True):
         """``mode``: the loss composition of train_vgan_stage1.py:359-388 -- 'vae-gan' (default), 'beta-vae' (KL weight
         hp.beta / batch), 'dcgan' (pixel nle, encoder not trained), 'vae' (pixel nle, discriminator not trained unless
-        the gate re-arms both)."""
+        the gate re-arms both).  ``gate_skip``: in ``step`` the weight-gradient GEMMs of the decoder / discriminator are
+        conditioned on the equilibrium gate's device flags (fmri_wgrad_if) -- a sub-network the gate does not train in a
+        step gets no gradients, as in the reference (`if train_dec: loss_decoder.backward()`,
+        train_vgan_stage1.py:420-431); False: they always run and only the update is conditional."""
         if mode not in MODES:
             raise ValueError(f"mode must be one of {sorted(MODES)}")
         self.cfg = cfg
+        self.gate_skip = bool(gate_skip)
         self.enc = EncoderNet(cfg, device)
         self.dec = DecoderNet(cfg, device, self.enc.size)
         self.dec.fc_bn.enable_lazy_running()
@@ -492,8 +496,10 @@ class Stage1Step(_GanStepBase):
         # ``early_apply`` also says that nobody reads reference-layout gradients between this pass and the updates: on one
         # GPU the weight gradients then stay in their GEMM layout until the sub-network's one fmri_apply_batch launch
         fuse = early_apply and self.dd.recorder is None
-        for n in (self.enc, self.dec, self.dis):
-            ops.begin_grads(n.group, fuse)
+        gs = self.gate_skip
+        ops.begin_grads(self.enc.group, fuse)
+        ops.begin_grads(self.dec.group, fuse, gate=self.flags[1:2] if gs else None)
+        ops.begin_grads(self.dis.group, fuse, gate=self.flags[0:1] if gs else None)
         dlogit16, dfeat16 = self._start_cotangents(fw["feat"], fw["logit32"], B)
         # weight gradients run on the side stream (ops.side_run) and are joined once, at the end of the backward pass, so
         # that a sub-network's last weight gradients overlap the next one's backward
@@ -723,9 +729,11 @@ class CognitiveStep(_GanStepBase):
     gate on, clamp +-1)."""
 
     def __init__(self, cfg: ArchConfig, n_voxels: int, device, stage: int, hp: Optional[GanHyper] = None,
-                 scales: Optional[Scales] = None, distributed: bool = False, sync_bn: bool = True):
+                 scales: Optional[Scales] = None, distributed: bool = False, sync_bn: bool = True,
+                 gate_skip: bool = True):
         assert stage in (2, 3)
         self.cfg, self.stage, self.n_voxels = cfg, stage, n_voxels
+        self.gate_skip = bool(gate_skip)
         self.cog = CognitiveEncoderNet(cfg, n_voxels, device)
         self.dec = DecoderNet(cfg, device, cfg.encoder_channels[2])
         self.dec.fc_bn.enable_lazy_running()
@@ -830,9 +838,10 @@ class CognitiveStep(_GanStepBase):
         dev = fw["disc_in"].device
         fuse = fuse and self.dd.recorder is None
         dlogit16, dfeat16 = self._start_cotangents(fw["feat"], fw["logit32"], B)
+        gs = self.gate_skip                  # (see Stage1Step: no gradients for a sub-network the gate does not train)
         if self.stage == 2:
             ops.begin_grads(self.cog.group, fuse)
-            ops.begin_grads(self.dis.group, fuse)
+            ops.begin_grads(self.dis.group, fuse, gate=self.flags[0:1] if gs else None)
             _, dimg_b = self.dis.backward(fw["sctx"], dlogit16, sc.a, dfeat16, sc.b, True, slice(B, 2 * B),
                                           img_streams=(False, True))
             self._reduce_async(self.dis.group)                  # under the decoder / cognitive-encoder backward
@@ -846,8 +855,8 @@ class CognitiveStep(_GanStepBase):
             self._reduce_async(self.cog.group)
             self.dd.wait_all()
         else:
-            ops.begin_grads(self.dec.group, fuse)
-            ops.begin_grads(self.dis.group, fuse)
+            ops.begin_grads(self.dec.group, fuse, gate=self.flags[1:2] if gs else None)
+            ops.begin_grads(self.dis.group, fuse, gate=self.flags[0:1] if gs else None)
             dimg_a, dimg_b = self.dis.backward(fw["sctx"], dlogit16, sc.a, dfeat16, sc.b, True, slice(B, 3 * B))
             self._reduce_async(self.dis.group)                  # under the decoder backward
             cot = axpby(dimg_b, dimg_a, sc.dec / sc.b, -sc.dec / sc.a, a_dev=self._slot(S_C1), b_dev=self._slot(S_C2))

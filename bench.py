@@ -448,6 +448,9 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    # under a profiler (rocprofv3 preloads its tool library) the run must not start profiler children of its own
+    if "rocprofiler" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ):
+        a.no_pmc = True
     if a.serial:
         os.environ["FMRI_SIDE_STREAM"] = "off"
     from fmri_hip import lib, ops

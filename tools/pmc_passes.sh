@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/$1; shift
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-B=("$R/bench.py" --steps 3 --warmup 2 --eager --serial --no-cpu-baseline --no-hbm-rows --no-gate-pass "$@")
+B=("$R/bench.py" --steps 3 --warmup 2 --eager --serial --no-cpu-baseline --no-hbm-rows --no-gate-pass --no-pmc "$@")
 
 # one counter pass: <name> <counters...>; prints the path of its counter CSV, or fails with the run's stderr
 pass() {

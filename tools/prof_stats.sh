@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/$1; shift
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o x -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --eager --serial "$@" > $OUT/bench.json 2> $OUT/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o x -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-pmc --no-gate-pass --eager --serial "$@" > $OUT/bench.json 2> $OUT/bench.err
 f=$(find $OUT/trace -name "*kernel_stats.csv" | head -1)
 cp $f $OUT/kernel_stats.csv
 t=$(find $OUT/trace -name "*kernel_trace.csv" | head -1)

@@ -85,6 +85,43 @@ def _scanner():
     return scan
 
 
+def test_apply_table_rows_without_gpu(lib):
+    """fmri_apply_entry_fill (host code): which layout maps the one-launch update takes, how many blocks a row occupies,
+    and what it refuses -- for the parameter shapes of the model (models/vae_gan.py)."""
+    n = lib.fmri_apply_entry_bytes()
+    assert 64 <= n <= 256
+    buf = ctypes.create_string_buffer(n)
+    P = lambda v: ctypes.c_void_p(v)
+    w, sq, g, src, pk = 0x10000, 0x20000, 0x30000, 0x40000, 0x50000
+
+    def fill(sa, sta, sb, stb, A, TA, B, KW, TH, TW, ld, kpad, flat=0, py=0, px=0, step=1, nsl=1, gsrc=src, pkp=pk):
+        return lib.fmri_apply_entry_fill(buf, P(gsrc), P(w), P(sq), P(g), P(pkp), sa, sta, sb, stb, A, TA, B, KW, py, px,
+                                         step, TH, TW, ld, kpad, nsl, A * TA * ld, 0, 1.0, flat, 0)
+    # Conv2d(128 -> 256, k5): rows co, taps contiguous in the reference layout: one block per (row, 64 input channels)
+    assert fill(128 * 25, 0, 25, 1, 256, 1, 128, 5, 5, 5, 25 * 128, 25 * 128) == 256 * 2
+    # Conv2d(3 -> 32): fewer than 64 channels -> 32-wide tiles
+    assert fill(3 * 25, 0, 25, 1, 32, 1, 3, 5, 5, 5, 256, 256) == 32
+    # Linear(16384 -> 1024) behind the (C,H,W) flatten: 64 'taps' (positions) of 256 channels
+    assert fill(16384, 0, 64, 1, 1024, 1, 256, 64, 1, 64, 16384, 16384) == 1024 * 4
+    # plain Linear(1024 -> 256): row-contiguous, 1024-element chunks
+    assert fill(1024, 0, 1, 0, 256, 1, 1024, 1, 1, 1, 1024, 1024) == 256
+    # a flat segment of 1-D parameters
+    assert fill(0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 0, 0, flat=5000, gsrc=0, pkp=0) == 5
+    # a tap SUBSET (one parity class of a transposed convolution) is not a gradient layout: refused (0 = keep the
+    # separate launches), as is a transposed dense map
+    assert fill(25, 0, 128 * 25, 1, 128, 1, 256, 5, 2, 2, 4 * 256, 4 * 256, py=1, px=1, step=2) == 0
+    assert fill(1, 0, 1024, 0, 1024, 1, 256, 1, 1, 1, 256, 256) == 0
+    # bad arguments: leading dimension too small for the taps, missing gradient source, fp16 copy narrower than the taps
+    assert fill(128 * 25, 0, 25, 1, 256, 1, 128, 5, 5, 5, 100, 25 * 128) < 0
+    assert fill(128 * 25, 0, 25, 1, 256, 1, 128, 5, 5, 5, 25 * 128, 25 * 128, gsrc=0) < 0
+    assert fill(128 * 25, 0, 25, 1, 256, 1, 128, 5, 5, 5, 25 * 128, 64) < 0
+    # launches are refused without a table / with an unknown mode (no GPU touched)
+    assert lib.fmri_apply_batch(None, 1, 1, 1, None, 0.9, 1e-8, 1.0, None, 0.0, None, 0, None) < 0
+    assert lib.fmri_apply_batch(P(0x1000), 1, 1, 7, None, 0.9, 1e-8, 1.0, None, 0.0, None, 0, None) < 0
+    assert lib.fmri_apply_batch(P(0x1000), 1, 1, 1, None, 0.9, 1e-8, 1.0, None, 0.0, None, 0, None) < 0      # mode 1 needs lr
+    assert lib.fmri_transpose_f16(P(0x1000), P(0x2000), 8, 8, 8, 12, 8, None) < 0                             # ld not a multiple of 8
+
+
 def test_no_store_data_hazard_in_the_code_objects(lib):
     """gfx950: a VMEM store of more than 64 bits followed within two issue slots by a VALU write of one of its data
     registers can store the NEW value (measured twice: DESIGN section 6; csrc/common.h FMRI_STORE_FENCE).  The compiler pads

@@ -567,6 +567,11 @@ def _plan_apply(group, state, update=True, pend=None):
     up = lambda rr: torch.frombuffer(bytearray(b"".join(rr)), dtype=torch.uint8).to(group.device) if rr else None
     plan = dict(key=key, table=up(rows), n=len(rows), tiles=tiles, flat=up(flat_rows), flat_n=len(flat_rows),
                 flat_tiles=ftiles, sig=tuple(segs), covered=covered, fused=fused)
+    if len(plans) >= 8:              # (buffers that keep changing, e.g. a varying batch size: do not collect tables)
+        keep = getattr(group, "_flat_clear", None)
+        plans.clear()
+        if keep is not None:
+            plans[keep["key"]] = keep
     plans[key] = plan
     if getattr(group, "_flat_clear", None) is None:
         # what begin_grads clears from now on: the first table's flat segments -- every 1-D parameter is in them (and,

@@ -426,3 +426,20 @@ def test_gated_weight_gradients_change_nothing_but_the_work(deterministic):
     for n in ("opt_enc", "opt_dec", "opt_dis"):
         assert torch.equal(getattr(a, n).s1, getattr(b, n).s1), f"{n}: RMSprop state differs"
     assert len(seen) >= 2 and any(not (d and c) for d, c in seen), f"the gate never switched a sub-network off: {seen}"
+
+
+def test_gradients_of_a_fused_step_are_not_silently_stale():
+    """``named_grads()`` after ``step()`` raises (the weight gradients went from the GEMM layout into the update and were
+    never stored in the reference layout); after ``backward()`` it returns them."""
+    a, _, args, _ = _stage1_pair(8)
+    a.step(*args)
+    _finish()
+    with pytest.raises(RuntimeError, match="consumed by its fused update"):
+        a.named_grads()
+    a.forward(*args)
+    a.gate(8)
+    a.backward()
+    _finish()
+    g = a.named_grads()
+    assert all(torch.isfinite(v).all() for v in g.values()) and float(g["decoder.conv.0.conv.weight"].abs().max()) > 0
+    a.apply()

@@ -487,6 +487,7 @@ def begin_grads(group, defer: bool, gate: Optional[torch.Tensor] = None):
     defer = bool(defer and _FUSED_APPLY)
     group.drop_pending()
     group.defer_grads = defer
+    group.grads_consumed = False
     # ``gate``: device int the group's update is conditioned on (the equilibrium gate's train_dis / train_dec): its
     # weight-gradient GEMMs are launched with fmri_wgrad_if and do nothing in a step that does not train the group --
     # the reference does not run that loss.backward() at all (train_vgan_stage1.py:420-431)
@@ -657,6 +658,7 @@ def apply_group(group, state, lr_dev, alpha, eps, flag, gdev, clamp=0.0) -> bool
             h["busy"] = False
     group.pending = []
     group.defer_grads = False
+    group.grads_consumed = mode == 1      # the reference-layout gradient buffer was never written in this pass
     group.version += 1
     for pw in plan["fused"]:
         pw.version = group.version

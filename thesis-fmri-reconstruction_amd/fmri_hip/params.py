@@ -245,6 +245,14 @@ class FlatGroup:
         self.drop_pending()
         self.grad.zero_()
         self._cleared = "all"
+        self.grads_consumed = False
+
+    def check_grads_readable(self):
+        """Raises when the last backward pass over this group ended in the one-launch update (ops.apply_group): its weight
+        gradients went from the GEMM layout straight into the optimizer and ``grads`` still holds an older pass."""
+        if getattr(self, "grads_consumed", False) or getattr(self, "defer_grads", False):
+            raise RuntimeError("the gradients of the last step() were consumed by its fused update and never stored in the "
+                               "reference layout: run forward() / gate() / backward() (and apply()) to inspect them")
 
 
 # ------------------------------------------------------------------------------------------------

@@ -711,11 +711,13 @@ class Stage1Step(_GanStepBase):
             mus=fw["head32"][:, :Z].clone(), log_variances=fw["head32"][:, Z:].clone())
 
     def named_grads(self):
-        """True-scale gradients (the device normalisation factors divided out) -- syncs; tests/API only."""
+        """True-scale gradients (the device normalisation factors divided out) -- syncs; tests/API only.  After
+        ``backward()``; ``step()`` does not leave any (FlatGroup.check_grads_readable)."""
         s = self.scal.tolist()
         out = {}
         for pre, n, f in (("encoder.", self.enc, s[S_NE]), ("decoder.", self.dec, s[S_GDEC]),
                           ("discriminator.", self.dis, s[S_NA])):
+            n.group.check_grads_readable()
             for k, v in n.group.grads.items():
                 out[pre + k] = v / f
         return out
@@ -897,6 +899,7 @@ class CognitiveStep(_GanStepBase):
                   (("decoder.", self.dec, s[S_NA]), ("discriminator.", self.dis, s[S_NA])))
         out = {}
         for pre, n, f in groups:
+            n.group.check_grads_readable()
             for k, v in n.group.grads.items():
                 out[pre + k] = v / f
         return out

@@ -192,10 +192,11 @@ def _group_of(entry, note):
         return "weight-gradient GEMMs" if "wgrad" in note["kernel"] else "conv / deconv / dense forward + data-gradient GEMMs"
     if entry.startswith("fmri_bn_") or entry == "fmri_act_bwd":
         return "BatchNorm + activation passes"
-    if entry in ("fmri_pack_weight", "fmri_pack_weight_batch", "fmri_unpack_grad", "fmri_reduce_slabs"):
-        return "weight re-pack / gradient unpack / slab sums"
-    if entry in ("fmri_rmsprop_dev", "fmri_adam_dev", "fmri_rmsprop", "fmri_adam", "fmri_counter_inc"):
-        return "optimizer"
+    if entry in ("fmri_apply_batch", "fmri_transpose_f16", "fmri_pack_weight", "fmri_pack_weight_batch",
+                 "fmri_unpack_grad", "fmri_rmsprop_dev", "fmri_adam_dev", "fmri_rmsprop", "fmri_adam", "fmri_counter_inc"):
+        return "update: gradient map + optimizer + fp16 weight copies"
+    if entry == "fmri_reduce_slabs":
+        return "split-K slab sums of the dense layers"
     return "losses, latent, gate, layout casts"
 
 

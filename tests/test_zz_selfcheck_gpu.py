@@ -47,16 +47,16 @@ def _same_update(sa, sb, what=""):
         assert bad <= max(4, a.numel() // 100), (what, k, bad, a.numel(), float((a - b).abs().max()))
 
 
-def _stage1_pair(B, seed=0):
+def _stage1_pair(B, seed=0, hp=None):
     """Two Stage-I engines with the same parameters and optimizer state + one seeded batch."""
     from oracle import vaegan_oracle as O
     from fmri_hip.params import ArchConfig
     from fmri_hip.steps import Stage1Step
     data = O.synth_batch(B, O.ArchCfg.px64(), seed=1234, steps=1)
     x, e, zp = data["x"].to(DEV), data["noise"][0, 0].to(DEV), data["noise"][0, 1].to(DEV)
-    a = Stage1Step(ArchConfig.px64(), DEV)
+    a = Stage1Step(ArchConfig.px64(), DEV, hp=hp)
     a.load_recipe(seed, True)
-    b = Stage1Step(ArchConfig.px64(), DEV)
+    b = Stage1Step(ArchConfig.px64(), DEV, hp=hp)
     b.load_state_dict(a.state_dict())
     return a, b, (x, e, zp), data
 
@@ -132,7 +132,11 @@ def test_one_launch_update_equals_separate_launches(deterministic, B):
     BASELINE configs[1]'s B = 256 (other weight-gradient kernels, other slab counts)."""
     from fmri_hip import ops
     from fmri_hip.nets import refresh_net
-    a, b, args, _ = _stage1_pair(B)
+    from fmri_hip.steps import GanHyper
+    # a margin nothing reaches: the gate trains all three sub-networks in EVERY step, so every gradient buffer of the
+    # one-launch path is consumed and refilled three times (with the default margin the B = 256 discriminator is switched
+    # off after the first step, and a buffer that kept part of an earlier step's sums would go unnoticed)
+    a, b, args, _ = _stage1_pair(B, hp=GanHyper(margin=10.0))
     fused = 0
     real = ops.apply_group
     def counting(*aa, **kw):
@@ -148,7 +152,9 @@ def test_one_launch_update_equals_separate_launches(deterministic, B):
             b.gate(B)
             b.backward()
             b.apply()
-        _finish()
+            _finish()
+            la = a.logs()
+            assert la["train_dis"] and la["train_dec"], "the gate switched a sub-network off: the test lost its point"
     finally:
         ops.apply_group = real
     assert fused == 9, f"the one-launch path ran {fused} times in 3 steps x 3 sub-networks"
@@ -443,3 +449,39 @@ def test_gradients_of_a_fused_step_are_not_silently_stale():
     g = a.named_grads()
     assert all(torch.isfinite(v).all() for v in g.values()) and float(g["decoder.conv.0.conv.weight"].abs().max()) > 0
     a.apply()
+
+
+def test_one_launch_update_in_the_default_reduction_mode():
+    """The same comparison with the DEFAULT reductions at BASELINE configs[1]'s batch: the weight-gradient kernels ADD into
+    persistent buffers (fp32 atomics), which fmri_apply_batch has to hand back zeroed every step.  Three steps of
+    After every ``step()`` each such buffer is zero again in ALL its columns (the narrow kernel keeps a bias gradient in a
+    spare column behind the taps); the first step agrees with forward / gate / backward / apply to the run-to-run spread
+    of the atomics."""
+    B = 256
+    a, b, args, _ = _stage1_pair(B)
+    for it in range(3):
+        a.step(*args)
+        b.forward(*args)
+        b.gate(B)
+        b.backward()
+        b.apply()
+        _finish()
+        if it == 0:
+            _same_update(a.state_dict(), b.state_dict(), "default mode, one launch vs separate, step 0")
+            b.load_state_dict(a.state_dict())          # re-synchronise: later steps compare one update each
+            _sync_optimizers(a, b)
+    # the direct statement: every buffer a weight-gradient kernel adds into is back to zero after the step
+    held = 0
+    for net in (a.enc, a.dec, a.dis):
+        for layer in vars(net).values():
+            for lay in (layer if isinstance(layer, (list, tuple)) else [layer]):
+                for obj in [lay] + [v for v in vars(lay).values()] if hasattr(lay, "__dict__") else []:
+                    hold = getattr(obj, "_ghold", None)
+                    if not isinstance(hold, dict):
+                        continue
+                    for key, buf in hold.items():
+                        if key != "busy" and getattr(buf, "_fmri_clear", False):
+                            held += 1
+                            assert float(buf.abs().max()) == 0.0, f"{type(obj).__name__}: accumulation buffer not cleared"
+    assert held >= 3, f"only {held} accumulation buffers found: the walk over the layers missed them"
+

@@ -594,6 +594,11 @@ __global__ __launch_bounds__(256) void apply_batch_kernel(const ApplyEntry* __re
                 if (en.clear) slab_clear(q, en.nslabs, en.slab_stride);
             }
         }
+        // columns behind the taps belong to the weight-gradient kernel too (the narrow kernel keeps sum_pixels P, a bias
+        // gradient, in the first of them): the row's first block hands them back zeroed as well
+        if (en.clear && b0 == 0)
+            for (int c = run * en.Bp + threadIdx.x; c < en.ld; c += 256)
+                slab_clear(gsrc + (int64_t)row * en.ld + c, en.nslabs, en.slab_stride);
         if (!live) return;
         __syncthreads();
     }

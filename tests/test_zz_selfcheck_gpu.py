@@ -388,16 +388,29 @@ def test_cognitive_step_one_launch_update_equals_separate_launches(deterministic
     data = O.synth_batch(B, cfg_o, n_voxels=V, seed=4321, steps=1)
     x, fm = data["x"].to(DEV), data["fmri"].to(DEV)
     nz = [t.to(DEV) for t in data["noise"][0]]
+    from fmri_hip import ops
     a, b = CognitiveStep(cfg, V, DEV, stage), CognitiveStep(cfg, V, DEV, stage)
     a.load_recipe(3, True)
     b.load_state_dict(a.state_dict())
-    for _ in range(3):
-        a.step(fm, x, nz[0], nz[1], nz[2])
-        b.forward(fm, x, nz[0], nz[1], nz[2])
-        b.gate(B)
-        b.backward()
-        b.apply()
-    _finish()
+    fused, real = 0, ops.apply_group
+
+    def counting(*aa, **kw):
+        nonlocal fused
+        r = real(*aa, **kw)
+        fused += 1 if r else 0
+        return r
+    ops.apply_group = counting
+    try:
+        for _ in range(3):
+            a.step(fm, x, nz[0], nz[1], nz[2])
+            b.forward(fm, x, nz[0], nz[1], nz[2])
+            b.gate(B)
+            b.backward()
+            b.apply()
+        _finish()
+    finally:
+        ops.apply_group = real
+    assert fused == 6, f"the one-launch path ran {fused} times in 3 steps x 2 trained sub-networks"
     _assert_same_logs(a.logs(), b.logs(), f"stage {stage}")
     _assert_same_bits(a.state_dict(), b.state_dict(), f"stage {stage}: one launch vs separate")
 

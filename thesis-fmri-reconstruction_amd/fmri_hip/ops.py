@@ -442,6 +442,9 @@ def _grad_buffer(hold, shape, zeroed: bool, device):
     key = (tuple(shape), zeroed)
     out = hold.get(key)
     if out is None:
+        if len(hold) > 6:                # (a batch size that keeps changing: do not collect a buffer per shape)
+            for k in [k for k in hold if k != "busy"]:
+                del hold[k]
         out = hold[key] = torch.zeros(shape, dtype=torch.float32, device=device)
         out._fmri_clear = zeroed
         out._fmri_hold = hold

@@ -405,6 +405,15 @@ int fmri_adam_dev(float* p, const float* g, float* m, float* v, int64_t n, const
  * layer's fp16 weight made from its forward orientation instead of a second pass over the fp32 master
  * (models/vae_gan.py:81,108,158,200: nn.Linear keeps ONE weight; the second GEMM layout is the engine's). */
 int fmri_transpose_f16(const void* src, void* dst, int R, int C, int src_rows, int ld_src, int ld_dst, void* stream);
+/* Batched form, one launch per sub-network from a device-resident table (fmri_transpose_entry_fill fills one host-side
+ * row and returns the blocks it occupies, < 0 on bad arguments).  A row is one 2-D transpose: a dense weight's second
+ * orientation, or ONE TAP of one output-parity class of a stride-2 transposed convolution's weight
+ * (nn.Conv2d / nn.ConvTranspose2d keep one weight, models/vae_gan.py:18-20,46-53: the class blocks are the engine's):
+ * `src` / `dst` point at the slices (16-byte aligned), `width` = source columns readable from `src` on to its row's end. */
+int fmri_transpose_entry_bytes(void);
+int fmri_transpose_entry_fill(void* host_entry, const void* src, void* dst, int R, int C, int src_rows, int width,
+                              int ld_src, int ld_dst, int tile_begin);
+int fmri_transpose_f16_batch(const void* table_dev, int n, int total_tiles, void* stream);
 int fmri_apply_entry_bytes(void);
 int fmri_apply_entry_fill(void* host_entry, const float* gsrc, float* w, float* sq, float* grad, void* pk, int64_t sa,
                           int64_t sta, int64_t sb, int64_t stb, int A, int TA, int B, int KW, int py, int px, int step,

@@ -547,6 +547,29 @@ def test_transpose_f16(R, C):
     assert bool((dst[:C, R:r8] == 0).all()) and bool((dst[:C, r8:] == 7.0).all()) and bool((dst[C:] == 7.0).all())
 
 
+@pytest.mark.parametrize("kind,cin,cout", [("conv", 3, 64), ("conv", 64, 128), ("conv", 128, 256), ("conv", 32, 128),
+                                           ("deconv", 256, 256), ("deconv", 256, 128), ("deconv", 128, 32)])
+def test_conv_class_blocks_are_tap_transposes(kind, cin, cout):
+    """The four parity-class blocks of a stride-2 layer's fp16 weight made by fmri_transpose_f16_batch from the
+    single-block copy (one transpose per tap) == the blocks fmri_pack_weight makes from the fp32 master, bit for bit,
+    padding included."""
+    from fmri_hip import lib
+    from fmri_hip.ops import ConvLayer
+    torch.manual_seed(cin + cout)
+    shape = (cout, cin, 5, 5) if kind == "conv" else (cin, cout, 5, 5)
+    g = _G({"w": torch.randn(*shape) * 0.05})
+    layer = ConvLayer(g, "w", None, kind, cin, cout, 5, 2, 2, 1 if kind == "deconv" else 0)
+    cls = layer.pw_d if kind == "conv" else layer.pw_f
+    assert getattr(cls, "taps_of", None) is not None and len(cls.specs) == 4
+    got = cls.get().clone()
+    ref = torch.zeros_like(got)
+    for item in cls._items():
+        lib.call("fmri_pack_weight", item[0], ref.data_ptr() + (item[1] - cls.buf.data_ptr()), *item[2:])
+    torch.cuda.synchronize()
+    assert float(ref.abs().max()) > 0
+    assert torch.equal(got, ref)
+
+
 @pytest.mark.parametrize("M,K,N,in_perm,out_perm", DENSE_CASES)
 def test_dense_second_orientation_is_the_transpose(M, K, N, in_perm, out_perm):
     """The data-gradient copy of a dense weight made by fmri_transpose_f16 from the forward copy == the one

@@ -165,6 +165,26 @@ int fmri_transpose_f16(const void* src, void* dst, int R, int C, int src_rows, i
     return transpose_f16_launch((const half_t*)src, (half_t*)dst, R, C, src_rows, ld_src, ld_dst, S(stream));
 }
 
+int fmri_transpose_entry_bytes(void) { return (int)sizeof(TransposeEntry); }
+
+int fmri_transpose_entry_fill(void* host_entry, const void* src, void* dst, int R, int C, int src_rows, int width,
+                              int ld_src, int ld_dst, int tile_begin) {
+    if (!host_entry || !src || !dst || R < 1 || C < 1 || src_rows < R || width < C || ld_src < width || (ld_src & 7) ||
+        (ld_dst & 7) || ld_dst < ((R + 7) & ~7) || tile_begin < 0 || (((uintptr_t)src | (uintptr_t)dst) & 15))
+        return FMRI_E_BADARG;
+    TransposeEntry e;
+    memset(&e, 0, sizeof(e));
+    e.src = (const half_t*)src; e.dst = (half_t*)dst; e.R = R; e.C = C; e.Rbuf = src_rows; e.width = width;
+    e.lds = ld_src; e.ldd = ld_dst; e.tile_begin = tile_begin;
+    memcpy(host_entry, &e, sizeof(e));
+    return ((R + 63) / 64) * ((C + 63) / 64);
+}
+
+int fmri_transpose_f16_batch(const void* table_dev, int n, int total_tiles, void* stream) {
+    if (!table_dev || n < 0 || total_tiles < 0) return FMRI_E_BADARG;
+    return transpose_batch_launch((const TransposeEntry*)table_dev, n, total_tiles, S(stream));
+}
+
 int fmri_apply_entry_bytes(void) { return (int)sizeof(ApplyEntry); }
 
 int fmri_apply_entry_fill(void* host_entry, const float* gsrc, float* w, float* sq, float* grad, void* pk, int64_t sa,

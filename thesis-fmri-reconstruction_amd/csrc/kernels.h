@@ -85,6 +85,15 @@ int pack_weight_launch(const PackArgs& p, hipStream_t st);
 int unpack_grad_launch(const UnpackArgs& p, hipStream_t st);
 int pack_tile_count(const PackArgs& p, int* run_out);
 int pack_batch_launch(const PackEntry* tab, int n, int total_tiles, hipStream_t st);
+struct TransposeEntry {    // one row of the device-resident table of fmri_transpose_f16_batch
+    const half_t* src;     // first element of the [R][C] source slice (row stride lds)
+    half_t* dst;           // first element of the [C][R] destination slice (row stride ldd)
+    int32_t R, C, Rbuf;    // Rbuf >= R rows exist behind src (the rows from R on are zero)
+    int32_t width;         // source columns readable from src on (>= C; whole 16-byte items are read)
+    int32_t lds, ldd;
+    int32_t tile_begin, pad_;
+};
+int transpose_batch_launch(const TransposeEntry* tab, int n, int total_tiles, hipStream_t st);
 int transpose_f16_launch(const half_t* src, half_t* dst, int R, int C, int Rbuf, int lds_, int ldd, hipStream_t st);
 int nchw_to_nhwc_launch(const float* s, half_t* d, int N, int C, int HW, int Cp, hipStream_t st);
 int nhwc_to_nchw_launch(const half_t* s, float* d, int N, int C, int HW, int Cp, float scale, hipStream_t st);

@@ -474,6 +474,53 @@ __global__ __launch_bounds__(256) void transpose_f16_kernel(const half_t* __rest
         }
     }
 }
+// Batched form: every second-orientation fp16 copy of a sub-network in one launch, from a device-resident table.  A row
+// of the table is one 2-D transpose: a dense weight, or ONE TAP of one parity class of a stride-2 transposed convolution
+// (class block [ci][t' * Cop + co] = forward copy [co][t * Cip + ci]: the [co][ci] slice at column t * Cip of the source,
+// written at column t' * Cop of the class block).  `width` = source columns that may be read from src on (its row's end).
+__global__ __launch_bounds__(256) void transpose_f16_batch_kernel(const TransposeEntry* __restrict__ tab, int n) {
+    __shared__ half_t t[64][72];
+    __shared__ int sel;
+    if (threadIdx.x < 64) {
+        int cnt = 0;
+        for (int e = threadIdx.x; e < n; e += 64) cnt += (int)blockIdx.x >= tab[e].tile_begin ? 1 : 0;
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) cnt += __shfl_xor(cnt, s, 64);
+        if (threadIdx.x == 0) sel = cnt - 1;
+    }
+    __syncthreads();
+    const TransposeEntry& en = tab[sel];
+    const int tile = blockIdx.x - en.tile_begin;
+    const int ntc = (en.C + 63) / 64;
+    const int r0 = (tile / ntc) * 64, c0 = (tile - (tile / ntc) * ntc) * 64;
+    const int R = en.R, C = en.C;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int e = threadIdx.x + 256 * k;
+        const int r = e >> 3, ch = e & 7;
+        h8 v = {};
+        if (r0 + r < en.Rbuf && c0 + ch * 8 + 8 <= en.width) v = *(const h8*)(en.src + (int64_t)(r0 + r) * en.lds + c0 + ch * 8);
+        *(h8*)&t[r][ch * 8] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int e = threadIdx.x + 256 * k;
+        const int c = e & 63, rh = e >> 6;
+        if (c0 + c < C && r0 + rh * 8 < R) {
+            h8 v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (r0 + rh * 8 + j < R) ? t[rh * 8 + j][c] : (half_t)0.f;
+            *(h8*)(en.dst + (int64_t)(c0 + c) * en.ldd + r0 + rh * 8) = v;
+        }
+    }
+}
+int transpose_batch_launch(const TransposeEntry* tab, int n, int total_tiles, hipStream_t st) {
+    if (n < 1 || total_tiles < 1) return OK;
+    hipLaunchKernelGGL(transpose_f16_batch_kernel, dim3((unsigned)total_tiles), dim3(256), 0, st, tab, n);
+    return hipGetLastError() == hipSuccess ? OK : E_LAUNCH;
+}
+
 int transpose_f16_launch(const half_t* src, half_t* dst, int R, int C, int Rbuf, int lds_, int ldd, hipStream_t st) {
     hipLaunchKernelGGL(transpose_f16_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, st, src, dst, R, C, Rbuf,
                        lds_, ldd);

@@ -23,6 +23,9 @@ _SIGS = {
     "fmri_pack_weight": [_p, _p, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "fmri_pack_entry_bytes": [],
     "fmri_apply_entry_bytes": [],
+    "fmri_transpose_entry_bytes": [],
+    "fmri_transpose_entry_fill": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i],
+    "fmri_transpose_f16_batch": [_p, _i, _i, _p],
     "fmri_pack_entry_fill": [_p, _p, _p, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i],
     "fmri_pack_weight_batch": [_p, _i, _i, _p],
     "fmri_apply_entry_fill": [_p, _p, _p, _p, _p, _p, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _l,

@@ -127,15 +127,29 @@ def _repack_group(group, skip=()):
         nbytes = L.fmri_pack_entry_bytes()
         rows, singles, tiles = [], [], 0
         skipped = set(id(pw) for pw in skip)
-        transposes = []
+        transposes = []                  # (src ptr, dst ptr, R, C, source rows, readable width, ld_src, ld_dst)
         for pw in packed:
             if id(pw) in skipped:
                 continue
             src = getattr(pw, "transpose_of", None)
             if src is not None and _TRANSPOSE_ON:
-                # a dense layer's second orientation: the transpose of its first fp16 copy (fmri_transpose_f16)
+                # a dense layer's second orientation: the transpose of its first fp16 copy
                 R, Cc = src.specs[0].rows, pw.specs[0].rows
-                transposes.append((_P(src.buf), _P(pw.buf), R, Cc, src.rows_pad, src.kpads[0], pw.kpads[0]))
+                transposes.append((_P(src.buf), _P(pw.buf), R, Cc, src.rows_pad, src.kpads[0], src.kpads[0], pw.kpads[0]))
+                continue
+            src = getattr(pw, "taps_of", None)
+            if src is not None and _TRANSPOSE_ON:
+                # the four parity classes of a stride-2 transposed convolution: tap t' of a class block is the transpose
+                # of tap t = (py + 2 ty) * k + (px + 2 tx) of the single-block copy [rows][t * Bp + b]
+                ssp = src.specs[0]
+                sbp, sbase = pad8(ssp.B), _P(src.buf) + 2 * src.offsets[0]
+                for sp, kp, off in zip(pw.specs, pw.kpads, pw.offsets):
+                    assert sp.B == ssp.rows and sp.rows == ssp.B, "class block and single block disagree"
+                    for ty in range(sp.TH):
+                        for tx in range(sp.TW):
+                            t = (sp.py + sp.step * ty) * sp.KW + (sp.px + sp.step * tx)
+                            transposes.append((sbase + 2 * t * sbp, _P(pw.buf) + 2 * (off + (ty * sp.TW + tx) * pad8(sp.B)),
+                                               ssp.rows, sp.rows, src.rows_pad, src.kpads[0] - t * sbp, src.kpads[0], kp))
                 continue
             for item in pw._items():
                 host = ctypes.create_string_buffer(nbytes)
@@ -150,13 +164,25 @@ def _repack_group(group, skip=()):
         dev_tab = None
         if rows:
             dev_tab = torch.frombuffer(bytearray(b"".join(rows)), dtype=torch.uint8).to(group.device)
-        tab = tabs[key] = dict(table=dev_tab, n=len(rows), tiles=tiles, singles=singles, transposes=transposes)
+        t_tab, t_tiles = None, 0
+        if transposes:
+            tb, trows = L.fmri_transpose_entry_bytes(), []
+            for item in transposes:
+                host = ctypes.create_string_buffer(tb)
+                n = L.fmri_transpose_entry_fill(host, *item, t_tiles)
+                if n <= 0:
+                    lib.check(n if n < 0 else -1, "fmri_transpose_entry_fill")
+                trows.append(host.raw)
+                t_tiles += n
+            t_tab = torch.frombuffer(bytearray(b"".join(trows)), dtype=torch.uint8).to(group.device)
+        tab = tabs[key] = dict(table=dev_tab, n=len(rows), tiles=tiles, singles=singles, t_table=t_tab,
+                               t_n=len(transposes), t_tiles=t_tiles)
     if tab["n"]:
         lib.call("fmri_pack_weight_batch", _P(tab["table"]), tab["n"], tab["tiles"])
     for item in tab["singles"]:
         lib.call("fmri_pack_weight", *item)
-    for item in tab["transposes"]:                   # (after the packs: their sources are current now)
-        lib.call("fmri_transpose_f16", *item)
+    if tab["t_n"]:                                   # (after the packs: the transposes' sources are current now)
+        lib.call("fmri_transpose_f16_batch", _P(tab["t_table"]), tab["t_n"], tab["t_tiles"])
     for pw in packed:
         pw.version = group.version
 
@@ -697,6 +723,8 @@ class ConvLayer:
                 self.pw_d = _single(self.w, group, PackSpec(sa=kk, sta=0, A=cin, TA=1, sb=cin * kk, stb=1, B=cout,
                                                             KW=k, TH=k, TW=k), self.t_in)
             self.gspec = PackSpec(sa=cin * kk, sta=0, A=cout, TA=1, sb=kk, stb=1, B=cin, KW=k, TH=k, TW=k)
+            if stride == 2:
+                self.pw_d.taps_of = self.pw_f       # class blocks = per-tap transposes of the forward copy (_repack_group)
         else:
             if stride != 2:
                 raise ValueError("deconv layers are stride 2")
@@ -704,6 +732,7 @@ class ConvLayer:
             self.pw_d = _single(self.w, group, PackSpec(sa=cout * kk, sta=0, A=cin, TA=1, sb=kk, stb=1, B=cout, KW=k,
                                                         TH=k, TW=k), self.t_in)
             self.gspec = PackSpec(sa=cout * kk, sta=0, A=cin, TA=1, sb=kk, stb=1, B=cout, KW=k, TH=k, TW=k)
+            self.pw_f.taps_of = self.pw_d
 
     def out_hw(self, hi: int, wi: int) -> Tuple[int, int]:
         if self.kind == "conv":

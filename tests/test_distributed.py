@@ -255,9 +255,20 @@ def _worker_hybrid(rank, world, port, q):
         ob.s1.copy_(oa.s1)
     run()
     ops.join_side()
+    fused, real = [0], ops.apply_group
+
+    def counting(*aa, **kw):
+        r = real(*aa, **kw)
+        fused[0] += 1 if r else 0
+        return r
+    ops.apply_group = counting
     b.step(x, e, zp)
+    ops.apply_group = real
     ops.join_side()
     torch.cuda.synchronize()
+    # the data-parallel step takes the one-launch update for all three sub-networks (mode 0 in front of each all-reduce,
+    # mode 3 behind it -- the encoder's gradients are materialised in two parts)
+    assert fused[0] == 3, f"fmri_apply_batch updated {fused[0]} of 3 sub-networks in the data-parallel step"
     la, lb = a.logs(), b.logs()
     sa, sb = a.state_dict(), b.state_dict()
     # per tensor: number of elements that differ by more than a quarter RMSprop step (8e-5), over the allowance

@@ -610,6 +610,15 @@ def _plan_apply(group, state, update=True, pend=None):
     return plan
 
 
+def _segments_within(segs, cleared) -> bool:
+    """Every flat segment the table updates from the in-place gradient buffer was cleared at the start of the pass
+    (``cleared``: "all", or the segments begin_grads cleared -- a superset when its table was built for a part of the
+    group, as in the data-parallel encoder)."""
+    if cleared == "all":
+        return True
+    return all(any(co <= o and o + n <= co + cn for co, cn in cleared) for o, n in segs)
+
+
 def flush_pending(group, keep=()):
     """Deferred gradients -> the reference-layout gradient buffer (what the separate launches would have left there).
     ``keep``: queue entries whose gradients materialize_grads has already put there."""
@@ -673,7 +682,7 @@ def apply_group(group, state, lr_dev, alpha, eps, flag, gdev, clamp=0.0) -> bool
         # same table drives the update from there (mode 3)
         mode = 3
         plan = _plan_apply(group, state, pend=done)
-    if plan is None or (group._cleared != "all" and group._cleared != plan["sig"]):
+    if plan is None or not _segments_within(plan["sig"], group._cleared):
         flush_pending(group, keep=done)
         return False
     lib.note(bytes=22.0 * group.numel)

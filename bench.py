@@ -127,11 +127,22 @@ def live_pmc_traffic(family, timeout_s=75):
             cmd = [rocprof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "x", "--",
                    sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "2", "--eager", "--serial",
                    "--no-cpu-baseline", "--no-hbm-rows", "--no-pmc", "--no-gate-pass"]
-            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=timeout_s,
-                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            # a process group of its own: on a timeout the profiler AND the python it started are killed together
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                                    stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = proc.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                import signal
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                proc.wait()
+                raise
             files = [os.path.join(d, f) for d, _, fs in os.walk(out) for f in fs if f.endswith("counter_collection.csv")]
-            if r.returncode != 0 or not files:
-                log(f"pmc pass {counter}: rc {r.returncode}, {len(files)} counter files")
+            if rc != 0 or not files:
+                log(f"pmc pass {counter}: rc {rc}, {len(files)} counter files")
                 return None
             acc = {}
             for row in csv.DictReader(open(files[0])):
@@ -556,6 +567,18 @@ def main():
     dt = time.perf_counter() - t0
     log(f"timed region done: {1e3 * dt / a.steps:.2f} ms/step ({mode})")
     logs = st.logs()
+
+    def require_finite(what, lg):
+        """A step whose losses are not finite is not a measurement: no `value` is printed and the run fails."""
+        bad = {k: v for k, v in lg.items() if isinstance(v, float) and not np.isfinite(v)}
+        if bad:
+            log(f"NON-FINITE losses after {what}: {bad}")
+            if rank == 0:
+                os.write(json_fd, (json.dumps({"metric": metric, "error": f"non-finite losses after {what}",
+                                               "losses": {k: repr(v) for k, v in lg.items() if isinstance(v, float)},
+                                               "launch": mode}) + "\n").encode())
+            sys.exit(3)
+    require_finite(f"the timed region ({a.warmup} warm-up + {a.steps} timed steps, launch mode {mode})", logs)
     # the same steps with the engine's default gate_skip=True (launches that are recorded into a full-step graph keep the
     # setting they were recorded with, so this pass uses the hybrid / eager launches), and how often the gate trained what
     gate_out = None
@@ -576,6 +599,7 @@ def main():
             dist.all_reduce(tgd, op=dist.ReduceOp.MAX)
         frac = torch.stack(seen).float().mean(0).tolist()
         st.gate_skip = False
+        require_finite("the gate-skip pass", st.logs())
         gate_out = {"ms_per_step": round(1e3 * float(tgd.item()) / gsteps, 3),
                     "value": round(world * B * gsteps / float(tgd.item()), 1), "steps": gsteps,
                     "launch": "hybrid" if "hybrid" in modes else "eager",
@@ -600,6 +624,7 @@ def main():
     e_last.record()
     barrier()
     prof, lib.PROFILE = lib.PROFILE, None
+    require_finite("the per-kernel profiling pass", st.logs())
     prof_ms_per_step = e_first.elapsed_time(e_last) / max(prof_steps, 1)
     ops._SIDE["on"] = side_was
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -628,7 +653,8 @@ def main():
             peak, runit = HBM_PEAK_GBS, "GB/s"
         # the committed PMC passes are of the Stage-I workload: no traffic figure for the other workloads
         traffic, traffic_src = None, None
-        if a.workload == "stage1" and world == 1 and not a.no_pmc:
+        # live counter passes only for the default configuration (the child runs profile THAT workload)
+        if a.workload == "stage1" and world == 1 and not a.no_pmc and not a.batch:
             traffic = live_pmc_traffic(label)
             traffic_src = "live" if traffic else None
         if traffic is None and a.workload == "stage1":
@@ -647,6 +673,7 @@ def main():
                          "unit": runit, "frac": round(achieved / peak, 4), "traffic": traffic,
                          "algorithmic_bytes": alg_bytes,
                          "traffic_over_algorithmic": round(traffic / alg_bytes, 2) if traffic and alg_bytes else None,
+                         "traffic_source": ("live" if traffic_src == "live" else f"committed:{traffic_src}") if traffic else None,
                          "traffic_unit": ("bytes per launch leaving L2, (2*FETCH_SIZE + WRITE_SIZE)*1024, "
                                           + ("measured on THIS box by two rocprofv3 --pmc child passes of this script "
                                              "(FETCH_SIZE, WRITE_SIZE: separate runs, --kernel-trace only, 5 one-stream steps)"

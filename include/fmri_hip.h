@@ -239,6 +239,17 @@ int fmri_bn_stats_finalize(const void* x, int M, int C, float* sums2C, float* ws
 int fmri_bn_cols_fwd(const void* x, void* y, int M, int C, float count, const float* gamma, const float* beta, float eps,
                      float momentum, int updates, float* running_mean, float* running_var, float* mean, float* rstd,
                      float* scale, float* shift, float* sums2C, int64_t* num_batches_tracked, int relu, void* stream);
+/* fmri_bn_cols_fwd / fmri_bn_finalize for rows stored range-scaled, x_stored = (*in_scale) * x with *in_scale a power of
+ * two (the latent batch behind fmri_latent_fwd_ranged; in_scale NULL = 1): eps is scaled by s^2, so the output equals
+ * BatchNorm(x); mean / rstd / scale / shift describe the STORED rows (what the apply and backward kernels read) and the
+ * running statistics receive mean / s and var / s^2 -- nn.BatchNorm1d behind `Decoder.fc` (models/vae_gan.py:107-109). */
+int fmri_bn_cols_fwd_s(const void* x, void* y, int M, int C, float count, const float* gamma, const float* beta, float eps,
+                       float momentum, int updates, float* running_mean, float* running_var, float* mean, float* rstd,
+                       float* scale, float* shift, float* sums2C, int64_t* num_batches_tracked, int relu,
+                       const float* in_scale, void* stream);
+int fmri_bn_finalize_s(const float* sums2C, int C, float count, const float* gamma, const float* beta, float eps,
+                       float momentum, int updates, float* running_mean, float* running_var, float* mean, float* rstd,
+                       float* scale, float* shift, int64_t* num_batches_tracked, const float* in_scale, void* stream);
 int fmri_bn_cols_bwd(const void* x, const void* dy, void* dx, int M, int C, int nstreams, float count, const float* mean,
                      const float* rstd, const float* gamma, const float* beta, int relu, float* sums, float* dbeta,
                      float* dgamma, float gscale, int param_stream, void* stream);
@@ -295,6 +306,19 @@ int fmri_colsum_rows(const void* x16, int M, int C, float* sums2C, float* ws, in
 /* ---- latent / losses (models/vae_gan.py:266-269, :302-320; train_vgan_stage1.py:368-404) ----------- */
 int fmri_latent_fwd(const float* head, const float* eps, int B, int Z, int zp, void* z16, float* kl_rows,
                     float* kl_total, int sample, void* stream);
+/* Range-safe `VaeGan.reparameterize` (models/vae_gan.py:266-269) for fp16 consumers: sigma = exp(0.5 logvar) leaves
+ * fp16's range at logvar > 22.2, where the reference's fp32 arithmetic is still finite (it overflows at logvar > 88.7).
+ *   phase & 1: z = eps * exp(0.5 logvar) + mu (sample) or mu -> z32 [B][Z] fp32, KL as fmri_latent_fwd,
+ *              *zmax = max(*zmax, max |z|)   (the caller zeroes *zmax; data-parallel SyncBN runs all-reduce it with MAX)
+ *   phase & 2: *zscale = s = the largest power of two <= 1 with s * (*zmax) <= cap (1 when *zmax <= cap or non-finite),
+ *              z16 [B][zp] = fp16(s * z32), padding columns zero.
+ * Consumers: the GEMM of `Decoder.fc` on z16, fmri_bn_cols_fwd_s / fmri_bn_finalize_s with in_scale = zscale; the data
+ * gradient w.r.t. z is s times the one w.r.t. the stored rows, the weight gradient needs no correction.
+ * fmri_rows_absmax: *zmax = max(*zmax, max |x|) for a caller-provided fp32 latent (then phase 2 with z32 = x). */
+int fmri_latent_fwd_ranged(const float* head, const float* eps, int B, int Z, int zp, void* z16, float* kl_rows,
+                           float* kl_total, int sample, float* z32, float* zmax, float* zscale, float cap, int phase,
+                           void* stream);
+int fmri_rows_absmax(const float* x, int64_t n, float* zmax, void* stream);
 int fmri_latent_bwd(const float* head, const float* eps, const float* dz, int ldz, float dz_unscale, float kl_w,
                     const float* kl_dev, int B, int Z, float out_scale, void* dhead16, float* dhead32, int sample,
                     void* stream);
@@ -363,6 +387,12 @@ int fmri_axpby2_f16(const void* x, const void* y, void* out, int64_t n, float a,
 int fmri_sumsq(const float* x, int64_t n, float* acc, void* stream);
 int fmri_renorm(const float* x, void* out16, int64_t n, float scale, const float* sumsq, float count,
                 const float* factor_in, float* factor_out, void* stream);
+/* The same with the sum of squares in double precision (8-byte aligned device double; zero_first: cleared by the launch
+ * itself): the encoder cotangent of `VaeGan.loss`'s KL term (models/vae_gan.py:310) holds 0.5 * (exp(logvar) - 1), whose
+ * square leaves fp32 at logvar > 44 while the reference's fp32 step is finite up to logvar 88 -- what the steps use. */
+int fmri_sumsq_f64(const float* x, int64_t n, double* acc, int zero_first, void* stream);
+int fmri_renorm_f64(const float* x, void* out16, int64_t n, float scale, const double* sumsq, float count,
+                    const float* factor_in, float* factor_out, void* stream);
 
 /* ---- optimizers over flat fp32 buffers (train_vgan_stage1.py:275-283; train_wae_stage1.py:221-224) ---
  * g_true = g * gscale / (*gdev) (gdev: device float or NULL), clamped to +-clamp if clamp > 0; the whole

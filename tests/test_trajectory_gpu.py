@@ -1,0 +1,191 @@
+"""Trajectory-level checks of the fused Stage-I step (the reference's unit of work is an epoch of steps,
+train/train_vgan_stage1.py:311-445, not one step).
+
+  * 150 steps at the benchmark's batch 256 on bench.py's rotating synthetic batches stay finite in every launch mode
+    (two streams, one stream, recorded forward), weights and optimizer state included -- before round 5 roughly a third of
+    such runs ended with NaN losses: the latent's sigma = exp(0.5 logvar) left fp16's range.
+  * 50 free-running steps at batch 32 next to the fp32 CPU oracle from the same weights and data: the same equilibrium-gate
+    decisions and losses inside a stated envelope for as long as two arithmetic models of a GAN can be expected to agree.
+  * the one-step parity repeated ALONG the oracle's trajectory (engine re-loaded with the oracle's weights, BatchNorm
+    buffers and RMSprop state every few steps): the step is right at trained weights too, not only at the initial recipe.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+NBATCH = 8
+LOSSES = ("bce_orig", "bce_pred", "bce_samp", "kl", "mse", "nle")
+
+
+def _bench_data(B, Z):
+    """bench.py's rotating batches (rank 0)."""
+    xs = [torch.from_numpy(np.random.RandomState(1234 + 97 * i).uniform(-1, 1, (B, 3, 64, 64)).astype(np.float32))
+          for i in range(NBATCH)]
+    nz = [torch.from_numpy(np.random.RandomState(1236 + 97 * i).standard_normal((2, B, Z)).astype(np.float32))
+          for i in range(NBATCH)]
+    return xs, nz
+
+
+def _finite_state(st):
+    for name, net, opt in (("encoder", st.enc, st.opt_enc), ("decoder", st.dec, st.opt_dec),
+                           ("discriminator", st.dis, st.opt_dis)):
+        assert torch.isfinite(net.group.data).all(), f"{name}: non-finite weights"
+        assert torch.isfinite(opt.s1).all(), f"{name}: non-finite RMSprop state"
+        for pw in net.group.packed:
+            assert torch.isfinite(pw.buf.float()).all(), f"{name}: non-finite fp16 weight copy"
+    for k, v in st.state_dict().items():
+        if v.is_floating_point():
+            assert torch.isfinite(v).all(), k
+
+
+@pytest.mark.parametrize("mode", ["two_streams", "one_stream", "hybrid"])
+def test_stage1_b256_150_steps_stay_finite(mode):
+    from fmri_hip import ops
+    from fmri_hip.params import ArchConfig
+    from fmri_hip.steps import Stage1Step
+    cfg = ArchConfig.px64()
+    B, steps = 256, 150
+    xs, nz = _bench_data(B, cfg.latent_dim)
+    xs = [x.to(DEV) for x in xs]
+    nz = [n.to(DEV) for n in nz]
+    side_was = ops._SIDE["on"]
+    ops.join_side()
+    ops._SIDE["on"] = mode != "one_stream"
+    try:
+        st = Stage1Step(cfg, DEV, gate_skip=False)           # bench.py's headline setting: every GEMM in every step
+        st.load_recipe(0, False)
+        run = lambda i: st.step(xs[i % NBATCH], nz[i % NBATCH][0], nz[i % NBATCH][1])
+        n0 = 0
+        if mode == "hybrid":
+            for i in range(20):
+                run(i)
+            n0 = 20
+            sb = [xs[0].clone(), nz[0][0].clone(), nz[0][1].clone()]
+            replay = st.capture_forward(*sb)
+
+            def run(i):
+                j = i % NBATCH
+                sb[0].copy_(xs[j]); sb[1].copy_(nz[j][0]); sb[2].copy_(nz[j][1])
+                return replay()
+        rec, lv = [], []
+        for i in range(n0, n0 + steps):
+            run(i)
+            rec.append(st.scal[:10].clone())
+            lv.append(st.fw["head32"][:, cfg.latent_dim:].max())
+        ops.join_side()
+        torch.cuda.synchronize()
+        R = torch.stack(rec).cpu().numpy()
+        bad = np.argwhere(~np.isfinite(R))
+        assert bad.size == 0, f"first non-finite loss at step {bad[0][0]} (slot {bad[0][1]})"
+        _finite_state(st)
+        print(f"[{mode}] max logvar over the run {float(torch.stack(lv).max()):.2f}; last kl {R[-1, 3]:.1f} "
+              f"mse {R[-1, 4]:.1f} nle {R[-1, 5]:.1f}")
+        # the run is a training run, not a fixed point: the decoder is alive (x_tilde is not the all-zero image, whose
+        # nle against U[-1, 1] images is 1/6 per pixel value)
+        assert R[-1, 5] > 1.2 * B * 3 * 64 * 64 / 6.0
+    finally:
+        ops.join_side()
+        ops._SIDE["on"] = side_was
+
+
+def _load_opt_state(st, opts, O, cfg_o):
+    """Oracle RMSprop state -> the engine's flat square-average buffers (reference layout, FlatGroup.offsets)."""
+    for name, net, opt in (("encoder", st.enc, st.opt_enc), ("decoder", st.dec, st.opt_dec),
+                           ("discriminator", st.dis, st.opt_dis)):
+        g = net.group
+        opt.s1.zero_()
+        for k in g.pkeys:
+            buf = opts[name].bufs.get(f"{name}.{k}")
+            if buf is not None:
+                o = g.offsets[k]
+                opt.s1[o:o + buf.numel()].copy_(buf.reshape(-1).to(DEV))
+
+
+def _sd_for_engine(P):
+    return {k: (v.detach().reshape(()) if k.endswith("num_batches_tracked") else v.detach().clone()) for k, v in P.items()}
+
+
+def test_stage1_b32_free_running_next_to_the_oracle():
+    from fmri_hip.params import ArchConfig
+    from fmri_hip.steps import Stage1Step
+    from oracle import vaegan_oracle as O
+    cfg_o, cfg_e = O.ArchCfg.px64(), ArchConfig.px64()
+    B, steps = 32, 50
+    xs, nz = _bench_data(B, cfg_e.latent_dim)
+    P = O.fill_state(O.vaegan_spec(cfg_o), 0, False)
+    opts = {n: O.OptState(kind="rmsprop", lr=1e-4) for n in ("encoder", "decoder", "discriminator")}
+    st = Stage1Step(cfg_e, DEV)
+    st.load_recipe(0, False)
+    rows = []
+    for i in range(steps):
+        j = i % NBATCH
+        st.step(xs[j].to(DEV), nz[j][0].to(DEV), nz[j][1].to(DEV))
+        torch.cuda.synchronize()
+        got = st.logs()
+        ref = O.stage1_step(P, opts, xs[j], nz[j][0], nz[j][1], cfg_o)["logs"]
+        rel = {k: abs(got[k] - ref[k]) / max(abs(ref[k]), 1e-12) for k in LOSSES}
+        rows.append((i, got["train_dis"] == ref["train_dis"] and got["train_dec"] == ref["train_dec"], rel, got, ref))
+        assert all(np.isfinite(got[k]) for k in LOSSES), (i, got)
+    print("step gate_same " + " ".join(f"{k:>9s}" for k in LOSSES))
+    for i, same, rel, got, ref in rows:
+        print(f"{i:4d} {str(same):>9s} " + " ".join(f"{rel[k]:9.2e}" for k in LOSSES)
+              + f"   kl {got['kl']:.1f}/{ref['kl']:.1f} bce_pred {got['bce_pred']:.2f}/{ref['bce_pred']:.2f}")
+    first_gate_split = next((i for i, same, *_ in rows if not same), steps)
+    # Envelope.  Step 0 is the one-step parity (tests/test_stage1_gpu.py: 1e-3).  From there two arithmetic models of the
+    # same GAN drift apart at the rate the dynamics amplify a 16-bit rounding -- measured tables in DESIGN 8.
+    assert all(rows[0][2][k] < 1e-3 for k in LOSSES), rows[0][2]
+    assert first_gate_split >= 10, f"equilibrium gate decisions differ already at step {first_gate_split}"
+    for i, same, rel, got, ref in rows[:10]:
+        for k in LOSSES:
+            assert rel[k] < 5e-2, (i, k, got[k], ref[k])
+
+
+def test_stage1_one_step_parity_along_the_oracle_trajectory():
+    """Every 6th step of a 37-step oracle run at batch 32: the engine, re-loaded with the oracle's weights, BatchNorm
+    buffers and RMSprop state, makes that step; its losses (before the step) agree to 1e-3 and the losses of the NEXT
+    forward -- i.e. after the engine's own update -- to the after-one-step bound."""
+    from fmri_hip.params import ArchConfig
+    from fmri_hip.steps import Stage1Step
+    from oracle import vaegan_oracle as O
+    cfg_o, cfg_e = O.ArchCfg.px64(), ArchConfig.px64()
+    B, steps, every = 32, 37, 6
+    xs, nz = _bench_data(B, cfg_e.latent_dim)
+    P = O.fill_state(O.vaegan_spec(cfg_o), 0, False)
+    opts = {n: O.OptState(kind="rmsprop", lr=1e-4) for n in ("encoder", "decoder", "discriminator")}
+    st = Stage1Step(cfg_e, DEV)
+    checked = 0
+    pending = None                       # (step, engine logs of the forward on its own updated weights)
+    for i in range(steps):
+        j = i % NBATCH
+        if i % every == 0:
+            st.load_state_dict(_sd_for_engine(P))
+            _load_opt_state(st, opts, O, cfg_o)
+            st.step(xs[j].to(DEV), nz[j][0].to(DEV), nz[j][1].to(DEV))
+            torch.cuda.synchronize()
+            got = st.logs()
+            # the forward on the engine's own updated weights, next batch (no update: forward + gate only)
+            jn = (i + 1) % NBATCH
+            st.forward(xs[jn].to(DEV), nz[jn][0].to(DEV), nz[jn][1].to(DEV))
+            st.gate(B)
+            torch.cuda.synchronize()
+            pending = (i, st.logs())
+        ref = O.stage1_step(P, opts, xs[j], nz[j][0], nz[j][1], cfg_o)["logs"]
+        if i % every == 0:
+            for k in LOSSES + ("loss_encoder", "loss_decoder", "loss_discriminator"):
+                rel = abs(got[k] - ref[k]) / max(abs(ref[k]), 1e-12)
+                assert rel < 1e-3, (i, k, got[k], ref[k], rel)
+            assert got["train_dis"] == ref["train_dis"] and got["train_dec"] == ref["train_dec"], (i, got, ref)
+            checked += 1
+        elif pending is not None and pending[0] == i - 1:
+            after = pending[1]
+            worst = max(abs(after[k] - ref[k]) / max(abs(ref[k]), 1e-12) for k in LOSSES)
+            print(f"step {i - 1}: losses after the engine's own update vs the oracle's: worst rel {worst:.2e} "
+                  + " ".join(f"{k} {abs(after[k] - ref[k]) / max(abs(ref[k]), 1e-12):.1e}" for k in LOSSES))
+            for k in LOSSES:
+                rel = abs(after[k] - ref[k]) / max(abs(ref[k]), 1e-12)
+                assert rel < 5e-2, (i, k, after[k], ref[k], rel)          # batch 4..32 bound of test_stage1_gpu.py
+            pending = None
+    assert checked == (steps + every - 1) // every

@@ -798,7 +798,14 @@ int fmri_bn_finalize(const float* sums2C, int C, float count, const float* gamma
                      float* scale, float* shift, int64_t* num_batches_tracked, void* stream) {
     if (!sums2C || !gamma || !beta || !mean || !rstd || !scale || !shift) return FMRI_E_BADARG;
     return bn_finalize_launch(sums2C, C, count, gamma, beta, eps, momentum, updates, running_mean, running_var, mean,
-                              rstd, scale, shift, (long long*)num_batches_tracked, S(stream));
+                              rstd, scale, shift, (long long*)num_batches_tracked, nullptr, S(stream));
+}
+int fmri_bn_finalize_s(const float* sums2C, int C, float count, const float* gamma, const float* beta, float eps,
+                       float momentum, int updates, float* running_mean, float* running_var, float* mean, float* rstd,
+                       float* scale, float* shift, int64_t* num_batches_tracked, const float* in_scale, void* stream) {
+    if (!sums2C || !gamma || !beta || !mean || !rstd || !scale || !shift) return FMRI_E_BADARG;
+    return bn_finalize_launch(sums2C, C, count, gamma, beta, eps, momentum, updates, running_mean, running_var, mean,
+                              rstd, scale, shift, (long long*)num_batches_tracked, in_scale, S(stream));
 }
 int fmri_bn_stats_finalize(const void* x, int M, int C, float* sums2C, float* ws, int64_t ws_floats, float count,
                            const float* gamma, const float* beta, float eps, float momentum, int updates,
@@ -817,7 +824,17 @@ int fmri_bn_cols_fwd(const void* x, void* y, int M, int C, float count, const fl
         return FMRI_E_BADARG;
     return bn_cols_fwd_launch((const half_t*)x, (half_t*)y, M, C, count, gamma, beta, eps, momentum, updates, running_mean,
                               running_var, mean, rstd, scale, shift, sums2C, (long long*)num_batches_tracked, relu,
-                              S(stream));
+                              nullptr, S(stream));
+}
+int fmri_bn_cols_fwd_s(const void* x, void* y, int M, int C, float count, const float* gamma, const float* beta, float eps,
+                       float momentum, int updates, float* running_mean, float* running_var, float* mean, float* rstd,
+                       float* scale, float* shift, float* sums2C, int64_t* num_batches_tracked, int relu,
+                       const float* in_scale, void* stream) {
+    if (!x || !y || !sums2C || (C & 7) || C < 8 || M < 1 || !gamma || !beta || !mean || !rstd || !scale || !shift)
+        return FMRI_E_BADARG;
+    return bn_cols_fwd_launch((const half_t*)x, (half_t*)y, M, C, count, gamma, beta, eps, momentum, updates, running_mean,
+                              running_var, mean, rstd, scale, shift, sums2C, (long long*)num_batches_tracked, relu,
+                              in_scale, S(stream));
 }
 int fmri_bn_cols_bwd(const void* x, const void* dy, void* dx, int M, int C, int nstreams, float count, const float* mean,
                      const float* rstd, const float* gamma, const float* beta, int relu, float* sums, float* dbeta,
@@ -904,6 +921,19 @@ int fmri_latent_fwd(const float* head, const float* eps, int B, int Z, int zp, v
                     float* kl_total, int sample, void* stream) {
     if (!head || !z16 || (sample && !eps) || zp < Z) return FMRI_E_BADARG;
     return latent_fwd_launch(head, eps, B, Z, zp, (half_t*)z16, kl_rows, kl_total, sample, S(stream));
+}
+int fmri_latent_fwd_ranged(const float* head, const float* eps, int B, int Z, int zp, void* z16, float* kl_rows,
+                           float* kl_total, int sample, float* z32, float* zmax, float* zscale, float cap, int phase,
+                           void* stream) {
+    if (!z32 || !zmax || phase < 1 || phase > 3 || zp < Z || B < 1 || Z < 1) return FMRI_E_BADARG;
+    if ((phase & 1) && (!head || (sample && !eps))) return FMRI_E_BADARG;
+    if ((phase & 2) && (!z16 || !zscale || !(cap > 0.f))) return FMRI_E_BADARG;
+    return latent_ranged_launch(head, eps, B, Z, zp, (half_t*)z16, kl_rows, kl_total, sample, z32, zmax, zscale, cap, phase,
+                                S(stream));
+}
+int fmri_rows_absmax(const float* x, int64_t n, float* zmax, void* stream) {
+    if (!x || !zmax || n < 1) return FMRI_E_BADARG;
+    return rows_absmax_launch(x, n, zmax, S(stream));
 }
 int fmri_latent_bwd(const float* head, const float* eps, const float* dz, int ldz, float dz_unscale, float kl_w,
                     const float* kl_dev, int B, int Z, float out_scale, void* dhead16, float* dhead32, int sample,
@@ -1015,6 +1045,15 @@ int fmri_renorm(const float* x, void* out16, int64_t n, float scale, const float
                 const float* factor_in, float* factor_out, void* stream) {
     if (!x || !out16 || !sumsq || count <= 0.f) return FMRI_E_BADARG;
     return renorm_launch(x, (half_t*)out16, n, scale, sumsq, count, factor_in, factor_out, S(stream));
+}
+int fmri_sumsq_f64(const float* x, int64_t n, double* acc, int zero_first, void* stream) {
+    if (!x || !acc || ((uintptr_t)acc & 7)) return FMRI_E_BADARG;
+    return sumsq64_launch(x, n, acc, zero_first, S(stream));
+}
+int fmri_renorm_f64(const float* x, void* out16, int64_t n, float scale, const double* sumsq, float count,
+                    const float* factor_in, float* factor_out, void* stream) {
+    if (!x || !out16 || !sumsq || ((uintptr_t)sumsq & 7) || count <= 0.f) return FMRI_E_BADARG;
+    return renorm64_launch(x, (half_t*)out16, n, scale, sumsq, count, factor_in, factor_out, S(stream));
 }
 int fmri_rmsprop(float* p, const float* g, float* sq, int64_t n, float lr, float alpha, float eps, float gscale,
                  const float* gdev, float clamp, const int* flag, void* stream) {

@@ -129,10 +129,11 @@ int bn_bwd_fold_launch(const float* part, int rows, int rows_cap, int C, int G, 
                        float* dbeta, float* dgamma, float gscale, int pgroup, hipStream_t st);
 int bn_finalize_launch(const float* sums, int C, float count, const float* gamma, const float* beta, float eps,
                        float momentum, int updates, float* rm, float* rv, float* mean, float* rstd, float* scale,
-                       float* shift, long long* nbt, hipStream_t st);
+                       float* shift, long long* nbt, const float* in_scale, hipStream_t st);
 int bn_cols_fwd_launch(const half_t* x, half_t* y, int M, int C, float count, const float* gamma, const float* beta,
                        float eps, float momentum, int updates, float* rm, float* rv, float* mean, float* rstd,
-                       float* scale, float* shift, float* sums2C, long long* nbt, int relu, hipStream_t st);
+                       float* scale, float* shift, float* sums2C, long long* nbt, int relu, const float* in_scale,
+                       hipStream_t st);
 int bn_cols_bwd_launch(const half_t* x, const half_t* dy, half_t* dx, int M, int C, int nstreams, float count,
                        const float* mean, const float* rstd, const float* gamma, const float* beta, int relu, float* sums,
                        float* dbeta, float* dgamma, float gscale, int pstream, hipStream_t st);
@@ -158,6 +159,10 @@ extern int g_deterministic;
 
 int latent_fwd_launch(const float* head, const float* eps, int B, int Z, int zp, half_t* z16, float* kl_rows,
                       float* kl_total, int sample, hipStream_t st);
+int latent_ranged_launch(const float* head, const float* eps, int B, int Z, int zp, half_t* z16, float* kl_rows,
+                         float* kl_total, int sample, float* z32, float* zmax, float* zscale, float cap, int phase,
+                         hipStream_t st);
+int rows_absmax_launch(const float* x, int64_t n, float* zmax, hipStream_t st);
 int latent_bwd_launch(const float* head, const float* eps, const float* dz, int ldz, float dz_unscale, float kl_w,
                       const float* kl_dev, int B, int Z, float out_scale, half_t* dhead16, float* dhead32, int sample,
                       hipStream_t st);
@@ -180,6 +185,9 @@ int axpby_f16_launch(const half_t* x, const half_t* y, half_t* out, int64_t n, f
 int sumsq_launch(const float* x, int64_t n, float* acc, hipStream_t st);
 int renorm_launch(const float* x, half_t* out, int64_t n, float scale, const float* sumsq, float count,
                   const float* factor_in, float* factor_out, hipStream_t st);
+int sumsq64_launch(const float* x, int64_t n, double* acc, int zero_first, hipStream_t st);
+int renorm64_launch(const float* x, half_t* out, int64_t n, float scale, const double* sumsq, float count,
+                    const float* factor_in, float* factor_out, hipStream_t st);
 int rmsprop_launch(float* p, const float* g, float* sq, int64_t n, float lr, float alpha, float eps, float gscale,
                    const float* gdev, float clamp, const int* flag, const float* lr_dev, hipStream_t st);
 int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,

@@ -79,6 +79,83 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(const float* __restrict
     if (threadIdx.x == 0 && kl_total) atomicAdd(kl_total, (sh[0] + sh[1]) + (sh[2] + sh[3]));
 }
 
+// ---- range-safe latent (fmri_latent_fwd_ranged).  sigma = exp(0.5 logvar) leaves fp16's range at logvar > 22.2, which
+// an fp32 run survives (the reference's arithmetic overflows at logvar > 88.7) and a training run does reach: one
+// outlier row of a BatchNorm1d batch is enough.  The fp16 rows the decoder's first GEMM reads are therefore
+// stored as s * z with s = 2^-k the largest power of two <= 1 that brings max |z| of the batch under `cap` -- s = 1, and
+// bit-identical rows, whenever max |z| <= cap.  The BatchNorm1d behind that GEMM is invariant under the scaling once its
+// eps is scaled by s^2 (bn_finalize_channel), the weight gradient is exact (cotangent / s times input * s) and the data
+// gradient is multiplied by s.
+//   phase 1: z (fp32, [B][Z]) -> z32, per-sample / total KL, *zmax = max(*zmax, max |z|) (bit pattern of a float >= 0)
+//   phase 2: s from *zmax -> *zscale; z16 = z32 * s (padding columns zero)
+__global__ __launch_bounds__(256) void latent_z32_kernel(const float* __restrict__ head, const float* __restrict__ eps,
+                                                         int B, int Z, float* __restrict__ z32,
+                                                         float* __restrict__ kl_rows, float* __restrict__ kl_total,
+                                                         int sample, float* __restrict__ zmax) {
+    __shared__ float sh[4], shm[4];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    float klw = 0.f, mx = 0.f;
+    for (int row = blockIdx.x * 4 + wave; row < B; row += gridDim.x * 4) {
+        float kl = 0.f;
+        for (int j = lane; j < Z; j += 64) {
+            const float mu = head[(int64_t)row * 2 * Z + j];
+            const float lv = head[(int64_t)row * 2 * Z + Z + j];
+            const float zz = sample ? eps[(int64_t)row * Z + j] * __expf(0.5f * lv) + mu : mu;
+            kl += -0.5f * (-__expf(lv) - mu * mu + lv + 1.f);
+            z32[(int64_t)row * Z + j] = zz;
+            mx = fmaxf(mx, fabsf(zz));           // (a NaN is dropped here and reaches z16 through phase 2)
+        }
+        kl = wave_sum(kl);
+        if (lane == 0 && kl_rows) kl_rows[row] = kl;
+        klw += kl;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) { sh[wave] = klw; shm[wave] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (kl_total) atomicAdd(kl_total, (sh[0] + sh[1]) + (sh[2] + sh[3]));
+        atomicMax((unsigned int*)zmax, __float_as_uint(fmaxf(fmaxf(shm[0], shm[1]), fmaxf(shm[2], shm[3]))));
+    }
+}
+
+__global__ __launch_bounds__(256) void rows_absmax_kernel(const float* __restrict__ x, int64_t n,
+                                                          float* __restrict__ zmax) {
+    __shared__ float shm[4];
+    float mx = 0.f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        mx = fmaxf(mx, fabsf(x[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) shm[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        atomicMax((unsigned int*)zmax, __float_as_uint(fmaxf(fmaxf(shm[0], shm[1]), fmaxf(shm[2], shm[3]))));
+}
+
+__device__ __forceinline__ float range_scale(float m, float cap) {
+    // largest power of two s <= 1 with m * s <= cap; 1 for a non-finite maximum (the rows then carry inf / NaN on, as
+    // the reference's arithmetic does) -- at most 2^-60, so that eps * s^2 stays a normal fp32 number
+    if (!(m > cap) || m > 3.0e38f) return 1.f;
+    int e;
+    (void)frexpf(m / cap, &e);                   // m / cap = f * 2^e, f in [0.5, 1)  ->  m * 2^-e <= cap
+    return ldexpf(1.f, -(e > 60 ? 60 : e));
+}
+
+__global__ __launch_bounds__(256) void latent_pack_kernel(const float* __restrict__ z32, int B, int Z, int zp,
+                                                          half_t* __restrict__ z16, const float* __restrict__ zmax,
+                                                          float* __restrict__ zscale, float cap) {
+    const float s = range_scale(*zmax, cap);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *zscale = s;
+    const int64_t total = (int64_t)B * zp;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i % zp);
+        const int64_t row = i / zp;
+        z16[i] = (half_t)(j < Z ? z32[row * Z + j] * s : 0.f);
+    }
+}
+
 // backward: dhead[row] = ([ g + w*mu | g*eps*0.5*exp(0.5 lv) + w*0.5*(exp(lv)-1) ]) * out_scale
 //   g = dz * dz_unscale (dz may be null), w = kl_w * (*kl_dev) (kl_dev may be null -> 1): when dz carries a
 //   device normalisation factor n the KL term is multiplied by the same n so the sum stays consistent.
@@ -358,10 +435,26 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
     if (threadIdx.x == 0) atomicAdd(acc, s);
 }
 
+// The double-precision form (fmri_sumsq_f64 / fmri_renorm_f64) is the one the steps use: the encoder cotangent holds
+// 0.5 * (exp(logvar) - 1) (the KL term), whose SQUARE leaves fp32 at logvar > 44 -- the float sum then reads inf, the
+// factor 0, and the optimizer divides 0 by 0 -- while the reference's fp32 arithmetic is finite up to logvar 88.
+__global__ __launch_bounds__(256) void sumsq64_kernel(const float* __restrict__ x, int64_t n, double* __restrict__ acc) {
+    __shared__ double shd[4];
+    double s = 0.0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        s += (double)x[i] * (double)x[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) shd[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(acc, (shd[0] + shd[1]) + (shd[2] + shd[3]));
+}
+
+template <typename T>
 __global__ void renorm_kernel(const float* __restrict__ x, half_t* __restrict__ out, int64_t n, float scale,
-                              const float* __restrict__ sumsq, float count, const float* __restrict__ factor_in,
+                              const T* __restrict__ sumsq, float count, const float* __restrict__ factor_in,
                               float* __restrict__ factor_out) {
-    const float f = 1.f / fmaxf(sqrtf(*sumsq / count), 1e-20f);
+    const float f = 1.f / fmaxf((float)sqrt((double)*sumsq / (double)count), 1e-20f);
     const float sc = f * scale;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         out[i] = (half_t)(x[i] * sc);
@@ -437,6 +530,23 @@ int latent_fwd_launch(const float* head, const float* eps, int B, int Z, int zp,
                        sample);
     return LAUNCH_OK();
 }
+int latent_ranged_launch(const float* head, const float* eps, int B, int Z, int zp, half_t* z16, float* kl_rows,
+                         float* kl_total, int sample, float* z32, float* zmax, float* zscale, float cap, int phase,
+                         hipStream_t st) {
+    if (phase & 1) {
+        const int grid = kl_total ? rblk((B + 3) / 4) : (B + 3) / 4;
+        hipLaunchKernelGGL(latent_z32_kernel, dim3(grid), dim3(256), 0, st, head, eps, B, Z, z32, kl_rows, kl_total, sample,
+                           zmax);
+    }
+    if (phase & 2)
+        hipLaunchKernelGGL(latent_pack_kernel, dim3(nblk((int64_t)B * zp, 256)), dim3(256), 0, st, (const float*)z32, B, Z,
+                           zp, z16, (const float*)zmax, zscale, cap);
+    return LAUNCH_OK();
+}
+int rows_absmax_launch(const float* x, int64_t n, float* zmax, hipStream_t st) {
+    hipLaunchKernelGGL(rows_absmax_kernel, dim3(nblk(n, 256)), dim3(256), 0, st, x, n, zmax);
+    return LAUNCH_OK();
+}
 int latent_bwd_launch(const float* head, const float* eps, const float* dz, int ldz, float dz_unscale, float kl_w,
                       const float* kl_dev, int B, int Z, float out_scale, half_t* dhead16, float* dhead32, int sample,
                       hipStream_t st) {
@@ -503,8 +613,19 @@ int sumsq_launch(const float* x, int64_t n, float* acc, hipStream_t st) {
 }
 int renorm_launch(const float* x, half_t* out, int64_t n, float scale, const float* sumsq, float count,
                   const float* factor_in, float* factor_out, hipStream_t st) {
-    hipLaunchKernelGGL(renorm_kernel, dim3(nblk(n, 256)), dim3(256), 0, st, x, out, n, scale, sumsq, count, factor_in,
-                       factor_out);
+    hipLaunchKernelGGL(renorm_kernel<float>, dim3(nblk(n, 256)), dim3(256), 0, st, x, out, n, scale, sumsq, count,
+                       factor_in, factor_out);
+    return LAUNCH_OK();
+}
+int sumsq64_launch(const float* x, int64_t n, double* acc, int zero_first, hipStream_t st) {
+    if (zero_first && hipMemsetAsync(acc, 0, sizeof(double), st) != hipSuccess) return E_LAUNCH;
+    hipLaunchKernelGGL(sumsq64_kernel, dim3(rblk(nblk(n, 256))), dim3(256), 0, st, x, n, acc);
+    return LAUNCH_OK();
+}
+int renorm64_launch(const float* x, half_t* out, int64_t n, float scale, const double* sumsq, float count,
+                    const float* factor_in, float* factor_out, hipStream_t st) {
+    hipLaunchKernelGGL(renorm_kernel<double>, dim3(nblk(n, 256)), dim3(256), 0, st, x, out, n, scale, sumsq, count,
+                       factor_in, factor_out);
     return LAUNCH_OK();
 }
 int rmsprop_launch(float* p, const float* g, float* sq, int64_t n, float lr, float alpha, float eps, float gscale,

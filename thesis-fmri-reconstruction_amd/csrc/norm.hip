@@ -43,6 +43,14 @@ static RowGeom row_geometry(int M, int C, int max_gy) {
 
 // MODE 0: sum x, sum x^2.  MODE 1: sum g, sum g*xhat (g = dy masked by the ReLU of the forward).
 // MODE 2: activation backward: dpre = dy*act'(y) written to `dout`, column sums of dpre.
+// fp16 store of a BatchNorm-backward result that SATURATES at +-65504 instead of overflowing to inf.  dx = gamma * rstd *
+// (...) is the one place of the backward pass where a healthy cotangent is multiplied by an unbounded factor: a feature
+// whose batch variance is tiny has rstd up to 1 / sqrt(eps) = 316 -- and 1 / (s sqrt(eps)) behind a range-scaled latent
+// batch (bn_finalize_channel) -- so a few of the 8 M results of a step that follows a latent excursion cross fp16's
+// range (measured: 1-6 values per such step).  An inf there turns the whole step into NaN (inf - inf in the
+// GEMMs that consume it); the saturated value is a clipped gradient for the handful of weights it touches.
+__device__ __forceinline__ half_t sat16(float v) { return (half_t)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f); }
+
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const half_t* __restrict__ x, const half_t* __restrict__ dy,
                                                         half_t* __restrict__ dout, int M, int C, int cx_log2,
@@ -237,25 +245,32 @@ __global__ __launch_bounds__(1024) void fold_groups_kernel(const float* __restri
     }
 }
 
-// shared by bn_finalize_kernel and fold_finalize_kernel: channel c from its batch sums
+// shared by bn_finalize_kernel and fold_finalize_kernel: channel c from its batch sums.
+// ``in_s``: the rows are s * x for a power of two s (a latent batch stored range-scaled, fmri_latent_fwd_ranged):
+// BN_eps(x) == BN_{eps s^2}(s x), so the normalisation runs on the stored values with eps * s^2 -- mean / rstd / scale /
+// shift are those of the STORED rows (what the apply and backward kernels read) -- and the running statistics receive
+// the true-scale mean / s and var / s^2.
 __device__ __forceinline__ void bn_finalize_channel(int c, float sx, float sxx, float count, const float* gamma,
                                                     const float* beta, float eps, float momentum, int updates,
                                                     float* running_mean, float* running_var, float* mean_out,
-                                                    float* rstd_out, float* scale_out, float* shift_out) {
+                                                    float* rstd_out, float* scale_out, float* shift_out,
+                                                    float in_s = 1.f) {
     const float mean = sx / count;
     float var = sxx / count - mean * mean;
     var = var > 0.f ? var : 0.f;
-    const float rstd = rsqrtf(var + eps);
+    const float rstd = rsqrtf(var + eps * in_s * in_s);
     mean_out[c] = mean;
     rstd_out[c] = rstd;
     const float sc = gamma[c] * rstd;
     scale_out[c] = sc;
     shift_out[c] = beta[c] - mean * sc;
     if (running_mean && updates > 0) {
-        const float unb = count > 1.f ? var * count / (count - 1.f) : var;
+        const float inv_s = 1.f / in_s;
+        const float unb = (count > 1.f ? var * count / (count - 1.f) : var) * inv_s * inv_s;
+        const float mean_t = mean * inv_s;
         float rm = running_mean[c], rv = running_var[c];
         for (int u = 0; u < updates; ++u) {
-            rm = (1.f - momentum) * rm + momentum * mean;
+            rm = (1.f - momentum) * rm + momentum * mean_t;
             rv = (1.f - momentum) * rv + momentum * unb;
         }
         running_mean[c] = rm;
@@ -313,12 +328,12 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, int C, float 
                                    float* __restrict__ running_mean, float* __restrict__ running_var,
                                    float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                    float* __restrict__ scale_out, float* __restrict__ shift_out,
-                                   long long* __restrict__ nbt) {
+                                   long long* __restrict__ nbt, const float* __restrict__ in_scale) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c == 0 && nbt && updates > 0) *nbt += updates;      // num_batches_tracked
     if (c >= C) return;
     bn_finalize_channel(c, sums[c], sums[C + c], count, gamma, beta, eps, momentum, updates, running_mean, running_var,
-                        mean_out, rstd_out, scale_out, shift_out);
+                        mean_out, rstd_out, scale_out, shift_out, in_scale ? *in_scale : 1.f);
 }
 
 // MODE 0: y = act(x*scale + shift).   MODE 1: dx = gamma*rstd*(g - sum_g/M - xhat*sum_gx/M), g = dy*mask
@@ -363,7 +378,7 @@ __global__ __launch_bounds__(256) void bn_stream_kernel(const half_t* __restrict
                 const float xh = ((float)xv[j] - b[j]) * a[j];
                 float g = (float)gv[j];
                 if (relu && !(xh * ga[j] + be[j] > 0.f)) g = 0.f;
-                ov[j] = (half_t)(k[j] * (g - c0[j] - xh * c1[j]));
+                ov[j] = sat16(k[j] * (g - c0[j] - xh * c1[j]));
             }
         }
         *(h8*)(out + (int64_t)m * C + coff) = ov;
@@ -497,8 +512,8 @@ __global__ __launch_bounds__(256) void bn_stream2_kernel(const half_t* __restric
             const float xh = ((float)xv[j] - b[j]) * a[j];
             const bool on = !relu || (xh * ga[j] + be[j] > 0.f);
             const float g_a = on ? (float)av[j] : 0.f, g_b = on ? (float)bv[j] : 0.f;
-            oa[j] = (half_t)(k[j] * (g_a - a0[j] - xh * a1[j]));
-            ob[j] = (half_t)(k[j] * (g_b - b0[j] - xh * b1[j]));
+            oa[j] = sat16(k[j] * (g_a - a0[j] - xh * a1[j]));
+            ob[j] = sat16(k[j] * (g_b - b0[j] - xh * b1[j]));
         }
         const int64_t o = (int64_t)m * C + coff;
         *(h8*)(out + o) = oa;
@@ -545,7 +560,8 @@ __global__ __launch_bounds__(256) void bn_cols_fwd_kernel(const half_t* __restri
                                                           float* __restrict__ running_var, float* __restrict__ mean_out,
                                                           float* __restrict__ rstd_out, float* __restrict__ scale_out,
                                                           float* __restrict__ shift_out, float* __restrict__ sums,
-                                                          long long* __restrict__ nbt, int relu) {
+                                                          long long* __restrict__ nbt, int relu,
+                                                          const float* __restrict__ in_scale) {
     __shared__ float red[256 * 17];
     __shared__ float par[COLS_CX * 8][2];
     const int cx = threadIdx.x & (COLS_CX - 1), ry = threadIdx.x >> 2;
@@ -573,7 +589,7 @@ __global__ __launch_bounds__(256) void bn_cols_fwd_kernel(const half_t* __restri
             sums[c] = sx;
             sums[C + c] = sxx;
             bn_finalize_channel(c, sx, sxx, count, gamma, beta, eps, momentum, updates, running_mean, running_var, mean_out,
-                                rstd_out, scale_out, shift_out);
+                                rstd_out, scale_out, shift_out, in_scale ? *in_scale : 1.f);
             par[threadIdx.x][0] = scale_out[c];
             par[threadIdx.x][1] = shift_out[c];
         }
@@ -672,7 +688,7 @@ __global__ __launch_bounds__(256) void bn_cols_bwd_kernel(const half_t* __restri
                 const float xh = ((float)xv[j] - mu[j]) * rs[j];
                 float g = (float)gv[j];
                 if (relu && !(xh * ga[j] + be[j] > 0.f)) g = 0.f;
-                ov[j] = (half_t)(ga[j] * rs[j] * (g - c0[j] - xh * c1[j]));
+                ov[j] = sat16(ga[j] * rs[j] * (g - c0[j] - xh * c1[j]));
             }
             *(h8*)(dx + st * sstride + o) = ov;
         }
@@ -767,10 +783,11 @@ int bn_bwd_fold_launch(const float* part, int rows, int rows_cap, int C, int G, 
 }
 int bn_cols_fwd_launch(const half_t* x, half_t* y, int M, int C, float count, const float* gamma, const float* beta,
                        float eps, float momentum, int updates, float* rm, float* rv, float* mean, float* rstd,
-                       float* scale, float* shift, float* sums2C, long long* nbt, int relu, hipStream_t st) {
+                       float* scale, float* shift, float* sums2C, long long* nbt, int relu, const float* in_scale,
+                       hipStream_t st) {
     const int nch = C / 8;
     hipLaunchKernelGGL(bn_cols_fwd_kernel, dim3((nch + COLS_CX - 1) / COLS_CX), dim3(256), 0, st, x, y, M, C, count, gamma,
-                       beta, eps, momentum, updates, rm, rv, mean, rstd, scale, shift, sums2C, nbt, relu);
+                       beta, eps, momentum, updates, rm, rv, mean, rstd, scale, shift, sums2C, nbt, relu, in_scale);
     return LAUNCH_OK();
 }
 int bn_cols_bwd_launch(const half_t* x, const half_t* dy, half_t* dx, int M, int C, int nstreams, float count,
@@ -826,9 +843,9 @@ int bn_bwd_reduce2_launch(const half_t* x, const half_t* dy, int M, int C, const
 }
 int bn_finalize_launch(const float* sums, int C, float count, const float* gamma, const float* beta, float eps,
                        float momentum, int updates, float* rm, float* rv, float* mean, float* rstd, float* scale,
-                       float* shift, long long* nbt, hipStream_t st) {
+                       float* shift, long long* nbt, const float* in_scale, hipStream_t st) {
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, C, count, gamma, beta, eps,
-                       momentum, updates, rm, rv, mean, rstd, scale, shift, nbt);
+                       momentum, updates, rm, rv, mean, rstd, scale, shift, nbt, in_scale);
     return LAUNCH_OK();
 }
 static RowGeom stream_geometry(int M, int C) {

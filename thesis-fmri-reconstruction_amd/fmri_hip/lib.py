@@ -58,6 +58,10 @@ _SIGS = {
     "fmri_bn_finalize": [_p, _i, _f, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p, _p, _p, _p],
     "fmri_bn_stats_finalize": [_p, _i, _i, _p, _p, _l, _f, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p, _p, _p, _p],
     "fmri_bn_cols_fwd": [_p, _p, _i, _i, _f, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p],
+    "fmri_bn_cols_fwd_s": [_p, _p, _i, _i, _f, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p],
+    "fmri_bn_finalize_s": [_p, _i, _f, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "fmri_latent_fwd_ranged": [_p, _p, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _f, _i, _p],
+    "fmri_rows_absmax": [_p, _l, _p, _p],
     "fmri_bn_cols_bwd": [_p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _i, _p, _p, _p, _f, _i, _p],
     "fmri_bn_fold_finalize": [_p, _i, _i, _p, _p, _f, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p, _p, _p, _p],
     "fmri_bn_fold": [_p, _i, _i, _p, _p, _p],
@@ -91,6 +95,8 @@ _SIGS = {
     "fmri_adam_dev": [_p, _p, _p, _p, _l, _p, _f, _f, _f, _p, _f, _p, _f, _p, _p],
     "fmri_sumsq": [_p, _l, _p, _p],
     "fmri_renorm": [_p, _p, _l, _f, _p, _f, _p, _p, _p],
+    "fmri_sumsq_f64": [_p, _l, _p, _i, _p],
+    "fmri_renorm_f64": [_p, _p, _l, _f, _p, _f, _p, _p, _p],
     "fmri_rmsprop": [_p, _p, _p, _l, _f, _f, _f, _f, _p, _f, _p, _p],
     "fmri_adam": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _f, _f, _p, _f, _p, _p],
 }

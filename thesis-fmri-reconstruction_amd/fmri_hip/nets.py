@@ -274,10 +274,12 @@ class DecoderNet:
         return [self.fc_bn] + self.bns
 
     def forward(self, z16: torch.Tensor, groups: int, out: Optional[torch.Tensor] = None, train_stats: bool = True,
-                stat_order=None):
+                stat_order=None, zscale: Optional[torch.Tensor] = None):
         """z16 [G*B, zp]: G independent decoder calls (own BN batch statistics each, reference
         models/vae_gan.py:279,282) executed as one batch.  ``stat_order`` = order in which the groups'
-        running-stat updates are applied (the reference's call order).  Returns (images fp16 [G*B,H,W,8], ctx)."""
+        running-stat updates are applied (the reference's call order).  ``zscale`` (device fp32 [>= G]): group g's rows
+        hold zscale[g] * z (``ops.latent_ranged``: a latent whose sigma left fp16's range); None = all 1.
+        Returns (images fp16 [G*B,H,W,8], ctx)."""
         GB = z16.shape[0]
         B = GB // groups
         f = self.cfg.fc_input
@@ -287,7 +289,8 @@ class DecoderNet:
         act_fc = torch.empty_like(raw_fc)
         grows = lambda t: [t[gi * B:(gi + 1) * B] for gi in range(groups)]
         # the call groups of one layer are ready together: with SyncBN their statistics travel in ONE all-reduce
-        sv_fc = self.fc_bn.forward_groups(grows(raw_fc), True, upd, grows(act_fc), [None] * groups, order)
+        ins = None if zscale is None else [zscale[gi:gi + 1] for gi in range(groups)]
+        sv_fc = self.fc_bn.forward_groups(grows(raw_fc), True, upd, grows(act_fc), [None] * groups, order, in_scales=ins)
         h = act_fc.reshape(GB, f, f, self.size0)
         acts, raws, svs = [h], [], []
         for dc, bn in zip(self.deconvs, self.bns):
@@ -308,7 +311,8 @@ class DecoderNet:
             acts.append(act)
             h = act
         y = self.c3.forward(h, ACT_TANH, out=out)
-        return y, dict(z=z16, raw_fc=raw_fc, sv_fc=sv_fc, acts=acts, raws=raws, svs=svs, y=y, B=B, groups=groups)
+        return y, dict(z=z16, raw_fc=raw_fc, sv_fc=sv_fc, acts=acts, raws=raws, svs=svs, y=y, B=B, groups=groups,
+                       zscale=zscale)
 
     def backward(self, *args, join: bool = True, **kwargs):
         """``_backward`` + join of the side stream its weight gradients were issued on (ops.side_run).  ``join=False``
@@ -409,6 +413,9 @@ class DecoderNet:
             if en.get("need_dz"):
                 _, dz32 = self.fc.dgrad(rows(draw_fc, e).contiguous(), want32=True)
                 out[e] = dz32 * (1.0 / en["scale"])
+                if ctx.get("zscale") is not None:
+                    # the group's rows were stored as s * z: d/dz = s * d/d(stored rows)
+                    out[e] *= ctx["zscale"][en["g"]:en["g"] + 1]
         return out
 
 

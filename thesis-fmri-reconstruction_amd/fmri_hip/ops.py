@@ -1062,15 +1062,17 @@ class BatchNorm:
             lib.call("fmri_permute_chw", _P(self.rv_e), _P(self.rv), c0, hw, 0, 1.0, 0)
             self._run_dirty = False
 
-    def forward_groups(self, raws, relu: bool, updates: int, outs, stat_accs, order):
+    def forward_groups(self, raws, relu: bool, updates: int, outs, stat_accs, order, in_scales=None):
         """Train-mode forward of several calls of this BatchNorm whose inputs are ready together (the decoder's call groups
         of one layer), running-statistics updates in ``order``.  Data parallel with SyncBN: the statistics of all calls are
-        exchanged in ONE all-reduce ([G][2][C]) instead of one per call.  Returns the BNSaved of each call."""
+        exchanged in ONE all-reduce ([G][2][C]) instead of one per call.  ``in_scales``: per call, the device scalar its
+        rows are stored range-scaled by (``forward``), or None.  Returns the BNSaved of each call."""
         G = len(raws)
         svs = [None] * G
+        ins = in_scales if in_scales is not None else [None] * G
         if self.reducer is None or self.eval_mode:
             for gi in order:
-                _, svs[gi] = self.forward(raws[gi], relu, updates, out=outs[gi], stat_acc=stat_accs[gi])
+                _, svs[gi] = self.forward(raws[gi], relu, updates, out=outs[gi], stat_acc=stat_accs[gi], in_scale=ins[gi])
             return svs
         C = self.C
         sums_all = torch.empty(G, 2, C, dtype=torch.float32, device=raws[0].device)
@@ -1078,7 +1080,8 @@ class BatchNorm:
             self._forward_sums(raws[gi], stat_accs[gi], sums_all[gi])
         world = self.reducer(sums_all)
         for gi in order:
-            _, svs[gi] = self.forward(raws[gi], relu, updates, out=outs[gi], exchanged=(sums_all[gi], world))
+            _, svs[gi] = self.forward(raws[gi], relu, updates, out=outs[gi], exchanged=(sums_all[gi], world),
+                                      in_scale=ins[gi])
         return svs
 
     def _forward_sums(self, raw: torch.Tensor, stat_acc, sums: torch.Tensor):
@@ -1095,12 +1098,14 @@ class BatchNorm:
             lib.call("fmri_bn_stats", _P(x2), M, C, _P(sums), _P(ws), ws.numel())
 
     def forward(self, raw: torch.Tensor, relu: bool = True, updates: int = 1, out: Optional[torch.Tensor] = None,
-                stat_acc: Optional[torch.Tensor] = None, exchanged=None):
+                stat_acc: Optional[torch.Tensor] = None, exchanged=None, in_scale: Optional[torch.Tensor] = None):
         """``stat_acc``: the batch statistics of ``raw`` as rows [P][2][C] written by the producing kernel's epilogue
         (``ConvLayer.take_stats``): the statistics pass over ``raw`` is skipped.  ``exchanged`` = (sums [2][C] already
-        summed over the ranks, world size): ``forward_groups``' second phase."""
+        summed over the ranks, world size): ``forward_groups``' second phase.  ``in_scale`` (device fp32 scalar s, a power
+        of two): ``raw`` holds s * x (a latent batch stored range-scaled, ``latent_ranged``) -- the result is BatchNorm(x),
+        the saved statistics are those of the stored rows, the running statistics the true-scale ones."""
         if self.eval_mode:
-            return self.forward_eval(raw, relu, out), None
+            return self.forward_eval(raw, relu, out, in_scale=in_scale), None
         C = self.C
         x2 = raw.reshape(-1, C)
         M = x2.shape[0]
@@ -1122,16 +1127,25 @@ class BatchNorm:
             if out is None:
                 out = torch.empty_like(raw)
             lib.note(bytes=6.0 * M * C)
-            lib.call("fmri_bn_cols_fwd", _P(x2), _P(out), M, C, count, _P(gamma), _P(beta), 1e-5, 0.9, updates,
+            lib.call("fmri_bn_cols_fwd_s", _P(x2), _P(out), M, C, count, _P(gamma), _P(beta), 1e-5, 0.9, updates,
                      _P(rm) if updates > 0 else None, _P(rv) if updates > 0 else None, _P(sv.mean), _P(sv.rstd),
-                     _P(sv.scale), _P(sv.shift), _P(sums), _P(self.nbt) if updates > 0 else None, 1 if relu else 0)
+                     _P(sv.scale), _P(sv.shift), _P(sums), _P(self.nbt) if updates > 0 else None, 1 if relu else 0,
+                     _P(in_scale))
             sv.count, sv.sums = count, sums
             if updates > 0:
                 self._running_out()
             return out, sv
         if exchanged is not None:
             count *= exchanged[1]
-            lib.call("fmri_bn_finalize", _P(sums), C, count, *fin)
+            lib.call("fmri_bn_finalize_s", _P(sums), C, count, *fin, _P(in_scale))
+        elif in_scale is not None:
+            # (many rows of a range-scaled input: statistics, exchange, finalize with the input scale)
+            assert stat_acc is None
+            lib.note(bytes=2.0 * M * C)
+            lib.call("fmri_bn_stats", _P(x2), M, C, _P(sums), _P(ws), ws.numel())
+            if self.reducer is not None:
+                count *= self.reducer(sums)
+            lib.call("fmri_bn_finalize_s", _P(sums), C, count, *fin, _P(in_scale))
         elif stat_acc is not None:
             assert stat_acc.shape[-1] == C and stat_acc.is_contiguous()
             rows = stat_acc.shape[0]
@@ -1187,14 +1201,18 @@ class BatchNorm:
             shift = torch.nn.functional.pad(shift, (0, pad))
         return scale, shift, relu
 
-    def forward_eval(self, raw: torch.Tensor, relu: bool = True, out: Optional[torch.Tensor] = None):
-        """Eval-mode BN (running statistics, models/vae_gan.py:288-297 path): y = relu(gamma*(x-rm)/sqrt(rv+eps)+beta)."""
+    def forward_eval(self, raw: torch.Tensor, relu: bool = True, out: Optional[torch.Tensor] = None,
+                     in_scale: Optional[torch.Tensor] = None):
+        """Eval-mode BN (running statistics, models/vae_gan.py:288-297 path): y = relu(gamma*(x-rm)/sqrt(rv+eps)+beta).
+        ``in_scale``: ``raw`` holds s * x (see ``forward``)."""
         C = self.C
         x2 = raw.reshape(-1, C)
         gamma, beta, rm, rv = self._params()
         self._running_in()
         scale = gamma * torch.rsqrt(rv + 1e-5)
         shift = beta - rm * scale
+        if in_scale is not None:
+            scale = scale / in_scale
         if out is None:
             out = torch.empty_like(raw)
         lib.call("fmri_bn_apply", _P(x2), _P(out), x2.shape[0], C, _P(scale), _P(shift), 1 if relu else 0)
@@ -1356,6 +1374,48 @@ def rows_to_f16(x: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
     out = torch.empty(M, pad8(Cc), dtype=torch.float16, device=x.device)
     lib.call("fmri_rows_f32_to_f16", _P(x), _P(out), M, Cc, pad8(Cc), float(scale))
     return out
+
+
+# largest |z| a latent batch is stored with at scale 1 (``latent_ranged``): above it the fp16 rows carry 2^-k * z
+LATENT_CAP = 256.0
+
+
+def latent_ranged(head32: Optional[torch.Tensor], eps: Optional[torch.Tensor], rows: int, Z: int, z16: torch.Tensor,
+                  zmax: torch.Tensor, zscale: torch.Tensor, kl_total: Optional[torch.Tensor] = None, sample: bool = True,
+                  z32: Optional[torch.Tensor] = None, max_reduce=None):
+    """Range-safe reparameterisation (fmri_latent_fwd_ranged): z = eps * exp(0.5 logvar) + mu (or mu) in fp32, then
+    ``z16`` [rows, zp] = fp16(s * z) with s = the largest power of two <= 1 that brings max |z| of the batch under
+    LATENT_CAP, written to the device scalar ``zscale`` -- the ``zscale`` argument of ``DecoderNet.forward``.  ``zmax``:
+    device scalar, zero on entry.  ``head32`` None: ``z32`` is a caller-provided fp32 latent [rows, Z].  ``max_reduce``
+    (data parallel with SyncBN: the decoder's batch is the global one): callable all-reducing ``zmax`` with MAX."""
+    zp = z16.shape[1]
+    if head32 is not None:
+        if z32 is None:
+            z32 = torch.empty(rows, Z, dtype=torch.float32, device=z16.device)
+        phase = 3 if max_reduce is None else 1
+        lib.call("fmri_latent_fwd_ranged", _P(head32), _P(eps), rows, Z, zp, _P(z16), None, _P(kl_total),
+                 1 if sample else 0, _P(z32), _P(zmax), _P(zscale), LATENT_CAP, phase)
+        if max_reduce is None:
+            return z32
+    else:
+        lib.call("fmri_rows_absmax", _P(z32), rows * Z, _P(zmax))
+    if max_reduce is not None:
+        max_reduce(zmax)
+    lib.call("fmri_latent_fwd_ranged", None, None, rows, Z, zp, _P(z16), None, None, 0, _P(z32), _P(zmax), _P(zscale),
+             LATENT_CAP, 2)
+    return z32
+
+
+def rows_to_f16_ranged(z: torch.Tensor):
+    """fp32 latent rows [M, Z] -> (fp16 [M, pad8(Z)] stored at scale s, s as a device scalar) -- ``rows_to_f16`` for a
+    latent of unknown range (the module API's ``Decoder(z)``)."""
+    require_gpu(z)
+    M, Z = z.shape
+    z = z.contiguous().float()
+    z16 = torch.empty(M, pad8(Z), dtype=torch.float16, device=z.device)
+    st = torch.zeros(2, dtype=torch.float32, device=z.device)
+    latent_ranged(None, None, M, Z, z16, st[0:1], st[1:2], z32=z)
+    return z16, st[1:2]
 
 
 def _reduce_ws(M: int, C: int, device) -> torch.Tensor:

@@ -34,6 +34,7 @@ _P = lib.ptr
 # slots of the fp32 scalar block (csrc/loss.hip enum Slot)
 (S_BCE_O, S_BCE_P, S_BCE_S, S_KL, S_MSE, S_NLE, S_LENC, S_LDIS, S_LDEC, S_DL2, S_NA, S_NB, S_RATIO,
  S_ONE, S_ESQ, S_NE, S_NP, S_C1, S_C2, S_C3, S_GDEC, S_KLW) = range(22)
+S_ZMAX = 22         # slots [22, 26): max |z| of the latent batch of decoder group 0..3 (ops.latent_ranged; zero at step start)
 # loss compositions of train/train_vgan_stage1.py:359-388 (csrc/loss.hip enum Mode)
 MODES = {"vae-gan": 0, "beta-vae": 1, "dcgan": 2, "vae": 3}
 N_REDUCED = 10      # slots [0, N_REDUCED) are sums over the batch -> all-reduced in data-parallel runs
@@ -189,6 +190,16 @@ class _Dist:
         else:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=grp)
 
+    def all_reduce_max(self, t: torch.Tensor):
+        """Blocking MAX all-reduce of a few scalars on the current stream (the latent range of a SyncBN step)."""
+        if not self.on:
+            return
+        fn = lambda: self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.small)
+        if self.recorder is not None:
+            self.recorder.collective(fn)
+        else:
+            fn()
+
     def all_reduce_async(self, t: torch.Tensor):
         """Start a SUM all-reduce (same communicator, so it queues behind / ahead of the blocking ones in program
         order on every rank) and return immediately; `wait_all` joins it with the compute stream."""
@@ -247,6 +258,10 @@ class _GanStepBase:
         self.hp_dev = torch.tensor([self.hp.lambda_mse, self.hp.equilibrium, self.hp.margin, self.hp.beta],
                                    dtype=torch.float32, device=device)
         self.flags = torch.zeros(2, dtype=torch.int32, device=device)
+        # per decoder call group: the power of two its latent rows are stored scaled by (ops.latent_ranged); the groups
+        # fed with caller noise keep 1
+        self.zs = torch.ones(4, dtype=torch.float32, device=device)
+        self.esq64 = torch.zeros(1, dtype=torch.float64, device=device)      # sum of squares of _renorm
         self.dd = _Dist(distributed, sync_bn)
         _attach_reducers(nets, self.dd)
         self.fw: Dict[str, object] = {}
@@ -261,6 +276,15 @@ class _GanStepBase:
 
     def _slot(self, i):
         return self.scal[i:i + 1]
+
+    def _latent(self, head32, eps, z16_rows, group: int, kl_slot: Optional[int]):
+        """z = eps * sigma + mu of decoder call group ``group`` into ``z16_rows``, range-safe (ops.latent_ranged): the
+        rows are stored at the power-of-two scale self.zs[group]; with SyncBN the decoder's batch is the global one, so
+        the range is the global maximum."""
+        B, Z = head32.shape[0], head32.shape[1] // 2
+        ops.latent_ranged(head32, eps, B, Z, z16_rows, self._slot(S_ZMAX + group), self.zs[group:group + 1],
+                          kl_total=None if kl_slot is None else self._slot(kl_slot), sample=True,
+                          max_reduce=self.dd.all_reduce_max if (self.dd.on and self.dd.sync_bn) else None)
 
     def set_hyper(self, lr: Optional[float] = None, lambda_mse: Optional[float] = None,
                   equilibrium: Optional[float] = None, margin: Optional[float] = None, beta: Optional[float] = None):
@@ -318,12 +342,14 @@ class _GanStepBase:
         """fp32 cotangent -> unit-RMS fp16 (times ``scale``); S_NE <- (*factor_in) / rms.  The sum of squares is
         all-reduced so that every data-parallel rank applies the same factor."""
         n = x32.numel()
-        # (slot S_ESQ is zero here: the gate kernel, which every step runs between forward and backward, clears it)
-        lib.call("fmri_sumsq", _P(x32), n, _P(self._slot(S_ESQ)))
-        self.dd.all_reduce(self._slot(S_ESQ))
+        # the sum of squares in double precision (the KL term's 0.5 * (exp(logvar) - 1), squared, leaves fp32 at
+        # logvar > 44), cleared by the launch itself: a second backward() after one gate() starts from zero as well
+        esq = self.esq64
+        lib.call("fmri_sumsq_f64", _P(x32), n, _P(esq), 1)
+        self.dd.all_reduce(esq)
         out = torch.empty(x32.shape, dtype=torch.float16, device=x32.device)
         count = float(rows_global) * (n // x32.shape[0])
-        lib.call("fmri_renorm", _P(x32), _P(out), n, float(scale), _P(self._slot(S_ESQ)), count, _P(factor_in),
+        lib.call("fmri_renorm_f64", _P(x32), _P(out), n, float(scale), _P(esq), count, _P(factor_in),
                  _P(self._slot(S_NE)))
         return out
 
@@ -467,11 +493,11 @@ class Stage1Step(_GanStepBase):
         head32, ectx = self.enc.forward(disc_in[:B], updates=self.enc_updates)
         z16 = torch.empty(G * B, zp, dtype=torch.float16, device=dev)
         eps = eps.contiguous().float()
-        lib.call("fmri_latent_fwd", _P(head32), _P(eps), B, Z, zp, _P(z16), None, _P(self._slot(S_KL)), 1)
+        self._latent(head32, eps, z16[:B], 0, S_KL)
         lib.call("fmri_rows_f32_to_f16", _P(z_p.contiguous().float()), _P(z16[B:]), B, Z, zp, 1.0)
         if G == 3:
             lib.call("fmri_latent_fwd", _P(head32), None, B, Z, zp, _P(z16[2 * B:]), None, None, 0)
-        _, dctx = self.dec.forward(z16, G, out=dec_out[B:])
+        _, dctx = self.dec.forward(z16, G, out=dec_out[B:], zscale=self.zs)
         feat, logit32, sctx = self.dis.forward(disc_in)
         prob, F = self._gan_losses(feat, logit32, B, disc_in[:B], disc_in[B:2 * B], H, W)
         self.fw = dict(B=B, H=H, W=W, F=F, disc_in=disc_in, head32=head32, eps=eps, ectx=ectx, dctx=dctx, sctx=sctx,
@@ -804,20 +830,18 @@ class CognitiveStep(_GanStepBase):
             z16 = torch.empty(3 * B, zp, dtype=torch.float16, device=dev)
             img16 = images_to_nhwc(image)
             head_t, _ = self.teacher_enc.forward(img16)
-            lib.call("fmri_latent_fwd", _P(head_t), _P(eps_teacher.contiguous().float()), B, Z, zp, _P(z16[:B]), None,
-                     None, 1)
-            lib.call("fmri_latent_fwd", _P(head32), _P(eps), B, Z, zp, _P(z16[B:2 * B]), None,
-                     _P(self._slot(S_KL)), 1)
+            self._latent(head_t, eps_teacher.contiguous().float(), z16[:B], 0, None)
+            self._latent(head32, eps, z16[B:2 * B], 1, S_KL)
             lib.call("fmri_rows_f32_to_f16", _P(z_p.contiguous().float()), _P(z16[2 * B:]), B, Z, zp, 1.0)
             # reference call order of the decoder: x_tilde, teacher reconstruction, x_p (vae_gan.py:365,377,390)
-            _, dctx = self.dec.forward(z16, 3, out=disc_in, stat_order=(1, 0, 2))
+            _, dctx = self.dec.forward(z16, 3, out=disc_in, stat_order=(1, 0, 2), zscale=self.zs)
             g_tilde, g_p = 1, 2
         else:
             z16 = torch.empty(2 * B, zp, dtype=torch.float16, device=dev)
             images_to_nhwc(image, out=disc_in[:B])
-            lib.call("fmri_latent_fwd", _P(head32), _P(eps), B, Z, zp, _P(z16[:B]), None, _P(self._slot(S_KL)), 1)
+            self._latent(head32, eps, z16[:B], 0, S_KL)
             lib.call("fmri_rows_f32_to_f16", _P(z_p.contiguous().float()), _P(z16[B:]), B, Z, zp, 1.0)
-            _, dctx = self.dec.forward(z16, 2, out=disc_in[B:])
+            _, dctx = self.dec.forward(z16, 2, out=disc_in[B:], zscale=self.zs)
             g_tilde, g_p = 0, 1
         feat, logit32, sctx = self.dis.forward(disc_in)
         prob, F = self._gan_losses(feat, logit32, B, disc_in[:B], disc_in[B:2 * B], H, W)

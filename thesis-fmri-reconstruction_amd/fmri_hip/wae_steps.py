@@ -221,12 +221,14 @@ class WaeStep(_LatentDiscPhase):
 
     def _renorm(self, x32: torch.Tensor, scale: float, rows_global: int):
         n = x32.numel()
-        esq, ne = self.scal[S_ESQ:S_ESQ + 1], self.scal[S_NE:S_NE + 1]
-        esq.zero_()
-        lib.call("fmri_sumsq", _P(x32), n, _P(esq))
+        ne = self.scal[S_NE:S_NE + 1]
+        esq = self.__dict__.get("esq64")
+        if esq is None:
+            esq = self.esq64 = torch.zeros(1, dtype=torch.float64, device=x32.device)
+        lib.call("fmri_sumsq_f64", _P(x32), n, _P(esq), 1)
         self.dd.all_reduce(esq)
         out = torch.empty(x32.shape, dtype=torch.float16, device=x32.device)
-        lib.call("fmri_renorm", _P(x32), _P(out), n, float(scale), _P(esq), float(rows_global) * (n // x32.shape[0]),
+        lib.call("fmri_renorm_f64", _P(x32), _P(out), n, float(scale), _P(esq), float(rows_global) * (n // x32.shape[0]),
                  None, _P(ne))
         return out
 

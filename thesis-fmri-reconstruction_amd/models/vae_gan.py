@@ -162,7 +162,9 @@ class _DecoderFn(Function):
     @staticmethod
     def forward(ctx, mod, z, *params):
         net = mod._engine()
-        y16, dctx = net.forward(_ops.rows_to_f16(z), 1)
+        # (a sampled latent can leave fp16's range -- sigma = exp(0.5 logvar) -- so its rows are stored range-scaled)
+        z16, zs = _ops.rows_to_f16_ranged(z)
+        y16, dctx = net.forward(z16, 1, zscale=zs)
         ctx.net, ctx.dctx, ctx.params, ctx.zdim = net, dctx, params, z.shape[1]
         ctx.need_dz = z.requires_grad
         return _ops.nhwc_to_images(y16, net.c3.cout)

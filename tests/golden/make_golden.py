@@ -67,7 +67,7 @@ def load_reference(cfg: O.ArchCfg):
 
 def summarize_state(sd):
     keys = list(sd.keys())
-    return keys, np.stack([O.tensor_summary(sd[k].float() if sd[k].dtype != torch.float32 else sd[k]) for k in keys])
+    return keys, np.stack([O.tensor_summary(sd[k] if sd[k].is_floating_point() else sd[k].float()) for k in keys])
 
 
 def grads_of(params_named):
@@ -715,7 +715,8 @@ def case_recon(name, cfg, B, seed):
     level 0 raises and level 4 returns None."""
     vg = load_reference(cfg)
     rs = np.random.RandomState(1000 + seed)
-    xs = [torch.from_numpy(rs.uniform(-1, 1, (B, 3, cfg.image_size, cfg.image_size)).astype(np.float32)) for _ in range(3)]
+    xs = [torch.from_numpy(rs.uniform(-1, 1, (B, 3, cfg.image_size, cfg.image_size)).astype(np.float32))
+          .to(torch.get_default_dtype()) for _ in range(3)]
     out = {"meta/case": np.array("recon"), "meta/B": B, "meta/seed": seed, "meta/image_size": cfg.image_size}
     for level in (1, 2):
         dis = vg.Discriminator(channel_in=3, recon_level=level)
@@ -723,7 +724,8 @@ def case_recon(name, cfg, B, seed):
         dis.train()
         xp = xs[1].clone().requires_grad_(True)
         feat = dis(xs[0], xp, xs[2], "REC")
-        w = torch.from_numpy(np.random.RandomState(2000 + level).standard_normal(tuple(feat.shape)).astype(np.float32))
+        w = torch.from_numpy(np.random.RandomState(2000 + level).standard_normal(tuple(feat.shape)).astype(np.float32)) \
+            .to(torch.get_default_dtype())
         (feat * w).sum().backward()
         tag = f"level{level}"
         out[f"{tag}/shape"] = np.array(feat.shape)
@@ -833,7 +835,24 @@ def case_ingest(name):
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["all"]
+    which = [a for a in sys.argv[1:] if not a.startswith("--")] or ["all"]
+    # --f64: the same cases with the reference modules, the recipe weights and the inputs in DOUBLE precision, written as
+    # <case>_f64.npz.  Two fp32 runs of the same arithmetic differ by ~1e-3 in some gradient norms with the host's thread
+    # count alone (reduction order of the CPU convolutions); two float64 runs agree to ~1e-12, so these fixtures pin the
+    # oracle's RESTATEMENT of the reference exactly, on any host (tests/test_oracle_golden.py).
+    F64 = "--f64" in sys.argv[1:]
+    if F64:
+        torch.set_default_dtype(torch.float64)
+        _fill, _synth = O.fill_state, O.synth_batch
+        dbl = lambda d: {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in d.items()}
+        O.fill_state = lambda *a, **k: dbl(_fill(*a, **k))
+        O.synth_batch = lambda *a, **k: dbl(_synth(*a, **k))
+        _savez = np.savez_compressed
+
+        def savez_f64(path, **out):
+            assert path.endswith(".npz")
+            return _savez(path[:-4] + "_f64.npz", **out)
+        np.savez_compressed = savez_f64
 
     def want(n):
         return "all" in which or n in which

@@ -11,41 +11,98 @@ import torch
 
 from oracle import vaegan_oracle as O
 
-LOG_RTOL = 2e-5      # logged scalar losses: same fp32 torch kernels on both sides
-SUM_RTOL = 2e-4      # tensor fingerprints (norm / sum / head / tail)
+# Every test below runs twice (fixture ``precision``).
+#
+#   f64  the oracle in DOUBLE precision against <case>_f64.npz, which make_golden.py --f64 wrote by running the reference
+#        modules in double on the same recipe weights and inputs: two float64 runs of the same arithmetic agree to ~1e-12
+#        whatever the host's thread count, so 1e-9 pins the RESTATEMENT -- every formula, order of operations, optimizer
+#        and BatchNorm detail -- exactly, on any host.
+#   f32  the oracle as everything else uses it (fp32) against the fp32 fixtures.  Two fp32 runs of the same torch-CPU
+#        arithmetic differ with the number of threads alone (reduction order of the convolutions): measured over 1 / 2 /
+#        8 / 16 threads up to 1.1e-2 on a gradient norm, 1.4e-3 on a post-update weight fingerprint, < 1e-5 on the logged
+#        losses of the first step and 1.4e-4 on those of the second (profiles/r05_oracle_threads.log).  And the
+#        ELEMENTS of a post-update tensor are not a continuous function of the gradient at all: the first RMSprop / Adam
+#        step moves every weight by +-lr * 3.16 (RMSprop) or +-lr (Adam) according to the SIGN of its gradient, so a
+#        gradient element at rounding level lands on either side (seen: 630 of 16.7 M weights of encoder.fc.0, bias entries
+#        of +-1e-4).  The fp32 pass therefore checks the logged losses, the forward tensors' fingerprints and the L2 NORMS
+#        of gradients and post-update tensors at that noise floor (with a margin); the exact pin -- every element -- is the
+#        f64 pass.
+TOL = {"f64": dict(log=1e-9, summ=1e-9, grad=1e-8, norm_only=False),
+       "f32": dict(log=1e-4, summ=5e-3, grad=5e-2, norm_only=True)}
+_MODE = {"p": "f32"}
+
+
+@pytest.fixture(autouse=True, params=["f64", "f32"])
+def precision(request, monkeypatch):
+    _MODE["p"] = request.param
+    if request.param == "f64":
+        was = torch.get_default_dtype()
+        torch.set_default_dtype(torch.float64)
+        fill, synth = O.fill_state, O.synth_batch
+        dbl = lambda d: {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in d.items()}
+        monkeypatch.setattr(O, "fill_state", lambda *a, **k: dbl(fill(*a, **k)))
+        monkeypatch.setattr(O, "synth_batch", lambda *a, **k: dbl(synth(*a, **k)))
+        yield request.param
+        torch.set_default_dtype(was)
+    else:
+        yield request.param
+    _MODE["p"] = "f32"
+
+
+def _tol(kind):
+    return TOL[_MODE["p"]][kind]
+
+
+def _real(a):
+    """numpy float32 array -> tensor of the pass's precision."""
+    return torch.from_numpy(np.ascontiguousarray(a)).to(torch.get_default_dtype())
 
 
 def _load(golden_dir, name):
-    return np.load(os.path.join(golden_dir, name + ".npz"), allow_pickle=False)
+    return np.load(os.path.join(golden_dir, name + ("_f64" if _MODE["p"] == "f64" else "") + ".npz"), allow_pickle=False)
 
 
 def _check_logs(g, tag, logs):
     for k, v in logs.items():
         ref = float(g[f"{tag}/logs/{k}"])
-        assert float(v) == pytest.approx(ref, rel=LOG_RTOL, abs=1e-6), (tag, k, v, ref)
+        # fp32 pass: the thread-count noise grows with every update behind the logged forward (measured 1e-5, 1.4e-4,
+        # 2.2e-3 at steps 0, 1, 2 of the fixtures)
+        step = int(tag[4:]) if tag.startswith("step") and tag[4:].isdigit() else 0
+        rel = _tol("log") * (10.0 ** step if _MODE["p"] == "f32" else 1.0)
+        assert float(v) == pytest.approx(ref, rel=rel, abs=1e-2 * rel), (tag, k, v, ref)
 
 
-def _check_summ(ref, got, what, rtol=SUM_RTOL):
+def _check_summ(ref, got, what, rtol=None, norm_only=False):
+    rtol = _tol("summ") if rtol is None else rtol
     scale = max(abs(ref[0]), 1e-12)  # tensor L2 norm
     np.testing.assert_allclose(got[0], ref[0], rtol=rtol, err_msg=f"{what} norm")
+    if norm_only:
+        return
     # sum / elements: absolute tolerance relative to the tensor's norm
     np.testing.assert_allclose(got[1:], ref[1:], rtol=rtol, atol=rtol * scale, err_msg=what)
+
+
+def _step_factor(tag):
+    """fp32 pass: growth of the thread-count noise with the number of updates behind a step (see _check_logs)."""
+    step = int(tag[4:]) if tag.startswith("step") and tag[4:].isdigit() else 0
+    return 10.0 ** step if _MODE["p"] == "f32" else 1.0
 
 
 def _check_step(g, tag, out, P):
     _check_logs(g, tag, out["logs"])
     for k, v in out["fw"].items():
-        _check_summ(g[f"{tag}/fw/{k}"], O.tensor_summary(v), f"{tag} fw {k}")
+        _check_summ(g[f"{tag}/fw/{k}"], O.tensor_summary(v), f"{tag} fw {k}", rtol=_tol("summ") * _step_factor(tag))
     gkeys = [str(k) for k in g[f"{tag}/grad_keys"]]
     gs = g[f"{tag}/grad_sum"]
     for i, k in enumerate(gkeys):
         if k in out["grads"] and out["grads"][k] is not None:
-            _check_summ(gs[i], O.tensor_summary(out["grads"][k]), f"{tag} grad {k}", rtol=1e-3)
+            _check_summ(gs[i], O.tensor_summary(out["grads"][k]), f"{tag} grad {k}",
+                        rtol=min(_tol("grad") * _step_factor(tag), 0.5), norm_only=_tol("norm_only"))
     skeys = [str(k) for k in g[f"{tag}/state_keys"]]
     ss = g[f"{tag}/state_sum"]
     for i, k in enumerate(skeys):
         assert k in P, k
-        _check_summ(ss[i], O.tensor_summary(P[k].float()), f"{tag} state {k}")
+        _check_summ(ss[i], O.tensor_summary(P[k].double()), f"{tag} state {k}", norm_only=_tol("norm_only"))
 
 
 def _rms_opts(*names):
@@ -216,9 +273,9 @@ def eval_state(cfg, seed):
     rs = np.random.RandomState(seed + 1000)
     for k in sd:
         if k.endswith("running_mean"):
-            sd[k] = torch.from_numpy(rs.uniform(-0.2, 0.2, tuple(sd[k].shape)).astype(np.float32))
+            sd[k] = _real(rs.uniform(-0.2, 0.2, tuple(sd[k].shape)).astype(np.float32))
         elif k.endswith("running_var"):
-            sd[k] = torch.from_numpy(rs.uniform(0.5, 1.5, tuple(sd[k].shape)).astype(np.float32))
+            sd[k] = _real(rs.uniform(0.5, 1.5, tuple(sd[k].shape)).astype(np.float32))
     return sd
 
 
@@ -246,7 +303,9 @@ def surface_states(cfg, V, seed):
     for k, v in tsd.items():
         cog["teacher_net." + k] = cog[k] if k.startswith(("decoder.", "discriminator.")) else v
     wsd = O.fill_state(O.encoder_spec(cfg) + O.decoder_spec(cfg) + O.wae_discriminator_spec(cfg), seed, True)
-    wae = dict(csd)
+    # (own copies: the train-mode forward on ``cog`` updates its BatchNorm buffers in place -- shared tensors would hand
+    # the WAE wrapper an encoder with moved running statistics; found by the float64 pass, a 1e-5 effect)
+    wae = {k: v.clone() for k, v in csd.items()}
     wae.update({k: v for k, v in wsd.items() if k.startswith("decoder.")})
     wae.update(O.fill_state(O.wae_discriminator_spec(cfg), seed + 200, True))
     dcg = {k: v.clone() for k, v in tsd.items() if k.startswith(("decoder.", "discriminator."))}
@@ -267,7 +326,7 @@ def test_wrapper_forwards_match_reference(golden_dir):
         _check_summ(g[f"cogwae/{k}"], O.tensor_summary(v), f"cogwae {k}")
     keys = [str(k) for k in g["cogwae/state_keys"]]
     for i, k in enumerate(keys):
-        _check_summ(g["cogwae/state_sum"][i], O.tensor_summary(cog[k].float()), f"cogwae state {k}")
+        _check_summ(g["cogwae/state_sum"][i], O.tensor_summary(cog[k].double()), f"cogwae state {k}")
     _check_summ(g["waecog/x_tilde"], O.tensor_summary(O.wae_cognitive_eval(wae, data["fmri"], cfg)), "waecog eval")
     spec_keys = lambda spec: [k for k, _, _ in spec]
     assert [str(k) for k in g["waecog/state_keys"]] == spec_keys(O.cognitive_encoder_spec(cfg, V)) + \
@@ -297,15 +356,15 @@ def test_discriminator_recon_levels_match_reference(golden_dir):
     B, seed = int(g["meta/B"]), int(g["meta/seed"])
     assert str(g["level0/raises"]) == "TypeError" and bool(g["level4/is_none"])
     rs = np.random.RandomState(1000 + seed)
-    xs = [torch.from_numpy(rs.uniform(-1, 1, (B, 3, cfg.image_size, cfg.image_size)).astype(np.float32)) for _ in range(3)]
+    xs = [_real(rs.uniform(-1, 1, (B, 3, cfg.image_size, cfg.image_size)).astype(np.float32)) for _ in range(3)]
     for level in (1, 2):
         tag = f"level{level}"
-        P = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and "running" not in k else v.clone())
+        P = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
              for k, v in O.fill_state(O.discriminator_spec(cfg, ""), seed, True).items()}
         xp = xs[1].clone().requires_grad_(True)
         feat = O.discriminator_fwd(P, "", xs[0], xp, xs[2], "REC", cfg, True, recon_level=level)
         assert list(feat.shape) == [int(v) for v in g[f"{tag}/shape"]]
-        w = torch.from_numpy(np.random.RandomState(2000 + level).standard_normal(tuple(feat.shape)).astype(np.float32))
+        w = _real(np.random.RandomState(2000 + level).standard_normal(tuple(feat.shape)).astype(np.float32))
         (feat * w).sum().backward()
         _check_summ(g[f"{tag}/feat"], O.tensor_summary(feat.detach()), f"{tag} feat")
         _check_summ(g[f"{tag}/dxp"], O.tensor_summary(xp.grad), f"{tag} dxp")

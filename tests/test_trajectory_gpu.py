@@ -135,12 +135,25 @@ def test_stage1_b32_free_running_next_to_the_oracle():
               + f"   kl {got['kl']:.1f}/{ref['kl']:.1f} bce_pred {got['bce_pred']:.2f}/{ref['bce_pred']:.2f}")
     first_gate_split = next((i for i, same, *_ in rows if not same), steps)
     # Envelope.  Step 0 is the one-step parity (tests/test_stage1_gpu.py: 1e-3).  From there two arithmetic models of the
-    # same GAN drift apart at the rate the dynamics amplify a 16-bit rounding -- measured tables in DESIGN 8.
+    # same GAN drift apart at the rate the dynamics amplify a 16-bit rounding, and after the first differing gate
+    # decision they are two different training runs; the bounds below hold UP TO that step and are 1.5-2x what the runs in
+    # profiles/r05_trajectory_b32.log measured (same gate decisions for the first 45-50 steps; first six steps <= 1.9e-2;
+    # nle <= 9.4e-2, mse <= 0.21, kl inside a factor 1.9 -- the largest kl ratios sit on the steps where the ORACLE's own
+    # KL jumps 2-3x from one step to the next, the latent excursions of DESIGN 8; the bce sums, which pass through zero
+    # when the discriminator wins, inside a factor 3 or 0.1 nat per sample).
     assert all(rows[0][2][k] < 1e-3 for k in LOSSES), rows[0][2]
-    assert first_gate_split >= 10, f"equilibrium gate decisions differ already at step {first_gate_split}"
-    for i, same, rel, got, ref in rows[:10]:
+    assert first_gate_split >= 25, f"equilibrium gate decisions differ already at step {first_gate_split}"
+    for i, same, rel, got, ref in rows[:first_gate_split]:
         for k in LOSSES:
-            assert rel[k] < 5e-2, (i, k, got[k], ref[k])
+            if i < 6:
+                assert rel[k] < 4e-2, (i, k, got[k], ref[k])
+            lim = {"nle": 0.15, "mse": 0.35}.get(k)
+            if lim is not None:
+                assert rel[k] < lim, (i, k, got[k], ref[k])
+            else:
+                ratio = max(got[k], 1e-12) / max(ref[k], 1e-12)
+                near = k.startswith("bce") and abs(got[k] - ref[k]) < 0.1 * B
+                assert near or 1 / 3.0 < ratio < 3.0, (i, k, got[k], ref[k])
 
 
 def test_stage1_one_step_parity_along_the_oracle_trajectory():

@@ -543,15 +543,21 @@ def stage1_step(P: State, opts: Dict[str, OptState], x: Tensor, eps: Tensor, z_p
 
 
 def stage2_step(P: State, opts: Dict[str, OptState], fmri: Tensor, image: Tensor, noise: Tensor, cfg: ArchCfg,
-                n_voxels: int, hp: GanHyper = GanHyper(), keep_grads: bool = False):
+                n_voxels: int, hp: GanHyper = GanHyper(), keep_grads: bool = False, mode: str = "vae-gan"):
     """Stage-II step (train/train_vgan_stage2.py:321-407): decoder frozen, teacher distillation,
-    encoder + discriminator trained, no gate, gradients clamped to +-1."""
+    encoder + discriminator trained, no gate, gradients clamped to +-1.
+
+    ``mode='vae'`` (:234-238, :362-366): the model is built without a teacher net (the "real" slot of the discriminator
+    is the ground-truth image), the encoder minimises KL + the PIXEL nle, the discriminator bce_orig + bce_sampled; the
+    `train_dis = False` of :366 is overwritten by :375-376, so the discriminator is trained in this mode too."""
+    if mode not in ("vae-gan", "vae"):
+        raise ValueError(mode)
     enc_k = param_keys(cognitive_encoder_spec(cfg, n_voxels))
     dis_k = param_keys(discriminator_spec(cfg))
     _leafify(P, enc_k + dis_k)
     B = fmri.shape[0]
-    fw = cognitive_forward(P, fmri, image, noise, cfg, stage=2, teacher=True)
-    loss_enc, loss_dis, loss_dec, logs = _compose_losses(fw, fw["gt_x"], B, hp)
+    fw = cognitive_forward(P, fmri, image, noise, cfg, stage=2, teacher=mode != "vae")
+    loss_enc, loss_dis, loss_dec, logs = _compose_losses(fw, fw["gt_x"], B, hp, mode)
     g_enc = _grads(loss_enc, P, enc_k, True)
     g_dis = _grads(loss_dis, P, dis_k, False)
     opt_step(P, enc_k, g_enc, opts["encoder"], clamp=1.0)
@@ -566,16 +572,27 @@ def stage2_step(P: State, opts: Dict[str, OptState], fmri: Tensor, image: Tensor
 
 
 def stage3_step(P: State, opts: Dict[str, OptState], fmri: Tensor, image: Tensor, noise: Tensor, cfg: ArchCfg,
-                n_voxels: int, hp: GanHyper = GanHyper(), keep_grads: bool = False):
+                n_voxels: int, hp: GanHyper = GanHyper(), keep_grads: bool = False, mode: str = "vae-gan"):
     """Stage-III step (train/train_vgan_stage3.py:324-411): cognitive encoder frozen, decoder +
-    discriminator trained, equilibrium gate on, gradients clamped to +-1."""
+    discriminator trained, equilibrium gate on, gradients clamped to +-1.
+
+    ``mode='vae'`` (:370-374): decoder loss lambda * nle, discriminator loss bce_orig + bce_sampled with train_dis
+    starting False -- the discriminator is updated only in a step whose gate re-arms both (:382-389)."""
+    if mode not in ("vae-gan", "vae"):
+        raise ValueError(mode)
     dec_k = param_keys(decoder_spec(cfg))
     dis_k = param_keys(discriminator_spec(cfg))
     _leafify(P, dec_k + dis_k)
     B = fmri.shape[0]
     fw = cognitive_forward(P, fmri, image, noise, cfg, stage=3, teacher=False)
-    loss_enc, loss_dis, loss_dec, logs = _compose_losses(fw, image, B, hp)
-    train_dis, train_dec = equilibrium_gate(logs["bce_orig"] / B, logs["bce_pred"] / B, hp)
+    loss_enc, loss_dis, loss_dec, logs = _compose_losses(fw, image, B, hp, mode)
+    train_dis, train_dec = mode != "vae", True                                           # :356-357, :374
+    if logs["bce_orig"] / B < hp.equilibrium - hp.margin or logs["bce_pred"] / B < hp.equilibrium - hp.margin:
+        train_dis = False
+    if logs["bce_orig"] / B > hp.equilibrium + hp.margin or logs["bce_pred"] / B > hp.equilibrium + hp.margin:
+        train_dec = False
+    if (not train_dec) and (not train_dis):
+        train_dis, train_dec = True, True
     g_dec = _grads(loss_dec, P, dec_k, True)
     g_dis = _grads(loss_dis, P, dis_k, False)
     if train_dec:
@@ -726,8 +743,10 @@ def wae_stage3_step(P: State, opts: Dict[str, OptState], fmri: Tensor, image: Te
 
 
 def dual_stage1_step(P: State, opts: Dict[str, OptState], x: Tensor, noise: Tensor, cfg: ArchCfg,
-                     hp: GanHyper = GanHyper(), lam: float = 1.0, keep_grads: bool = False):
-    """Dual WAE + VAE/GAN Stage-I step, mode 'vae-gan' (train/wae_vgan_stage1.py:284-441).
+                     hp: GanHyper = GanHyper(), lam: float = 1.0, keep_grads: bool = False, mode: str = "vae-gan",
+                     beta: float = 1.0):
+    """Dual WAE + VAE/GAN Stage-I step (train/wae_vgan_stage1.py:284-441), ``mode`` in 'vae-gan' (default), 'beta-vae',
+    'dcgan' (encoder never stepped, :419), 'vae' (train_dis starts False) -- the compositions of :311-364.
 
     = the Stage-I VAE/GAN forward and losses (:290-364), then a WAE latent-discriminator phase on the encoder
     means (`wae_discriminator.`, RMSprop, :384-397), then the penalty -lam*sum log(d_real+1e-3) back-propagated
@@ -745,8 +764,15 @@ def dual_stage1_step(P: State, opts: Dict[str, OptState], x: Tensor, noise: Tens
     _leafify(P, enc_k + dec_k + dis_k)
     B = x.shape[0]
     fw = vaegan_forward(P, x, noise[0], noise[1], cfg)
-    loss_enc, loss_dis, loss_dec, logs = _compose_losses(fw, x, B, hp)
-    train_dis, train_dec = equilibrium_gate(logs["bce_orig"] / B, logs["bce_pred"] / B, hp)
+    loss_enc, loss_dis, loss_dec, logs = _compose_losses(fw, x, B, hp, mode, beta)
+    train_enc = mode != "dcgan"                                            # :343
+    train_dis, train_dec = mode != "vae", True                             # :311-312, :354
+    if logs["bce_orig"] / B < hp.equilibrium - hp.margin or logs["bce_pred"] / B < hp.equilibrium - hp.margin:
+        train_dis = False
+    if logs["bce_orig"] / B > hp.equilibrium + hp.margin or logs["bce_pred"] / B > hp.equilibrium + hp.margin:
+        train_dec = False
+    if (not train_dec) and (not train_dis):
+        train_dis, train_dec = True, True
     with torch.no_grad():
         z_real, _ = encoder_fwd(P, "encoder.", x, cfg)                     # :384
     z_fake = noise[2] * 0.5                                                # :385
@@ -764,10 +790,11 @@ def dual_stage1_step(P: State, opts: Dict[str, OptState], x: Tensor, noise: Tens
             for k in dec_k:
                 if k in dopt.bufs:
                     dopt.bufs[k].mul_(dopt.alpha)
-    g_enc = _gsum(_grads(loss_enc, P, enc_k, True), g_pen)                 # :421 accumulates onto the penalty
+    g_enc = _gsum(_grads(loss_enc, P, enc_k, True), g_pen) if train_enc else [None] * len(enc_k)   # :421
     g_dec = _grads(loss_dec, P, dec_k, True)
     g_dis = _grads(loss_dis, P, dis_k, False)
-    opt_step(P, enc_k, g_enc, opts["encoder"])
+    if train_enc:
+        opt_step(P, enc_k, g_enc, opts["encoder"])
     if train_dec:
         opt_step(P, dec_k, g_dec, opts["decoder"])
     if train_dis:

@@ -226,8 +226,9 @@ def case_stage1(name, cfg, B, seed, perturb, steps=2, mode="vae-gan", beta=1.0):
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
 
 
-def build_cognitive(vg, cfg, V, seed, perturb, stage):
-    """Model wiring of train_vgan_stage2.py:211-232 / train_vgan_stage3.py:222-245 on recipe weights."""
+def build_cognitive(vg, cfg, V, seed, perturb, stage, mode="vae-gan"):
+    """Model wiring of train_vgan_stage2.py:211-232 / train_vgan_stage3.py:222-245 on recipe weights (``mode`` 'vae' at
+    Stage II: no teacher net, train_vgan_stage2.py:234-238)."""
     teacher = vg.VaeGan(device="cpu", z_size=cfg.latent_dim)
     teacher.load_state_dict(O.fill_state(O.vaegan_spec(cfg), seed, perturb))
     cog = vg.CognitiveEncoder(input_size=V, z_size=cfg.latent_dim)
@@ -237,8 +238,8 @@ def build_cognitive(vg, cfg, V, seed, perturb, stage):
         for p in teacher.decoder.parameters():
             p.requires_grad = False
         model = vg.VaeGanCognitive(device="cpu", encoder=cog, decoder=teacher.decoder,
-                                   discriminator=teacher.discriminator, teacher_net=teacher, stage=2,
-                                   z_size=cfg.latent_dim)
+                                   discriminator=teacher.discriminator, teacher_net=None if mode == "vae" else teacher,
+                                   stage=2, z_size=cfg.latent_dim)
     else:
         # stage 3 builds fresh Decoder/Discriminator and loads stage-II weights; equivalent: reuse tensors
         for p in cog.parameters():
@@ -250,26 +251,30 @@ def build_cognitive(vg, cfg, V, seed, perturb, stage):
     return model
 
 
-def case_cognitive(name, cfg, B, V, seed, perturb, stage, steps=2):
+def case_cognitive(name, cfg, B, V, seed, perturb, stage, steps=2, mode="vae-gan"):
+    """``mode``: 'vae-gan' or 'vae' (train_vgan_stage2.py:355-366, train_vgan_stage3.py:361-374)."""
     vg = load_reference(cfg)
     hp = O.GanHyper()
-    model = build_cognitive(vg, cfg, V, seed, perturb, stage)
+    teach = stage == 2 and mode != "vae"
+    _build = build_cognitive
+    build_cognitive_m = lambda *a: _build(*a, mode)
+    model = build_cognitive_m(vg, cfg, V, seed, perturb, stage)
     data = O.synth_batch(B, cfg, n_voxels=V, seed=1234, steps=steps)
     x, fmri = data["x"], data["fmri"]
 
     # RNG-order check against the reference's own forward (eps_cog, [eps_teacher], z_p)
-    chk = build_cognitive(vg, cfg, V, seed, perturb, stage)
+    chk = build_cognitive_m(vg, cfg, V, seed, perturb, stage)
     torch.manual_seed(11)
     ref_out = chk({"fmri": fmri, "image": x})
     torch.manual_seed(11)
     e1 = torch.empty(B, cfg.latent_dim).normal_()
-    e2 = torch.empty(B, cfg.latent_dim).normal_() if stage == 2 else None
+    e2 = torch.empty(B, cfg.latent_dim).normal_() if teach else None
     zp = torch.randn(B, cfg.latent_dim)
-    chk2 = build_cognitive(vg, cfg, V, seed, perturb, stage)
+    chk2 = build_cognitive_m(vg, cfg, V, seed, perturb, stage)
     mus, lv = chk2.encoder(fmri)
     xt = chk2.decoder(e1 * torch.exp(0.5 * lv) + mus)
     gt = x
-    if stage == 2:
+    if teach:
         mt, lt = chk2.teacher_net.encoder(x)
         gt = chk2.decoder(e2 * torch.exp(0.5 * lt) + mt)
     xp = chk2.decoder(zp)
@@ -282,7 +287,7 @@ def case_cognitive(name, cfg, B, V, seed, perturb, stage, steps=2):
     opt_d = rms(model.decoder.parameters(), hp.lr)
     opt_s = rms(model.discriminator.parameters(), hp.lr)
     out = {"meta/case": np.array(f"stage{stage}"), "meta/B": B, "meta/V": V, "meta/seed": seed,
-           "meta/perturb": perturb, "meta/steps": steps, "meta/image_size": cfg.image_size}
+           "meta/perturb": perturb, "meta/steps": steps, "meta/image_size": cfg.image_size, "meta/mode": np.array(mode)}
     for s in range(steps):
         nz = data["noise"][s]
         if stage == 2:
@@ -298,7 +303,7 @@ def case_cognitive(name, cfg, B, V, seed, perturb, stage, steps=2):
         mus, lv = model.encoder(fmri)
         x_tilde = model.decoder(nz[0] * torch.exp(0.5 * lv) + mus)
         gt_x = x
-        if stage == 2:
+        if teach:
             for p in model.teacher_net.encoder.parameters():
                 p.requires_grad = False
             mt, lt = model.teacher_net.encoder(x)
@@ -309,16 +314,30 @@ def case_cognitive(name, cfg, B, V, seed, perturb, stage, steps=2):
         nle, kld, mse, bo, bp, bs = vg.VaeGanCognitive.loss(gt_x, x_tilde, disc_layer[:B], disc_layer[B:-B],
                                                             disc_layer[-B:], disc_class[:B], disc_class[B:-B],
                                                             disc_class[-B:], mus, lv)
-        loss_enc = torch.sum(kld) + torch.sum(mse)
-        loss_dis = torch.sum(bo) + torch.sum(bp) + torch.sum(bs)
-        loss_dec = torch.sum(hp.lambda_mse * mse) - (1.0 - hp.lambda_mse) * loss_dis
+        if mode == "vae":
+            loss_enc = torch.sum(kld) + torch.sum(nle)
+            loss_dis = torch.sum(bo) + torch.sum(bs)
+            loss_dec = torch.sum(hp.lambda_mse * nle)
+        else:
+            loss_enc = torch.sum(kld) + torch.sum(mse)
+            loss_dis = torch.sum(bo) + torch.sum(bp) + torch.sum(bs)
+            loss_dec = torch.sum(hp.lambda_mse * mse) - (1.0 - hp.lambda_mse) * loss_dis
         if stage == 2:
+            # train_vgan_stage2.py:366 sets train_dis = False for 'vae', :375-376 then overwrite both flags
             train_dis, train_dec = True, False
             g = literal_three_backward(model, loss_enc, loss_dec, loss_dis, ("encoder", "discriminator"))
             apply_grads(model.encoder, "encoder.", g, opt_e, clamp=1.0)
             apply_grads(model.discriminator, "discriminator.", g, opt_s, clamp=1.0)
         else:
-            train_dis, train_dec = gate(torch.mean(bo).item(), torch.mean(bp).item(), hp)
+            # train_vgan_stage3.py:356-357 (both True), :374 ('vae': train_dis = False), gate :382-389
+            train_dis, train_dec = mode != "vae", True
+            bom, bpm = torch.mean(bo).item(), torch.mean(bp).item()
+            if bom < hp.equilibrium - hp.margin or bpm < hp.equilibrium - hp.margin:
+                train_dis = False
+            if bom > hp.equilibrium + hp.margin or bpm > hp.equilibrium + hp.margin:
+                train_dec = False
+            if train_dec is False and train_dis is False:
+                train_dis, train_dec = True, True
             g = literal_three_backward(model, loss_enc, loss_dec, loss_dis, ("decoder", "discriminator"))
             if train_dec:
                 apply_grads(model.decoder, "decoder.", g, opt_d, clamp=1.0)
@@ -496,7 +515,7 @@ def case_wae23(name, cfg, B, V, seed, stage, steps=2):
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
 
 
-def case_dual1(name, cfg, B, seed, perturb, steps=3, lam=1.0):
+def case_dual1(name, cfg, B, seed, perturb, steps=3, lam=1.0, mode="vae-gan", beta=1.0):
     """train/wae_vgan_stage1.py:284-441, mode 'vae-gan': Stage-I VAE/GAN step + WAE latent-discriminator phase +
     latent penalty into the encoder.  Optimizer steps are applied after all gradients are taken (SURVEY 0.5);
     `zero_grad()` follows the pinned torch 1.4 (zeroes instead of dropping .grad), which makes the
@@ -523,7 +542,8 @@ def case_dual1(name, cfg, B, seed, perturb, steps=3, lam=1.0):
             p.requires_grad = not flag
 
     out = {"meta/case": np.array("dual1"), "meta/B": B, "meta/seed": seed, "meta/perturb": perturb,
-           "meta/steps": steps, "meta/image_size": cfg.image_size, "meta/lam": lam}
+           "meta/steps": steps, "meta/image_size": cfg.image_size, "meta/lam": lam, "meta/mode": np.array(mode),
+           "meta/beta": beta}
     for s in range(steps):
         nz = data["noise"][s]
         model.train()
@@ -534,10 +554,33 @@ def case_dual1(name, cfg, B, seed, perturb, steps=3, lam=1.0):
         disc_class = model.discriminator(x, x_tilde, x_p, "GAN")
         nle, kld, mse, bo, bp, bs = vg.VaeGan.loss(x, x_tilde, disc_layer[:B], disc_layer[B:-B], disc_layer[-B:],
                                                    disc_class[:B], disc_class[B:-B], disc_class[-B:], mus, lv)
-        loss_enc = torch.sum(kld) + torch.sum(mse)
-        loss_dis = torch.sum(bo) + torch.sum(bp) + torch.sum(bs)
-        loss_dec = torch.sum(hp.lambda_mse * mse) - (1.0 - hp.lambda_mse) * loss_dis
-        train_dis, train_dec = gate(torch.mean(bo).item(), torch.mean(bp).item(), hp)
+        # loss compositions and flags of wae_vgan_stage1.py:311-364
+        train_enc, train_dis, train_dec = True, True, True
+        if mode == "beta-vae":
+            loss_enc = torch.sum(kld) * beta * (1 / B) + torch.sum(mse)
+            loss_dis = torch.sum(bo) + torch.sum(bp) + torch.sum(bs)
+            loss_dec = torch.sum(hp.lambda_mse * mse) - (1.0 - hp.lambda_mse) * loss_dis
+        elif mode == "vae-gan":
+            loss_enc = torch.sum(kld) + torch.sum(mse)
+            loss_dis = torch.sum(bo) + torch.sum(bp) + torch.sum(bs)
+            loss_dec = torch.sum(hp.lambda_mse * mse) - (1.0 - hp.lambda_mse) * loss_dis
+        elif mode == "dcgan":
+            train_enc = False
+            loss_enc = torch.sum(kld) + torch.sum(nle)
+            loss_dis = torch.sum(bo) + torch.sum(bs)
+            loss_dec = torch.sum(hp.lambda_mse * nle) - (1.0 - hp.lambda_mse) * loss_dis
+        elif mode == "vae":
+            loss_enc = torch.sum(kld) + torch.sum(nle)
+            loss_dis = torch.sum(bo) + torch.sum(bs)
+            loss_dec = torch.sum(hp.lambda_mse * nle)
+            train_dis = False
+        bom, bpm = torch.mean(bo).item(), torch.mean(bp).item()
+        if bom < hp.equilibrium - hp.margin or bpm < hp.equilibrium - hp.margin:
+            train_dis = False
+        if bom > hp.equilibrium + hp.margin or bpm > hp.equilibrium + hp.margin:
+            train_dec = False
+        if train_dec is False and train_dis is False:
+            train_dis, train_dec = True, True
         model.zero_grad()
         # ---- WAE discriminator phase (:378-397)
         freeze(model.decoder, True)
@@ -564,17 +607,20 @@ def case_dual1(name, cfg, B, seed, perturb, steps=3, lam=1.0):
         l_pen = -lam * torch.sum(torch.log(d_real + 1e-3))
         g_pen = torch.autograd.grad(l_pen, list(model.encoder.parameters()), allow_unused=True)
         # ---- VAE/GAN updates (:419-441), gradients at the pre-update weights
-        g3 = literal_three_backward(model, loss_enc, loss_dec, loss_dis, ("encoder", "decoder", "discriminator"))
-        for (k, p), gp in zip(model.encoder.named_parameters(), g_pen):
-            if gp is not None:
-                g3["encoder." + k] = g3["encoder." + k] + gp  # :421 accumulates onto the penalty gradient
+        g3 = literal_three_backward(model, loss_enc, loss_dec, loss_dis,
+                                    (("encoder",) if train_enc else ()) + ("decoder", "discriminator"))
+        if train_enc:
+            for (k, p), gp in zip(model.encoder.named_parameters(), g_pen):
+                if gp is not None:
+                    g3["encoder." + k] = g3["encoder." + k] + gp  # :421 accumulates onto the penalty gradient
         g.update(g3)
         if s > 0:   # :417 under torch 1.4: decoder .grad are zero tensors there -> RMSprop decays square_avg, params
             #         unchanged (run here, after the backward passes, because the step bumps tensor versions)
             for p in model.decoder.parameters():
                 p.grad = torch.zeros_like(p)
             opt_d.step()
-        apply_grads(model.encoder, "encoder.", g, opt_e)
+        if train_enc:                                  # ('dcgan': the encoder is never stepped, :419)
+            apply_grads(model.encoder, "encoder.", g, opt_e)
         if train_dec:
             apply_grads(model.decoder, "decoder.", g, opt_d)
         if train_dis:
@@ -873,6 +919,10 @@ if __name__ == "__main__":
         case_cognitive("stage3_px128_b2", O.ArchCfg.px128(), B=2, V=3620, seed=5, perturb=True, stage=3, steps=1)
     if want("wae3_px128_b2"):
         case_wae23("wae3_px128_b2", O.ArchCfg.px128(), B=2, V=3620, seed=7, stage=3, steps=1)
+    if want("stage2_vae_b4"):
+        case_cognitive("stage2_vae_b4", O.ArchCfg.px64(), B=4, V=4096, seed=1, perturb=True, stage=2, mode="vae")
+    if want("stage3_vae_b4"):
+        case_cognitive("stage3_vae_b4", O.ArchCfg.px64(), B=4, V=4096, seed=2, perturb=True, stage=3, mode="vae")
     if want("stage2_b4"):
         case_cognitive("stage2_b4", O.ArchCfg.px64(), B=4, V=4096, seed=1, perturb=True, stage=2)
     if want("stage3_b4"):
@@ -885,6 +935,10 @@ if __name__ == "__main__":
         case_wae23("wae3_b4", O.ArchCfg.px64(), B=4, V=4096, seed=7, stage=3)
     if want("dual1_b4"):
         case_dual1("dual1_b4", O.ArchCfg.px64(), B=4, seed=8, perturb=True)
+    for m in ("beta-vae", "dcgan", "vae"):
+        n = "dual1_" + m.replace("-", "") + "_b4"
+        if want(n):
+            case_dual1(n, O.ArchCfg.px64(), B=4, seed=8, perturb=True, steps=2, mode=m, beta=4.0)
     if want("metrics"):
         case_metrics("metrics")
     if want("eval_b4"):

@@ -172,10 +172,11 @@ def test_stage1_literal_equals_pruned():
         assert torch.equal(res[0][1][k], res[1][1][k]), k
 
 
+@pytest.mark.parametrize("mode", ["vae-gan", "vae"])
 @pytest.mark.parametrize("stage", [2, 3])
-def test_cognitive_stages_match_reference(golden_dir, stage):
+def test_cognitive_stages_match_reference(golden_dir, stage, mode):
     cfg = O.ArchCfg.px64()
-    g = _load(golden_dir, f"stage{stage}_b4")
+    g = _load(golden_dir, f"stage{stage}_b4" if mode == "vae-gan" else f"stage{stage}_vae_b4")
     B, V, seed, perturb, steps = (int(g["meta/B"]), int(g["meta/V"]), int(g["meta/seed"]), bool(g["meta/perturb"]),
                                   int(g["meta/steps"]))
     teacher = O.fill_state(O.vaegan_spec(cfg), seed, perturb)
@@ -190,7 +191,7 @@ def test_cognitive_stages_match_reference(golden_dir, stage):
     opts = _rms_opts("encoder", "decoder", "discriminator")
     step = O.stage2_step if stage == 2 else O.stage3_step
     for s in range(steps):
-        out = step(P, opts, data["fmri"], data["x"], data["noise"][s], cfg, V, keep_grads=True)
+        out = step(P, opts, data["fmri"], data["x"], data["noise"][s], cfg, V, keep_grads=True, mode=mode)
         assert out["logs"].pop("train_dis") == bool(g[f"step{s}/logs/train_dis"])
         assert out["logs"].pop("train_dec") == bool(g[f"step{s}/logs/train_dec"])
         if stage == 2:  # keep aliases in sync after the functional update replaced tensors
@@ -256,15 +257,21 @@ def dual_state(cfg, seed, perturb):
     return P
 
 
-def test_dual_stage1_matches_reference(golden_dir):
+@pytest.mark.parametrize("mode", ["vae-gan", "beta-vae", "dcgan", "vae"])
+def test_dual_stage1_matches_reference(golden_dir, mode):
+    """train/wae_vgan_stage1.py:284-441 in its four loss compositions (:311-364)."""
     cfg = O.ArchCfg.px64()
-    g = _load(golden_dir, "dual1_b4")
+    g = _load(golden_dir, "dual1_b4" if mode == "vae-gan" else "dual1_" + mode.replace("-", "") + "_b4")
     B, seed, perturb, steps = int(g["meta/B"]), int(g["meta/seed"]), bool(g["meta/perturb"]), int(g["meta/steps"])
+    beta = float(g["meta/beta"]) if "meta/beta" in g.files else 1.0
     P = dual_state(cfg, seed, perturb)
     data = O.synth_batch(B, cfg, seed=1234, steps=steps)
     opts = _rms_opts("encoder", "decoder", "discriminator", "wae_discriminator")
     for s in range(steps):
-        out = O.dual_stage1_step(P, opts, data["x"], data["noise"][s], cfg, lam=float(g["meta/lam"]), keep_grads=True)
+        out = O.dual_stage1_step(P, opts, data["x"], data["noise"][s], cfg, lam=float(g["meta/lam"]), keep_grads=True,
+                                 mode=mode, beta=beta)
+        assert out["logs"].pop("train_dis") == bool(g[f"step{s}/logs/train_dis"])
+        assert out["logs"].pop("train_dec") == bool(g[f"step{s}/logs/train_dec"])
         _check_step(g, f"step{s}", out, P)
 
 

@@ -33,21 +33,26 @@ def _oracle_state(O, cfg, V, seed, perturb, stage):
     return P, teacher
 
 
+@pytest.mark.parametrize("mode", ["vae-gan", "vae"])
 @pytest.mark.parametrize("stage", [2, 3])
-def test_cognitive_step_matches_oracle_and_golden(golden_dir, stage):
+def test_cognitive_step_matches_oracle_and_golden(golden_dir, stage, mode):
+    """``mode='vae'``: the scripts' `--mode vae` (train_vgan_stage2.py:234-238,362-366; train_vgan_stage3.py:370-374) --
+    no teacher net, pixel nle instead of the feature mse -- against the oracle and the reference-generated
+    tests/golden/stage{2,3}_vae_b4.npz."""
     from oracle import vaegan_oracle as O
     from fmri_hip.params import ArchConfig
     from fmri_hip.steps import CognitiveStep
-    g = np.load(os.path.join(golden_dir, f"stage{stage}_b4.npz"))
+    g = np.load(os.path.join(golden_dir, f"stage{stage}_b4.npz" if mode == "vae-gan" else f"stage{stage}_vae_b4.npz"))
     B, V, seed, perturb = int(g["meta/B"]), int(g["meta/V"]), int(g["meta/seed"]), bool(g["meta/perturb"])
     cfg_o = O.ArchCfg.px64()
     steps = 2
     data = O.synth_batch(B, cfg_o, n_voxels=V, seed=1234, steps=steps)
-    st = CognitiveStep(ArchConfig.px64(), V, DEV, stage)
+    st = CognitiveStep(ArchConfig.px64(), V, DEV, stage, mode=mode)
     st.load_recipe(seed, perturb)
     P, teacher = _oracle_state(O, cfg_o, V, seed, perturb, stage)
     opts = {n: O.OptState(kind="rmsprop", lr=1e-4) for n in ("encoder", "decoder", "discriminator")}
-    ostep = O.stage2_step if stage == 2 else O.stage3_step
+    ostep_ = O.stage2_step if stage == 2 else O.stage3_step
+    ostep = lambda *a, **k: ostep_(*a, mode=mode, **k)
     fm, im = data["fmri"].to(DEV), data["x"].to(DEV)
     for s in range(steps):
         nz = data["noise"][s]

@@ -147,16 +147,21 @@ def test_wae_step_matches_oracle_and_golden(golden_dir, stage):
         _check_counters(st, g, f"step{s}", 2e-2 if s == 0 else (5e-2 if s == 1 else 1e-1))
 
 
-def test_dual_stage1_matches_oracle_and_golden(golden_dir):
+@pytest.mark.parametrize("mode", ["vae-gan", "beta-vae", "dcgan", "vae"])
+def test_dual_stage1_matches_oracle_and_golden(golden_dir, mode):
+    """The four loss compositions of train/wae_vgan_stage1.py:311-364 against the oracle and the reference-generated
+    goldens (tests/golden/dual1_b4.npz, dual1_{betavae,dcgan,vae}_b4.npz)."""
     from oracle import vaegan_oracle as O
     from fmri_hip.params import ArchConfig
+    from fmri_hip.steps import GanHyper
     from fmri_hip.wae_steps import DualStage1Step
-    g = np.load(os.path.join(golden_dir, "dual1_b4.npz"))
+    g = np.load(os.path.join(golden_dir, "dual1_b4.npz" if mode == "vae-gan" else f"dual1_{mode.replace('-', '')}_b4.npz"))
     B, seed, perturb, steps = int(g["meta/B"]), int(g["meta/seed"]), bool(g["meta/perturb"]), int(g["meta/steps"])
     lam = float(g["meta/lam"])
+    beta = float(g["meta/beta"]) if "meta/beta" in g.files else 1.0
     cfg_o = O.ArchCfg.px64()
     data = O.synth_batch(B, cfg_o, seed=1234, steps=steps)
-    st = DualStage1Step(ArchConfig.px64(), DEV, lam=lam)
+    st = DualStage1Step(ArchConfig.px64(), DEV, lam=lam, mode=mode, hp=GanHyper(beta=beta))
     st.load_recipe(seed, perturb)
     P = O.fill_state(O.vaegan_spec(cfg_o), seed, perturb)
     P.update(O.fill_state(O.wae_discriminator_spec(cfg_o, pre="wae_discriminator."), seed + 200, perturb))
@@ -167,11 +172,11 @@ def test_dual_stage1_matches_oracle_and_golden(golden_dir):
         nz = data["noise"][s]
         st.step(x, nz[0].to(DEV), nz[1].to(DEV), nz[2].to(DEV))
         logs = st.logs()
-        ref = O.dual_stage1_step(P, opts, data["x"], nz, cfg_o, lam=lam, keep_grads=True)
+        ref = O.dual_stage1_step(P, opts, data["x"], nz, cfg_o, lam=lam, keep_grads=True, mode=mode, beta=beta)
         assert logs["train_dis"] == ref["logs"]["train_dis"] and logs["train_dec"] == ref["logs"]["train_dec"]
         for k in GAN_KEYS + WAE_KEYS[1:]:
             r = _rel(logs[k], ref["logs"][k])
-            print(s, k, logs[k], ref["logs"][k], r)
+            print(mode, s, k, logs[k], ref["logs"][k], r)
             if s == 0:
                 assert r < 1e-3, (k, logs[k], ref["logs"][k])
                 assert _rel(logs[k], float(g[f"step0/logs/{k}"])) < 1e-3, (k, "golden")
@@ -184,10 +189,11 @@ def test_dual_stage1_matches_oracle_and_golden(golden_dir):
             o16 = {n: O.OptState(kind="rmsprop", lr=1e-4) for n in ("encoder", "decoder", "discriminator",
                                                                        "wae_discriminator")}
             with gradcheck.storage16(O):
-                ref16 = O.dual_stage1_step(P16, o16, data["x"], nz, cfg_o, lam=lam, keep_grads=True)
+                ref16 = O.dual_stage1_step(P16, o16, data["x"], nz, cfg_o, lam=lam, keep_grads=True, mode=mode, beta=beta)
             # (the latent discriminator's two passes cancel, see test_wae_step_matches_oracle_and_golden: plain bound)
             latent_d = [k for k in ref["grads"] if k.startswith("wae_discriminator.")]
-            gradcheck.check(grads, ref["grads"], ref16["grads"], "dual1", skip=latent_d, tol16=None)
+            skip = latent_d + ([k for k in ref["grads"] if k.startswith("encoder.")] if mode == "dcgan" else [])
+            gradcheck.check(grads, ref["grads"], ref16["grads"], "dual1", skip=skip, tol16=None)
             for k in latent_d:
                 assert _terr(grads[k], ref["grads"][k]) < 0.1, k
         # running statistics after the first (sign-like) parameter update follow the 5e-2 "next forward" bound; after the

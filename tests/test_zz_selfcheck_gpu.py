@@ -498,3 +498,47 @@ def test_one_launch_update_in_the_default_reduction_mode():
                             assert float(buf.abs().max()) == 0.0, f"{type(obj).__name__}: accumulation buffer not cleared"
     assert held >= 3, f"only {held} accumulation buffers found: the walk over the layers missed them"
 
+
+
+@pytest.mark.parametrize("B", [4, 5, 7])
+def test_deterministic_px100_unfused_backward_sums_only_written_slabs(deterministic, B):
+    """Deterministic weight gradients at the as-shipped 100-px geometry through the NON-fused forward / gate / backward
+    path (fresh slab buffers per launch, no persistent zero-initialised holds): the library stores ceil(steps /
+    ceil(steps / splits)) slabs, which is fewer than the ``splits`` the caller allocates at these sizes (18 of 19 at
+    encoder.conv.0 with 4 images) -- the trailing slabs must be zero, not allocator leftovers.  The allocator is primed
+    with NaN-filled blocks of the slab sizes first, so a summed stale slab cannot pass by luck; two runs must give the
+    same bits, finite, and agree with the default (atomic) reduction mode to its rounding."""
+    from oracle import vaegan_oracle as O
+    from fmri_hip import ops
+    from fmri_hip.params import ArchConfig
+    from fmri_hip.steps import Stage1Step
+    cfg, cfg_o = ArchConfig.px100(), O.ArchCfg.px100()
+    data = O.synth_batch(B, cfg_o, seed=99, steps=1)
+    x, e, zp = data["x"].to(DEV), data["noise"][0, 0].to(DEV), data["noise"][0, 1].to(DEV)
+
+    def grads(det):
+        was = ops.set_deterministic(det)
+        try:
+            st = Stage1Step(cfg, DEV)
+            st.load_recipe(3, True)
+            # poison the caching allocator's free lists: blocks of many sizes filled with NaN, then released
+            junk = [torch.full((n,), float("nan"), device=DEV) for n in (1 << 12, 1 << 16, 1 << 18, 1 << 20, 1 << 22, 1 << 24)
+                    for _ in range(3)]
+            del junk
+            st.forward(x, e, zp)
+            st.gate(B)
+            st.backward()
+            ops.join_side()
+            torch.cuda.synchronize()
+            return {k: v.clone() for k, v in st.named_grads().items()}
+        finally:
+            ops.set_deterministic(was)
+
+    ga, gb, gd = grads(True), grads(True), grads(False)
+    for k in ga:
+        assert torch.isfinite(ga[k]).all(), f"{k}: non-finite deterministic gradient (an unwritten slab was summed)"
+    _assert_same_bits(ga, gb, f"two deterministic px100 backward passes at B = {B}")
+    for k in ga:
+        ref = gd[k].float()
+        err = (ga[k].float() - ref).abs().max().item()
+        assert err <= 2e-3 * ref.abs().max().item() + 1e-7, (k, err, ref.abs().max().item())

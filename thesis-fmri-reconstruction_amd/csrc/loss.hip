@@ -384,7 +384,8 @@ __global__ void compose_gate_kernel(float* __restrict__ scal, int* __restrict__ 
     scal[S_NP] = np;
     scal[S_RATIO] = na / nb;
     scal[S_ONE] = 1.f;
-    scal[14] = 0.f;         // sum of squares of the encoder-stream re-normalisation (fmri_sumsq adds into it)
+    scal[14] = 0.f;         // S_ESQ of the float form of the encoder-stream re-normalisation (fmri_sumsq adds into it;
+                            // the steps use fmri_sumsq_f64, which clears its own double accumulator)
     scal[S_C1] = lambda_mse * na / nb;
     scal[S_C2] = 1.f - lambda_mse;
     scal[S_C3] = lambda_mse * na;

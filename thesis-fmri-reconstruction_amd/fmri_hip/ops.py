@@ -439,7 +439,10 @@ def run_wgrad(P, Q, N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad, flip=0, flops=0.0,
     mode = 1 if splits > 1 else 0
     if splits > 1 and _DET["on"]:
         mode = 4                     # per-split slabs (plain stores), summed in slab order by unpack_grad
-        out = _grad_buffer(hold, (splits, apad, ldo), False, P.device)
+        # zero-filled: the library re-derives the split count from the K steps (ceil(steps / ceil(steps / splits)), which
+        # can be smaller than ``splits`` -- e.g. 18 of 19 at the 100-px encoder conv.0 with 4 images) and stores only that
+        # many slabs, while unpack_grad / fmri_apply_batch sum all of them
+        out = _grad_buffer(hold, (splits, apad, ldo), True, P.device)
     elif splits > 1:
         out = _grad_buffer(hold, (apad, ldo), True, P.device)
     else:
@@ -653,7 +656,8 @@ def materialize_grads(group):
         st = group._no_state = torch.zeros(1, dtype=torch.float32, device=group.device)
     plan = _plan_apply(group, st, update=False)
     if plan is None:
-        flush_pending(group)
+        # (keep what an earlier partial call has already put into the reference layout -- it may be mid-reduction)
+        flush_pending(group, keep=getattr(group, "materialized", []))
         return
     lib.note(bytes=8.0 * group.numel)
     lib.call("fmri_apply_batch", _P(plan["table"]), plan["n"], plan["tiles"], 0, None, 0.0, 0.0, 1.0, None, 0.0, None, 0)

@@ -157,6 +157,18 @@ class _SegmentRecorder:
                 it()
 
 
+_SMALL_GROUP = {}
+
+
+def _small_group(dist):
+    """The second communicator (small messages), created once per process and default group -- not once per step object."""
+    key = id(dist.group.WORLD)
+    if key not in _SMALL_GROUP:
+        _SMALL_GROUP.clear()
+        _SMALL_GROUP[key] = dist.new_group()
+    return _SMALL_GROUP[key]
+
+
 class _Dist:
     """Data-parallel glue (one process per GPU, RCCL): SUM all-reduce of flat gradients / loss scalars and
     the SyncBN statistic exchange.  Inactive (world size 1) unless torch.distributed is initialised."""
@@ -174,7 +186,7 @@ class _Dist:
         # SyncBN sums).  Collectives of one communicator run in issue order on its stream: behind a 44 MB gradient
         # all-reduce that is itself waiting for the side stream's weight gradients, a 40-byte all-reduce of the main
         # stream would stall the whole backward pass (head-of-line blocking); on a second communicator it does not.
-        self.small = dist.new_group() if self.on else None
+        self.small = _small_group(dist) if self.on else None
         self.recorder: Optional[_SegmentRecorder] = None     # set while a step is recorded into graph segments
 
     SMALL = 1 << 16          # elements: at most this many go through the small-message communicator
@@ -514,7 +526,7 @@ class Stage1Step(_GanStepBase):
         pass of the next sub-network instead of after the whole backward (nothing later in the step reads those weights);
         ``apply`` then only updates the encoder."""
         if self.mode in ("dcgan", "vae"):
-            return self._backward_pixel(early_apply)
+            return self._backward_pixel(early_apply, extra_dmu)
         fw, sc, hp, cfg = self.fw, self.sc, self.hp, self.cfg
         B, H, W = fw["B"], fw["H"], fw["W"]
         Z = cfg.latent_dim
@@ -591,8 +603,9 @@ class Stage1Step(_GanStepBase):
         self.dd.all_reduce(eg.grad[:tail])
         self.dd.wait_all()
 
-    def _backward_pixel(self, early_apply: bool):
+    def _backward_pixel(self, early_apply: bool, extra_dmu: Optional[torch.Tensor] = None):
         """Modes 'dcgan' and 'vae' (train_vgan_stage1.py:374-388): the reconstruction term is the pixel nle.
+        ``extra_dmu``: see ``backward`` (mode 'vae' of the Dual step; 'dcgan' does not train the encoder).
 
         dcgan: decoder <- lambda*d nle - (1-lambda)*d(bce_orig + bce_sampled) on [x_tilde ; x_p], discriminator <-
                d(bce_orig + bce_sampled), encoder not trained.
@@ -636,6 +649,8 @@ class Stage1Step(_GanStepBase):
         dhead32 = torch.empty(B, 2 * Z, dtype=torch.float32, device=dev)
         lib.call("fmri_latent_bwd", _P(fw["head32"]), _P(fw["eps"]), _P(dz), Z, 1.0, 1.0, _P(self._slot(S_NP)), B, Z,
                  1.0, None, _P(dhead32), 1)                                  # = nP * dhead_true
+        if extra_dmu is not None:
+            dhead32[:, :Z].addcmul_(extra_dmu, self._slot(S_NP))                # carried at the same device factor nP
         dhead16 = self._renorm(dhead32, sc.enc, self._slot(S_NP), B * self.dd.world)    # S_NE = nP * nE
         eg = self.enc.group
         tail = eg.offsets["fc.0.weight"]
@@ -758,8 +773,16 @@ class CognitiveStep(_GanStepBase):
 
     def __init__(self, cfg: ArchConfig, n_voxels: int, device, stage: int, hp: Optional[GanHyper] = None,
                  scales: Optional[Scales] = None, distributed: bool = False, sync_bn: bool = True,
-                 gate_skip: bool = True):
+                 gate_skip: bool = True, mode: str = "vae-gan"):
+        """``mode``: 'vae-gan' (default) or 'vae' -- the scripts' `--mode vae` (train_vgan_stage2.py:234-238,362-366;
+        train_vgan_stage3.py:370-374): no teacher net (the discriminator's "real" slot is the ground-truth image), the
+        reconstruction term is the PIXEL nle instead of the feature mse, the discriminator loss bce_orig + bce_sampled.
+        Stage II: encoder <- d(KL + nle) through the frozen decoder, discriminator trained (the script's train_dis = False
+        is overwritten two lines later).  Stage III: decoder <- lambda * d nle, discriminator updated only in a step whose
+        gate re-arms both."""
         assert stage in (2, 3)
+        if mode not in ("vae-gan", "vae"):
+            raise ValueError("mode must be 'vae-gan' or 'vae'")
         self.cfg, self.stage, self.n_voxels = cfg, stage, n_voxels
         self.gate_skip = bool(gate_skip)
         self.cog = CognitiveEncoderNet(cfg, n_voxels, device)
@@ -767,9 +790,10 @@ class CognitiveStep(_GanStepBase):
         self.dec.fc_bn.enable_lazy_running()
         self._pre_replay = [self.dec.fc_bn._running_in]      # reloads after an outside write of the buffers only
         self.dis = DiscriminatorNet(cfg, device)
-        self.teacher_enc = EncoderNet(cfg, device) if stage == 2 else None
-        nets = [self.cog, self.dec, self.dis] + ([self.teacher_enc] if stage == 2 else [])
+        self.teacher_enc = EncoderNet(cfg, device) if (stage == 2 and mode != "vae") else None
+        nets = [self.cog, self.dec, self.dis] + ([self.teacher_enc] if self.teacher_enc is not None else [])
         self._init_common(device, hp, scales, distributed, sync_bn, nets)
+        self.mode = mode
         hp = self.hp
         self.opt_enc = _Optim(self.cog.group, "rmsprop", hp.lr, hp.alpha, hp.eps)
         self.opt_dec = _Optim(self.dec.group, "rmsprop", hp.lr, hp.alpha, hp.eps)
@@ -825,7 +849,7 @@ class CognitiveStep(_GanStepBase):
         fmri16 = rows_to_f16(fmri)
         head32, cctx = self.cog.forward(fmri16)
         eps = eps.contiguous().float()
-        if self.stage == 2:
+        if self.teacher_enc is not None:
             # decoder groups in disc_in row order: 0 = teacher reconstruction ("real"), 1 = x_tilde, 2 = x_p
             z16 = torch.empty(3 * B, zp, dtype=torch.float16, device=dev)
             img16 = images_to_nhwc(image)
@@ -863,6 +887,8 @@ class CognitiveStep(_GanStepBase):
         B, H, W, Z = fw["B"], fw["H"], fw["W"], cfg.latent_dim
         dev = fw["disc_in"].device
         fuse = fuse and self.dd.recorder is None
+        if self.mode == "vae":
+            return self._backward_pixel(fuse)
         dlogit16, dfeat16 = self._start_cotangents(fw["feat"], fw["logit32"], B)
         gs = self.gate_skip                  # (see Stage1Step: no gradients for a sub-network the gate does not train)
         if self.stage == 2:
@@ -891,12 +917,52 @@ class CognitiveStep(_GanStepBase):
             self._reduce_async(self.dec.group)
             self.dd.wait_all()
 
+    def _backward_pixel(self, fuse: bool):
+        """mode 'vae' (train_vgan_stage2.py:362-366, train_vgan_stage3.py:370-374): the reconstruction term is the pixel
+        nle, d nle / d x_tilde = x_tilde - x_gt; the discriminator's loss is bce_orig + bce_sampled (no image gradient
+        is needed: nothing upstream of it trains on a discriminator term)."""
+        fw, sc, cfg = self.fw, self.sc, self.cfg
+        B, H, W, Z = fw["B"], fw["H"], fw["W"], cfg.latent_dim
+        d_in = fw["disc_in"]
+        dev = d_in.device
+        gs = self.gate_skip
+        dlogit16 = torch.empty(3 * B, 8, dtype=torch.float16, device=dev)
+        lib.call("fmri_gan_head_bwd_parts", _P(fw["logit32"]), 1, B, _P(dlogit16), 8, sc.a, _P(self._slot(S_NA)),
+                 self._dis_parts())
+        x16, xt16 = d_in[:B], d_in[B:2 * B]
+        if self.stage == 2:
+            ops.begin_grads(self.cog.group, fuse)
+            ops.begin_grads(self.dis.group, fuse, gate=self.flags[0:1] if gs else None)
+        else:
+            ops.begin_grads(self.dec.group, fuse, gate=self.flags[1:2] if gs else None)
+            ops.begin_grads(self.dis.group, fuse, gate=self.flags[0:1] if gs else None)
+        self.dis.backward(fw["sctx"], dlogit16, sc.a, None, sc.b, True, None)
+        self._reduce_async(self.dis.group)
+        # stored = p * nP * (x_tilde - x_gt)
+        cot = axpby(xt16, x16, sc.p, -sc.p, a_dev=self._slot(S_NP), b_dev=self._slot(S_NP))
+        if self.stage == 2:
+            entries = [dict(g=fw["g_tilde"], scale=sc.p, train=False, need_dz=True)]
+            dz = self.dec.backward(fw["dctx"], cot, entries)[0]                  # = nP * dz_true
+            dhead32 = torch.empty(B, 2 * Z, dtype=torch.float32, device=dev)
+            lib.call("fmri_latent_bwd", _P(fw["head32"]), _P(fw["eps"]), _P(dz), Z, 1.0, 1.0, _P(self._slot(S_NP)), B,
+                     Z, 1.0, None, _P(dhead32), 1)
+            dhead16 = self._renorm(dhead32, sc.enc, self._slot(S_NP), B * self.dd.world)   # S_NE = nP * nE
+            self.cog.backward(fw["cctx"], dhead16, sc.enc)
+            self._reduce_async(self.cog.group)
+        else:
+            # the decoder gradients carry nP; the optimizer divides by S_GDEC = nP / lambda (loss_decoder = lambda * nle)
+            entries = [dict(g=fw["g_tilde"], scale=sc.p, train=True)]
+            self.dec.backward(fw["dctx"], cot, entries)
+            self._reduce_async(self.dec.group)
+        self.dd.wait_all()
+
     def apply(self):
         if self.stage == 2:
             self.opt_enc.step(None, clamp=1.0, gdev=self._slot(S_NE))
             self.opt_dis.step(self.flags[0:1], clamp=1.0, gdev=self._slot(S_NA))
         else:
-            self.opt_dec.step(self.flags[1:2], clamp=1.0, gdev=self._slot(S_NA))
+            # (S_GDEC: nA in mode 'vae-gan', nP / lambda in mode 'vae' -- the gate kernel writes it)
+            self.opt_dec.step(self.flags[1:2], clamp=1.0, gdev=self._slot(S_GDEC))
             self.opt_dis.step(self.flags[0:1], clamp=1.0, gdev=self._slot(S_NA))
 
     def step(self, fmri, image, eps, z_p, eps_teacher=None):
@@ -920,7 +986,7 @@ class CognitiveStep(_GanStepBase):
     def named_grads(self):
         s = self.scal.tolist()
         groups = ((("encoder.", self.cog, s[S_NE]), ("discriminator.", self.dis, s[S_NA])) if self.stage == 2 else
-                  (("decoder.", self.dec, s[S_NA]), ("discriminator.", self.dis, s[S_NA])))
+                  (("decoder.", self.dec, s[S_GDEC]), ("discriminator.", self.dis, s[S_NA])))
         out = {}
         for pre, n, f in groups:
             n.group.check_grads_readable()

@@ -257,17 +257,19 @@ class WaeStep(_LatentDiscPhase):
 
 
 class DualStage1Step(Stage1Step, _LatentDiscPhase):
-    """Dual WAE + VAE/GAN Stage-I step, mode 'vae-gan' (train/wae_vgan_stage1.py:284-441): the Stage-I VAE/GAN step
-    plus a WAE latent discriminator (RMSprop) trained on the encoder means, whose penalty gradient is added to the
-    encoder's VAE/GAN gradient.  The encoder runs three times per batch in the script (one pass here, three
+    """Dual WAE + VAE/GAN Stage-I step (train/wae_vgan_stage1.py:284-441; ``mode``: its four loss compositions,
+    :311-364, as in Stage1Step -- 'vae-gan' default, 'beta-vae', 'dcgan' (the encoder is never stepped, :419), 'vae'):
+    the Stage-I VAE/GAN step plus a WAE latent discriminator (RMSprop) trained on the encoder means, whose penalty
+    gradient is added to the encoder's VAE/GAN gradient.  The encoder runs three times per batch in the script (one pass here, three
     running-stat updates) and the decoder three times (z, z_p, mu -- the last only moves BN statistics).
 
     ``torch14_zero_grad=True`` reproduces the pinned torch 1.4: the script's `optimizer_decoder.step()` at :417
     runs on zeroed gradients from the second iteration on, which only decays the decoder's RMSprop state."""
 
     def __init__(self, cfg: ArchConfig, device, hp: Optional[GanHyper] = None, scales: Optional[Scales] = None,
-                 lam: float = 1.0, distributed: bool = False, sync_bn: bool = True, torch14_zero_grad: bool = True):
-        super().__init__(cfg, device, hp, scales, distributed, sync_bn)
+                 lam: float = 1.0, distributed: bool = False, sync_bn: bool = True, torch14_zero_grad: bool = True,
+                 mode: str = "vae-gan"):
+        super().__init__(cfg, device, hp, scales, distributed, sync_bn, mode=mode)
         hp = self.hp
         self.lam = lam
         self.torch14 = torch14_zero_grad

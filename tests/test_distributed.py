@@ -444,3 +444,35 @@ def test_two_rank_other_steps_equal_single_process_global_batch(kind):
             assert abs(sdn[k] - v) < 3e-3 * v + slack + 1e-6, (kind, rank, k, sdn[k], v)
     for k in res[0][2]:
         assert abs(res[0][2][k] - res[1][2][k]) <= 1e-6 * abs(res[0][2][k]) + 1e-9, (kind, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.selfcheck
+@pytest.mark.parametrize("extra", [[], ["--sync-bn"]])
+def test_bench_two_rank_control_flow_rehearsal(extra, tmp_path):
+    """bench.py's multi-process control flow (what the driver launches for N > 1) with two ranks sharing this one GPU,
+    gloo as the collective backend: launch-mode probe decided collectively, barrier + max-over-ranks timing, one JSON
+    line from rank 0 with the whole-job aggregate, finite losses, exit code 0.  (Two GPUs over RCCL are not available
+    to the tests; the data path of the ranks is covered by the 2-rank step tests above.)"""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, FMRI_REHEARSE_ON_ONE_GPU="1", FMRI_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "8",
+           "--warmup", "3", "--batch", "64", "--no-cpu-baseline", "--no-hbm-rows", "--no-pmc"] + extra
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 8 and out["warmup"] == 3 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 128 and out["config"]["batch_per_gpu"] == 64
+    assert out["config"]["parallelism"] == ("dp2-syncbn" if extra else "dp2-localbn")
+    assert out["losses_finite"] is True and out["value"] > 0
+    assert abs(out["value"] - 128 * 8 / (out["ms_per_step"] * 8e-3)) < 0.01 * out["value"]      # whole-job aggregate

@@ -852,6 +852,16 @@ FULL_SIZE = [
     ("deconv", 256, 128, 2, 16, 1, 512),  # decoder.conv.1
     ("deconv", 128, 32, 2, 32, 1, 512),   # decoder.conv.2        (igemm_tc32)
     ("conv", 32, 3, 1, 64, 0, 512),       # decoder.conv.3        (igemm_narrow)
+    # the 128-px geometry of BASELINE configs[4] (ArchConfig.px128: fc_input 16, stride_gan 2) at its per-GPU batch 128
+    # (1024 over 8 GPUs); the discriminator behind conv.0 has the 64-px shapes above
+    ("conv", 3, 64, 2, 128, 0, 128),      # encoder.conv.0 @128 px
+    ("conv", 64, 128, 2, 64, 0, 128),     # encoder.conv.1 @128 px
+    ("conv", 128, 256, 2, 32, 0, 128),    # encoder.conv.2 @128 px
+    ("deconv", 256, 256, 2, 16, 1, 128),  # decoder.conv.0 @128 px
+    ("deconv", 256, 128, 2, 32, 1, 128),  # decoder.conv.1 @128 px
+    ("deconv", 128, 32, 2, 64, 1, 128),   # decoder.conv.2 @128 px
+    ("conv", 32, 3, 1, 128, 0, 128),      # decoder.conv.3 @128 px
+    ("conv", 3, 32, 2, 128, 0, 384),      # discriminator.conv.0 @128 px (stride_gan = 2), 3 x 128 images
 ]
 
 

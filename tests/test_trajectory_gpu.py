@@ -3,7 +3,7 @@ train/train_vgan_stage1.py:311-445, not one step).
 
   * 150 steps at the benchmark's batch 256 on bench.py's rotating synthetic batches stay finite in every launch mode
     (two streams, one stream, recorded forward), weights and optimizer state included -- before round 5 roughly a third of
-    such runs ended with NaN losses: the latent's sigma = exp(0.5 logvar) left fp16's range (DESIGN 8).
+    such runs ended with NaN losses: the latent's sigma = exp(0.5 logvar) left fp16's range (DESIGN 4a).
   * 50 free-running steps at batch 32 next to the fp32 CPU oracle from the same weights and data: the same equilibrium-gate
     decisions and losses inside a stated envelope for as long as two arithmetic models of a GAN can be expected to agree.
   * the one-step parity repeated ALONG the oracle's trajectory (engine re-loaded with the oracle's weights, BatchNorm
@@ -139,7 +139,7 @@ def test_stage1_b32_free_running_next_to_the_oracle():
     # decision they are two different training runs; the bounds below hold UP TO that step and are 1.5-2x what the runs in
     # profiles/r05_trajectory_b32.log measured (same gate decisions for the first 45-50 steps; first six steps <= 1.9e-2;
     # nle <= 9.4e-2, mse <= 0.21, kl inside a factor 1.9 -- the largest kl ratios sit on the steps where the ORACLE's own
-    # KL jumps 2-3x from one step to the next, the latent excursions of DESIGN 8; the bce sums, which pass through zero
+    # KL jumps 2-3x from one step to the next, the latent excursions of DESIGN 4a; the bce sums, which pass through zero
     # when the discriminator wins, inside a factor 3 or 0.1 nat per sample).
     assert all(rows[0][2][k] < 1e-3 for k in LOSSES), rows[0][2]
     assert first_gate_split >= 25, f"equilibrium gate decisions differ already at step {first_gate_split}"

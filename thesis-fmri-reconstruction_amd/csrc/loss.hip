@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(const float* __restrict
 
 // ---- range-safe latent (fmri_latent_fwd_ranged).  sigma = exp(0.5 logvar) leaves fp16's range at logvar > 22.2, which
 // an fp32 run survives (the reference's arithmetic overflows at logvar > 88.7) and a training run does reach: one
-// outlier row of a BatchNorm1d batch is enough (DESIGN 8).  The fp16 rows the decoder's first GEMM reads are therefore
+// outlier row of a BatchNorm1d batch is enough (DESIGN 4a).  The fp16 rows the decoder's first GEMM reads are therefore
 // stored as s * z with s = 2^-k the largest power of two <= 1 that brings max |z| of the batch under `cap` -- s = 1, and
 // bit-identical rows, whenever max |z| <= cap.  The BatchNorm1d behind that GEMM is invariant under the scaling once its
 // eps is scaled by s^2 (bn_finalize_channel), the weight gradient is exact (cotangent / s times input * s) and the data

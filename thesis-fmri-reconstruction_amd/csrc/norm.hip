@@ -47,7 +47,7 @@ static RowGeom row_geometry(int M, int C, int max_gy) {
 // (...) is the one place of the backward pass where a healthy cotangent is multiplied by an unbounded factor: a feature
 // whose batch variance is tiny has rstd up to 1 / sqrt(eps) = 316 -- and 1 / (s sqrt(eps)) behind a range-scaled latent
 // batch (bn_finalize_channel) -- so a few of the 8 M results of a step that follows a latent excursion cross fp16's
-// range (measured: 1-6 values per such step, DESIGN 8).  An inf there turns the whole step into NaN (inf - inf in the
+// range (measured: 1-6 values per such step, DESIGN 4a).  An inf there turns the whole step into NaN (inf - inf in the
 // GEMMs that consume it); the saturated value is a clipped gradient for the handful of weights it touches.
 __device__ __forceinline__ half_t sat16(float v) { return (half_t)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f); }
 

@@ -234,7 +234,9 @@ def family_table(prof, steps, key=_family_of):
         if f["flops"] > 0:
             row["tflops"] = round(f["flops"] / (f["ms"] * 1e-3) / 1e12, 1)
             row["frac_of_mfma_peak"] = round(row["tflops"] / MFMA_PEAK_TFLOPS, 4)
-        elif f["bytes"] > 0 and f["ms_b"] > 0:
+        if f["bytes"] > 0 and f["ms_b"] > 0:
+            # (GEMM families carry both: the small-channel and dense ones -- K = 75, N = 3, M = batch rows -- are priced
+            # by their algorithmic bytes, input + output + weights once, not by the MFMA peak)
             row["gb_s"] = round(f["bytes"] / (f["ms_b"] * 1e-3) / 1e9, 1)
             row["frac_of_hbm_peak"] = round(row["gb_s"] / HBM_PEAK_GBS, 4)
         rows.append((row, f))
@@ -342,17 +344,26 @@ def hbm_rows(dev, B):
     P = lib.ptr
     out = {}
 
-    def timed(fn, nbytes, reps=20):
+    def timed(fn, nbytes, reps=20, inner=10):
+        """GPU time per call: `inner` calls recorded into a HIP graph and replayed `reps` times (a loop of eagerly issued
+        Python calls measures the host for kernels of a few microseconds: the dense layer's two launches cost ~15 us of
+        Python and ~14 us of GPU)."""
         for _ in range(3):
             fn()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(inner):
+                fn()
+        g.replay()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
-            fn()
+            g.replay()
         e1.record()
         torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / reps
+        ms = e0.elapsed_time(e1) / (reps * inner)
         return dict(gb_s=round(nbytes / ms / 1e6, 1), frac_of_peak=round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 3),
                     us=round(ms * 1e3, 1), mbytes=round(nbytes / 1e6, 1))
     V = 4096

@@ -186,7 +186,10 @@ class _Dist:
         # SyncBN sums).  Collectives of one communicator run in issue order on its stream: behind a 44 MB gradient
         # all-reduce that is itself waiting for the side stream's weight gradients, a 40-byte all-reduce of the main
         # stream would stall the whole backward pass (head-of-line blocking); on a second communicator it does not.
-        self.small = _small_group(dist) if self.on else None
+        # FMRI_SMALL_COMM=off: everything on the default communicator (collectives then run in issue order, the order of
+        # the program on every rank) -- the fallback should two communicators driven from two streams ever misbehave on a
+        # real multi-GPU node; costs the head-of-line blocking described above
+        self.small = _small_group(dist) if (self.on and os.environ.get("FMRI_SMALL_COMM") != "off") else None
         self.recorder: Optional[_SegmentRecorder] = None     # set while a step is recorded into graph segments
 
     SMALL = 1 << 16          # elements: at most this many go through the small-message communicator

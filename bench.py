@@ -170,7 +170,7 @@ def pmc_traffic(family):
     arguments), launch-weighted over its instantiations, from the committed rocprofv3 PMC passes of this same command
     (tools/pmc_traffic.py); None when no committed pass holds the family."""
     want = family.replace(" ", "")
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
         try:
             with open(path) as f:

@@ -208,10 +208,14 @@ def synth_batch(batch: int, cfg: ArchCfg, n_voxels: int = 0, seed: int = 1234, s
 # The ReLU masks of such a run are the engine's masks, so its gradients can be compared tightly; the default (False)
 # is the plain fp32 restatement that the golden vectors pin.
 STORAGE16 = False
+# tags of storage points kept in fp32 under STORAGE16 (tests/probe_storage16_levers.py: which 16-bit tensors carry the
+# after-one-update distance from fp32): "rec_feat" (the raw conv features the 'REC' call returns), "images" (decoder
+# outputs / the discriminator's input batch), "disc_raw" (every raw convolution output of the discriminator)
+STORAGE16_KEEP32 = frozenset()
 
 
-def _q(t: Tensor) -> Tensor:
-    if not STORAGE16:
+def _q(t: Tensor, tag: str = None) -> Tensor:
+    if not STORAGE16 or (tag is not None and tag in STORAGE16_KEEP32):
         return t
     return t + (t.detach().half().float() - t.detach())
 
@@ -270,16 +274,17 @@ def decoder_fwd(P: State, pre: str, z: Tensor, cfg: ArchCfg, train: bool = True)
                                   output_padding=1 if cfg.output_pad_dec[i] else 0))
         h = _q(_relu(_bn(P, f"{pre}conv.{i}.bn.", h, train)))
     h = F.conv2d(h, _w(P, f"{pre}conv.3.0.weight"), P[f"{pre}conv.3.0.bias"], 1, 2)
-    return _q(torch.tanh(h))
+    return _q(torch.tanh(h), "images")
 
 
 def discriminator_fwd(P: State, pre: str, x_orig: Tensor, x_pred: Tensor, x_samp: Tensor, mode: str,
                       cfg: ArchCfg, train: bool = True, recon_level: int = 3):
     """Discriminator.forward, models/vae_gan.py:163-183 (mode 'REC' or 'GAN')."""
-    h = _q(torch.cat((x_orig, x_pred, x_samp), 0))
+    h = _q(torch.cat((x_orig, x_pred, x_samp), 0), "images")
     h = _q(_relu(F.conv2d(h, _w(P, f"{pre}conv.0.0.weight"), P[f"{pre}conv.0.0.bias"], cfg.stride_gan, 2)))
     for i in (1, 2, 3):
-        raw = _q(F.conv2d(h, _w(P, f"{pre}conv.{i}.conv.weight"), None, cfg.stride, cfg.padding))
+        raw = F.conv2d(h, _w(P, f"{pre}conv.{i}.conv.weight"), None, cfg.stride, cfg.padding)
+        raw = _q(raw, "rec_feat" if i == recon_level and "rec_feat" in STORAGE16_KEEP32 else "disc_raw")
         if mode == "REC" and i == recon_level:
             # reference still runs bn+relu on this block before returning (vae_gan.py:25-30)
             _bn(P, f"{pre}conv.{i}.bn.", raw, train)

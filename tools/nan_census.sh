@@ -23,3 +23,6 @@ run gate_skip    X=1 -- --mode eager --gate-skip --diag
 run det_two      X=1 -- --mode eager --det --repeats 3 --diag
 run snap_two     X=1 -- --mode eager --diag --snap
 run snap_hybrid  X=1 -- --mode hybrid --diag --snap
+run wl_stage2     X=1 -- --workload stage2
+run wl_dual1      X=1 -- --workload dual1
+run wl_stage3px   X=1 -- --workload stage3_px128

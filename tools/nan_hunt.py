@@ -154,7 +154,39 @@ class Sentinel:
         return False
 
 
+def run_other(a, dev, rep):
+    """The other bench workloads (stage2, dual1, stage3_px128): bench.py's own builders, eager steps, finiteness of the
+    loss block and of every parameter / optimizer-state buffer at the end."""
+    import bench
+    from fmri_hip import ops
+    metric, unit, desc, wl_batch, builder = bench.WORKLOADS[a.workload]
+    st, run_i, _, _ = builder(dev, a.batch or wl_batch, 0, False, False)
+    n = 4 if a.workload == "stage3_px128" else 10
+    rec = []
+    for i in range(a.steps):
+        run_i(i)
+        rec.append(st.scal[:n].clone())
+    ops.join_side()
+    torch.cuda.synchronize()
+    R = torch.stack(rec).cpu().numpy()
+    fin = np.isfinite(R).all(1)
+    bad_state = []
+    for name in ("enc", "img_enc", "cog", "dec", "dis", "wd", "teacher_enc"):
+        net = getattr(st, name, None)
+        if net is not None and not torch.isfinite(net.group.data).all():
+            bad_state.append(name)
+    for name in ("opt_enc", "opt_dec", "opt_dis", "opt_wd"):
+        o = getattr(st, name, None)
+        if o is not None and not (torch.isfinite(o.s1).all() and (o.s2 is None or torch.isfinite(o.s2).all())):
+            bad_state.append(name)
+    return dict(rep=rep, workload=a.workload, mode="eager", side=ops._SIDE["on"], det=ops.deterministic(), steps=a.steps,
+                finite=bool(fin.all()) and not bad_state, first_bad_step=None if fin.all() else int(np.argmin(fin)),
+                nonfinite_state=bad_state, checksum="-", last=[float("%.5g" % v) for v in R[-1]])
+
+
 def run_repeat(a, dev, rep):
+    if a.workload != "stage1":
+        return run_other(a, dev, rep)
     from fmri_hip import ops
     from fmri_hip.steps import (S_GDEC, S_NA, S_NB, S_NE)
     st, xs, nz = build(dev, a.batch, a.gate_skip)
@@ -237,7 +269,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=150)
     ap.add_argument("--repeats", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--batch", type=int, default=0, help="0 = 256 (stage1) / the workload's own")
+    ap.add_argument("--workload", choices=("stage1", "stage2", "dual1", "stage3_px128"), default="stage1")
     ap.add_argument("--pre", type=int, default=20, help="eager steps before a recording (hybrid / graph modes)")
     ap.add_argument("--mode", choices=("eager", "hybrid", "graph"), default="eager")
     ap.add_argument("--det", action="store_true")
@@ -246,6 +279,8 @@ def main():
     ap.add_argument("--gate-skip", action="store_true", help="engine default (bench headline runs with it off)")
     ap.add_argument("--tag", default="")
     a = ap.parse_args()
+    if a.workload == "stage1" and not a.batch:
+        a.batch = 256
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     from fmri_hip import lib, ops

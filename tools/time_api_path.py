@@ -33,6 +33,8 @@ torch.cuda.synchronize(); t0 = time.perf_counter(); n = 20
 for _ in range(n): l = step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
 print(f"API path (literal loop body, B={B}): {1e3 * dt:.2f} ms/step  {B / dt:.0f} images/s  loss_encoder {float(l.detach()):.1f}", flush=True)
+if os.environ.get("API_ONLY") == "1":      # (under rocprofv3: the kernel table then holds the API path's launches only)
+    sys.exit(0)
 from fmri_hip.params import ArchConfig
 from fmri_hip.steps import Stage1Step
 st = Stage1Step(ArchConfig.px64(), dev); st.load_recipe(0, False)

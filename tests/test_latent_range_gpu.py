@@ -208,3 +208,31 @@ def test_stage1_step_survives_a_latent_excursion():
     for k, v in sd.items():
         if v.is_floating_point():
             assert torch.isfinite(v).all(), k
+
+
+def test_batchnorm_backward_saturates_finite_overflow_and_keeps_nan():
+    """`sat16` of csrc/norm.hip: a BatchNorm-backward result beyond fp16's range is stored as +-65504, not inf (one inf
+    there turned a whole step into NaN) -- and a NaN cotangent stays a NaN (nothing is hidden)."""
+    from fmri_hip.ops import BatchNorm
+    from test_kernels_gpu import _G
+    M, C = 64, 64
+    torch.manual_seed(9)
+    x = torch.randn(M, C)
+    x[:, 5] = 1.0 + 1e-4 * torch.randn(M)          # a nearly constant feature: rstd ~ 1 / sqrt(1e-8 + 1e-5) = 316
+    gam = torch.ones(C)
+    gam[5] = 50.0
+    g = _G({"bn.weight": gam, "bn.bias": torch.zeros(C)})
+    g.bufs = {"bn.running_mean": torch.zeros(C, device=DEV), "bn.running_var": torch.ones(C, device=DEV),
+              "bn.num_batches_tracked": torch.zeros((), dtype=torch.int64, device=DEV)}
+    bn = BatchNorm(g, "bn.", C)
+    xs = x.half().to(DEV)
+    _, sv = bn.forward(xs, relu=False, updates=0)
+    dy = (torch.randn(M, C) * 100.0).half().to(DEV)          # gamma * rstd * g ~ 50 * 316 * 100 >> 65504
+    dy[3, 9] = float("nan")
+    dx, _ = bn.backward(xs, dy, sv, False, None)
+    col = dx[:, 5].float()
+    assert torch.isfinite(col).all() and col.abs().max().item() == 65504.0
+    assert torch.isnan(dx[:, 9].float()).all()               # the NaN went through the column's batch sums
+    ok = torch.ones(C, dtype=torch.bool)
+    ok[5] = ok[9] = False
+    assert torch.isfinite(dx[:, ok].float()).all()

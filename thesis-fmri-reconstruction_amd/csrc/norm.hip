@@ -49,7 +49,10 @@ static RowGeom row_geometry(int M, int C, int max_gy) {
 // batch (bn_finalize_channel) -- so a few of the 8 M results of a step that follows a latent excursion cross fp16's
 // range (measured: 1-6 values per such step).  An inf there turns the whole step into NaN (inf - inf in the
 // GEMMs that consume it); the saturated value is a clipped gradient for the handful of weights it touches.
-__device__ __forceinline__ half_t sat16(float v) { return (half_t)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f); }
+// A NaN stays a NaN (v_med3_f32 would return one of the bounds for it): only finite overflow is clipped.
+__device__ __forceinline__ half_t sat16(float v) {
+    return (half_t)(v == v ? __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f) : v);
+}
 
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const half_t* __restrict__ x, const half_t* __restrict__ dy,

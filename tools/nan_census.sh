@@ -4,6 +4,7 @@
 out=${1:-gpurun_out/census}; steps=${2:-150}; reps=${3:-10}; shift 3
 arms="${*:-two_stream one_stream hybrid no_fused no_transpose gate_skip det_two snap_two}"
 mkdir -p "$out"
+{ hostname; rocm-smi --showuniqueid 2>/dev/null | grep -i "GPU\[" | head -1; } > "$out/box.txt" 2>&1; cat "$out/box.txt" >&2
 run() {  # tag, env assignments..., -- tool args
   tag=$1; shift
   envs=(); while [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift

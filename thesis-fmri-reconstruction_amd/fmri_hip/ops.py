@@ -293,9 +293,14 @@ _EPI_ACT = os.environ.get("FMRI_EPI_ACT") != "off"
 # window-resident wgrad kernel: on/off, resident-block target (2 per CU), largest split count still written as slabs
 _WW_ON = os.environ.get("FMRI_WGRAD_WIN") != "off"
 _WN_ON = os.environ.get("FMRI_WGRAD_NARROW") != "off"
-# resident-block target: 2 blocks per CU when the kernel has the GPU to itself (one stream, recorded graphs); 1 per CU
-# when it runs on the side stream beside the main stream's kernels (measured 8.18 vs 8.26 ms per step)
+# block budget per tile group (FMRI_WW_BLOCKS overrides): one 8-wave block per CU (256) when the kernel has the GPU to
+# itself; 160 when it runs on the side stream beside the main stream's kernels -- its blocks hold a CU (144 KB of LDS) for
+# their whole K range, and a main-stream kernel that finds no free CU waits for one: leaving ~96 CUs to the main stream
+# measured 6.39-6.41 ms per step against 6.48-6.50 (two boxes, two repeats each; 224 / 192: no gain, 128: 6.40-6.42,
+# <= 112: 6.8+; tools/probes/ab_ww_blocks.sh).  Deterministic mode keeps 256 in every launch mode, so that its results
+# stay bit-identical between one-stream, two-stream and recorded steps.
 _WW_BLOCKS = int(os.environ.get("FMRI_WW_BLOCKS", "0"))
+_WW_SIDE_BLOCKS = 160
 _WW_SLABS = int(os.environ.get("FMRI_WW_SLABS", "24"))
 
 
@@ -407,7 +412,7 @@ def run_wgrad(P, Q, N, Yc, Xc, A, Hq, Wq, Bc, k, stride, pad, flip=0, flops=0.0,
         # window-resident kernel (csrc/wgrad_win.hip): blocks = 32-channel column blocks x 128-row blocks x 4 parity
         # planes x splits over the 8x8 pixel tiles; every split stores its own slab, unpack_grad sums them
         groups = (Bc // 32) * (apad // 128)
-        budget = _WW_BLOCKS or 256              # one 8-wave block per CU (csrc/wgrad_win.hip)
+        budget = _WW_BLOCKS or (_WW_SIDE_BLOCKS if (_SIDE["on"] and not _DET["on"]) else 256)
         splits = max(4, budget // groups)                               # block budget per group over the 4 planes
         nslabs = lib.load().fmri_wgrad_slabs(N, Yc, Xc, k, pad, splits)
         slabs = nslabs <= _WW_SLABS or _DET["on"]                       # few splits: per-split slabs, else atomics

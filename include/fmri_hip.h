@@ -319,6 +319,8 @@ int fmri_latent_fwd_ranged(const float* head, const float* eps, int B, int Z, in
                            float* kl_total, int sample, float* z32, float* zmax, float* zscale, float cap, int phase,
                            void* stream);
 int fmri_rows_absmax(const float* x, int64_t n, float* zmax, void* stream);
+/* host only: the scale phase 2 derives from a batch maximum (the same function the kernel evaluates) */
+float fmri_latent_range_scale(float zmax, float cap);
 int fmri_latent_bwd(const float* head, const float* eps, const float* dz, int ldz, float dz_unscale, float kl_w,
                     const float* kl_dev, int B, int Z, float out_scale, void* dhead16, float* dhead32, int sample,
                     void* stream);

@@ -77,6 +77,35 @@ def test_argument_validation_without_gpu(lib):
     assert L.load().fmri_bn_ws_floats(786432, 128) >= 2 * 128
 
 
+def test_latent_range_scale_and_its_argument_checks(lib):
+    """Host side of the range-safe latent path (fmri_latent_fwd_ranged): the scale a batch maximum maps to is
+    the LARGEST power of two <= 1 that brings it under the cap -- 1 inside the cap (a healthy batch is stored unchanged)
+    and for a non-finite maximum (inf / NaN rows are carried on, not hidden) -- and bad arguments are refused before
+    anything is enqueued."""
+    import math
+    cap = 256.0
+    f = lambda m: lib.fmri_latent_range_scale(ctypes.c_float(m), ctypes.c_float(cap))
+    for m in (0.0, 1e-30, 1.0, 255.99, 256.0):
+        assert f(m) == 1.0, m
+    for m in (256.0001, 300.0, 511.9, 512.0, 512.1, 65504.0, 9.4e4, 1e9, 2e20):
+        s = f(m)
+        assert s < 1.0 and math.log2(s) == int(math.log2(s)), (m, s)
+        assert np.float32(m) * np.float32(s) <= cap < np.float32(m) * np.float32(s) * 2, (m, s)
+    assert f(1e38) == 2.0 ** -60                       # capped: eps * s^2 must stay a normal fp32 number
+    assert f(float("inf")) == 1.0 and f(float("nan")) == 1.0
+    z = ctypes.c_void_p(16)
+    L = lib
+    # phase out of range, missing scratch / maximum, zp < Z, non-positive cap in phase 2
+    assert L.fmri_latent_fwd_ranged(z, z, 4, 128, 128, z, None, None, 1, z, z, z, cap, 0, None) == -1
+    assert L.fmri_latent_fwd_ranged(z, z, 4, 128, 128, z, None, None, 1, None, z, z, cap, 3, None) == -1
+    assert L.fmri_latent_fwd_ranged(z, z, 4, 128, 128, z, None, None, 1, z, None, z, cap, 3, None) == -1
+    assert L.fmri_latent_fwd_ranged(z, z, 4, 128, 120, z, None, None, 1, z, z, z, cap, 3, None) == -1
+    assert L.fmri_latent_fwd_ranged(z, z, 4, 128, 128, z, None, None, 1, z, z, z, 0.0, 2, None) == -1
+    assert L.fmri_latent_fwd_ranged(None, z, 4, 128, 128, z, None, None, 1, z, z, z, cap, 1, None) == -1     # phase 1 needs the heads
+    assert L.fmri_rows_absmax(None, 16, z, None) == -1
+    assert L.fmri_sumsq_f64(z, 16, ctypes.c_void_p(12), 1, None) == -1                                      # misaligned double
+
+
 def _scanner():
     import importlib.util
     spec = importlib.util.spec_from_file_location("scan_store_hazard", os.path.join(ROOT, "tools", "scan_store_hazard.py"))

@@ -931,6 +931,7 @@ int fmri_latent_fwd_ranged(const float* head, const float* eps, int B, int Z, in
     return latent_ranged_launch(head, eps, B, Z, zp, (half_t*)z16, kl_rows, kl_total, sample, z32, zmax, zscale, cap, phase,
                                 S(stream));
 }
+float fmri_latent_range_scale(float zmax, float cap) { return latent_range_scale_host(zmax, cap); }
 int fmri_rows_absmax(const float* x, int64_t n, float* zmax, void* stream) {
     if (!x || !zmax || n < 1) return FMRI_E_BADARG;
     return rows_absmax_launch(x, n, zmax, S(stream));

@@ -163,6 +163,7 @@ int latent_ranged_launch(const float* head, const float* eps, int B, int Z, int 
                          float* kl_total, int sample, float* z32, float* zmax, float* zscale, float cap, int phase,
                          hipStream_t st);
 int rows_absmax_launch(const float* x, int64_t n, float* zmax, hipStream_t st);
+float latent_range_scale_host(float zmax, float cap);
 int latent_bwd_launch(const float* head, const float* eps, const float* dz, int ldz, float dz_unscale, float kl_w,
                       const float* kl_dev, int B, int Z, float out_scale, half_t* dhead16, float* dhead32, int sample,
                       hipStream_t st);

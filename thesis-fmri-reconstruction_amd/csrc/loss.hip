@@ -134,12 +134,13 @@ __global__ __launch_bounds__(256) void rows_absmax_kernel(const float* __restric
         atomicMax((unsigned int*)zmax, __float_as_uint(fmaxf(fmaxf(shm[0], shm[1]), fmaxf(shm[2], shm[3]))));
 }
 
-__device__ __forceinline__ float range_scale(float m, float cap) {
+__host__ __device__ __forceinline__ float range_scale(float m, float cap) {
     // largest power of two s <= 1 with m * s <= cap; 1 for a non-finite maximum (the rows then carry inf / NaN on, as
     // the reference's arithmetic does) -- at most 2^-60, so that eps * s^2 stays a normal fp32 number
     if (!(m > cap) || m > 3.0e38f) return 1.f;
     int e;
-    (void)frexpf(m / cap, &e);                   // m / cap = f * 2^e, f in [0.5, 1)  ->  m * 2^-e <= cap
+    const float f = frexpf(m / cap, &e);         // m / cap = f * 2^e, f in [0.5, 1)  ->  m * 2^-e <= cap
+    if (f == 0.5f) --e;                          // an exact power of two: m * 2^-(e-1) == cap
     return ldexpf(1.f, -(e > 60 ? 60 : e));
 }
 
@@ -544,6 +545,7 @@ int latent_ranged_launch(const float* head, const float* eps, int B, int Z, int 
                            zp, z16, (const float*)zmax, zscale, cap);
     return LAUNCH_OK();
 }
+float latent_range_scale_host(float zmax, float cap) { return range_scale(zmax, cap); }
 int rows_absmax_launch(const float* x, int64_t n, float* zmax, hipStream_t st) {
     hipLaunchKernelGGL(rows_absmax_kernel, dim3(nblk(n, 256)), dim3(256), 0, st, x, n, zmax);
     return LAUNCH_OK();

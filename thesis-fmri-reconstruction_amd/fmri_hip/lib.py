@@ -115,7 +115,7 @@ EP_AFFINE_APPLIED = 0x20000000
 
 
 EXPORTS = sorted(list(_SIGS) + ["fmri_version", "fmri_last_error_string", "fmri_test_fastdiv", "fmri_bn_ws_floats",
-                             "fmri_bn_fold_scratch_floats", "fmri_resize_coeffs"])
+                             "fmri_bn_fold_scratch_floats", "fmri_resize_coeffs", "fmri_latent_range_scale"])
 
 _lib = None
 
@@ -145,6 +145,8 @@ def load():
     lib.fmri_bn_fold_scratch_floats.argtypes = [_i]
     lib.fmri_resize_coeffs.restype = _i
     lib.fmri_resize_coeffs.argtypes = [_i, _i, _p, _p, _i]
+    lib.fmri_latent_range_scale.restype = _f
+    lib.fmri_latent_range_scale.argtypes = [_f, _f]
     _lib = lib
     return lib
 

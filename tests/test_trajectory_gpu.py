@@ -109,8 +109,9 @@ def _sd_for_engine(P):
     return {k: (v.detach().reshape(()) if k.endswith("num_batches_tracked") else v.detach().clone()) for k, v in P.items()}
 
 
-def test_stage1_b32_next_to_the_oracle_free_running_and_reloaded():
-    """ONE 25-step run of the fp32 CPU oracle at batch 32 on bench.py's data (~4.5 s per step on the GPU box's host),
+def test_stage1_b32_next_to_the_oracle_free_running_and_reloaded(deterministic):
+    """(Deterministic reductions: a free-running comparison amplifies last-bit differences, and the test should give the same
+    verdict on every run.)  ONE 25-step run of the fp32 CPU oracle at batch 32 on bench.py's data (~4.5 s per step on the GPU box's host),
     two engines beside it:
 
     free-running   same initial weights, same batches, never re-synchronised: the equilibrium-gate decisions are the
@@ -197,8 +198,8 @@ def test_stage1_b32_next_to_the_oracle_free_running_and_reloaded():
 
 
 @pytest.mark.parametrize("kind", ["stage2", "stage3", "stage2-vae", "dual1", "wae1", "stage1-px100", "stage1-betavae"])
-def test_other_steps_free_running_next_to_the_oracle(kind):
-    """Eight free-running steps at batch 8 of the other fused steps (Stage II / III of the cognitive VAE/GAN, Stage II in the
+def test_other_steps_free_running_next_to_the_oracle(deterministic, kind):
+    """(Deterministic reductions, as above.)  Eight free-running steps at batch 8 of the other fused steps (Stage II / III of the cognitive VAE/GAN, Stage II in the
     scripts' `--mode vae`, the Dual WAE + VAE/GAN step, WAE Stage I with Adam) beside the fp32 oracle from the same recipe
     weights and the same per-step noise: every logged loss finite, the equilibrium-gate decisions the oracle's, the
     first-step losses at 1e-3 and the following ones inside the after-k-updates envelope the first-step tests of these
